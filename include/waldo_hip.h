@@ -1,0 +1,119 @@
+/*
+ * waldo_hip.h -- C ABI of the MI355X (gfx950) WIF warp/composite hot path.
+ *
+ * Drop-in boundary for the operator layer of 16lemoing/waldo that the hot path lives in
+ * (reference files cited per entry point; paths relative to the reference root).  Every entry
+ * point is a stream-ordered launcher:
+ *   - plain pointers and sizes only (no torch types); all tensors are fp32, contiguous, in the
+ *     layout stated below; index tensors are int32/int64 as stated;
+ *   - the CALLER owns and allocates every buffer (inputs, outputs, workspaces); the library never
+ *     allocates or frees device memory and never synchronises;
+ *   - kernels are launched on `stream` (a hipStream_t passed as void*) of the CURRENT device;
+ *   - returns 0 on success, a negative WALDO_E* code otherwise; no C++ exception crosses the ABI;
+ *     waldo_last_error_string() gives the message of the last failure on the calling thread;
+ *   - re-entrant: no global mutable state except the thread-local error string.
+ *
+ * Build: hipcc --offload-arch=gfx950 -shared -fPIC (see waldo_amd/build.py).
+ */
+#ifndef WALDO_HIP_H
+#define WALDO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WALDO_OK 0
+#define WALDO_EINVAL (-1)  /* bad shape / null pointer / unsupported size */
+#define WALDO_ELAUNCH (-2) /* hipLaunch / runtime error */
+
+typedef void* waldo_stream_t; /* hipStream_t */
+
+/* ABI version: major*1000 + minor. */
+int waldo_version(void);
+const char* waldo_last_error_string(void);
+/* Largest layer count L the fused composite kernels accept. */
+int waldo_max_layers(void);
+
+/* ---------------------------------------------------------------------------------------
+ * A2. Thin-plate-spline grid synthesis -- replaces TPSWarp.forward
+ *     (models/modules/warp.py:49-55).  K3 = N + 3.
+ *   mapping[b] = inverse_kernel (K3,K3) @ [src_pts[b] (N,2); 0 (3,2)]          (warp.py:52-53)
+ *   grid[b,p]  = sum_k basis_t[k,p] * mapping[b,k]                              (warp.py:54)
+ * basis_t is the reference buffer `tgt_grid_repr` (HW,K3) stored TRANSPOSED as (K3,HW) so that
+ * a wavefront reads 64 consecutive pixels of one basis function in one coalesced request.
+ * ------------------------------------------------------------------------------------- */
+int waldo_tps_mapping_fwd(const float* inverse_kernel, const float* src_pts, float* mapping,
+                          int64_t B, int N, waldo_stream_t stream);
+/* grad_src_pts[b,n] = sum_r inverse_kernel[r,n] * grad_mapping[b,r]  (rows n < N only) */
+int waldo_tps_mapping_bwd(const float* inverse_kernel, const float* grad_mapping,
+                          float* grad_src_pts, int64_t B, int N, waldo_stream_t stream);
+/* grid (B,HW,2) */
+int waldo_tps_grid_fwd(const float* basis_t, const float* mapping, float* grid, int64_t B,
+                       int64_t HW, int K3, waldo_stream_t stream);
+/* grad_mapping (B,K3,2) is OVERWRITTEN (the launcher zero-fills it on `stream` first). */
+int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid, float* grad_mapping,
+                       int64_t B, int64_t HW, int K3, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A4/A5. Bilinear backward warp -- replaces F.grid_sample(x + delta, grid) - delta with the
+ *     defaults (bilinear, zeros, align_corners=False) as used by Warper.obj_to_output /
+ *     bg_to_output / obj_from_input / bg_from_input (models/nets/lvd.py:502-559).
+ *   input (Nin,C,Hi,Wi), grid (N,Ho,Wo,2), output (N,C,Ho,Wo).
+ *   Input batch broadcast (the reference's .expand over T, lvd.py:544,555):
+ *       n_in = (n / outer_div) * inner + (n % inner);  pass outer_div = inner = N for identity.
+ * ------------------------------------------------------------------------------------- */
+int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output, int64_t N,
+                            int C, int Hi, int Wi, int Ho, int Wo, float delta,
+                            int64_t outer_div, int64_t inner, waldo_stream_t stream);
+/* grad_input (Nin,C,Hi,Wi) must be ZERO-FILLED by the caller (accumulated with atomics; may be
+ * NULL to skip); grad_grid (N,Ho,Wo,2) is overwritten (may be NULL to skip). */
+int waldo_grid_sample2d_bwd(const float* input, const float* grid, const float* grad_output,
+                            float* grad_input, float* grad_grid, int64_t N, int C, int Hi, int Wi,
+                            int Ho, int Wo, float delta, int64_t outer_div, int64_t inner,
+                            waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A6. Occlusion product / soft-alpha composite -- replaces the
+ *     (1 - alpha * occ).prod(dim) * alpha pattern of models/nets/lvd.py:651-652,686,764-765,809
+ *     (spec form LVD.reduce_comp, lvd.py:100-114).
+ *   alpha (M,L,HW) in [0,1], occ (Mo,L,L) with m_occ = m / occ_div (broadcast of occ over a
+ *   trailing group, e.g. Tc), out (M,L,HW):  out[m,j,p] = alpha[m,j,p] * prod_i (1 - alpha[m,i,p]*occ[m_occ,i,j])
+ * ------------------------------------------------------------------------------------- */
+int waldo_occ_composite_fwd(const float* alpha, const float* occ, float* out, int64_t M, int L,
+                            int64_t HW, int64_t occ_div, waldo_stream_t stream);
+/* grad_alpha (M,L,HW) overwritten; grad_occ (Mo,L,L) must be ZERO-FILLED by the caller
+ * (accumulated with atomics; may be NULL to skip). */
+int waldo_occ_composite_bwd(const float* alpha, const float* occ, const float* grad_out,
+                            float* grad_alpha, float* grad_occ, int64_t M, int L, int64_t HW,
+                            int64_t occ_div, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused hot path (BASELINE.json metric): TPS grid (A2) -> bilinear warp of every 4-channel
+ * layer (A4) -> LVD.reduce_comp (A6, lvd.py:100-114) in ONE launch.
+ *   layers   (F,L,4,H,W) in [-1,1]   channel 3 = alpha; the alpha of layer 0 is taken as +1
+ *   basis_t  (K3,H*W)                TPS basis of the output raster (shared by all frames)
+ *   mapping  (F*L,K3,2)              from waldo_tps_mapping_fwd
+ *   occ      (F,L,L)
+ *   rgb      (F,3,H,W)  out, in [-1,1]
+ *   alpha    (F,L,H,W)  out, composited alpha in [-1,1]; may be NULL (not written)
+ * K3 <= 32, L <= waldo_max_layers().
+ * ------------------------------------------------------------------------------------- */
+int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const float* mapping,
+                             const float* occ, float* rgb, float* alpha, int64_t F, int L, int H,
+                             int W, int K3, waldo_stream_t stream);
+/* Backward of the above.
+ *   grad_rgb (F,3,H,W); grad_alpha (F,L,H,W) or NULL;
+ *   grad_layers (F,L,4,H,W): must be ZERO-FILLED by the caller (accumulated with atomics);
+ *   grad_mapping (F*L,K3,2): must be ZERO-FILLED by the caller; may be NULL to skip;
+ *   grad_occ (F,L,L): must be ZERO-FILLED by the caller; may be NULL to skip. */
+int waldo_warp_composite_bwd(const float* layers, const float* basis_t, const float* mapping,
+                             const float* occ, const float* grad_rgb, const float* grad_alpha,
+                             float* grad_layers, float* grad_mapping, float* grad_occ, int64_t F,
+                             int L, int H, int W, int K3, waldo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WALDO_HIP_H */

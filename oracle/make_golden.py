@@ -1,0 +1,154 @@
+"""Generate golden vectors from the REFERENCE ITSELF (run in the build container only).
+
+    python oracle/make_golden.py
+
+Imports the reference's own modules from /root/reference through ``oracle/ref_import.py``
+(nothing is copied), runs them on seeded inputs on the CPU and stores inputs + outputs (+
+autograd gradients) as small .npz fixtures under tests/golden/.  The fixtures are data; this
+script is the provenance.  InverseWarp vectors are produced with ``Tensor.sort`` forced stable
+(see ``ref_import.stable_sort``): the reference's own tie-break is implementation-defined.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import as R  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+warnings.filterwarnings("ignore", message="Default grid_sample")
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  keys={sorted(out)}")
+
+
+def lvd_stub(ns, num_obj):
+    """An LVD instance with only what compute_occ / reduce_comp touch (lvd.py:49)."""
+    lvd = ns.LVD.__new__(ns.LVD)
+    torch.nn.Module.__init__(lvd)
+    lvd.register_buffer("diag", torch.eye(num_obj, num_obj)[None, None, :, :])
+    return lvd
+
+
+def gen_tps(ns):
+    g = torch.Generator().manual_seed(1)
+    for tag, (h, w, kh, kw) in {"k16": (16, 32, 4, 4), "k32": (12, 20, 4, 8)}.items():
+        ctrl = ns.get_grid(kh, kw).view(-1, 2)
+        mod = ns.TPSWarp(h, w, ctrl)
+        pts = (ctrl.view(1, -1, 2) + 0.1 * torch.randn(5, kh * kw, 2, generator=g)).requires_grad_()
+        grid = mod(pts)
+        wgt = torch.randn(grid.shape, generator=g)
+        (grid * wgt).sum().backward()
+        save(f"tps_{tag}", h=h, w=w, ctrl=ctrl, pts=pts, grid=grid, wgt=wgt, grad_pts=pts.grad,
+             inverse_kernel=mod.inverse_kernel, tgt_grid_repr=mod.tgt_grid_repr)
+
+
+def gen_grid_sample(ns):
+    g = torch.Generator().manual_seed(2)
+    n, c, hi, wi, ho, wo = 3, 5, 9, 14, 11, 13
+    x = torch.randn(n, c, hi, wi, generator=g, requires_grad=True)
+    # grid with in-range, border-straddling and far-out-of-range samples
+    grid = (torch.rand(n, ho, wo, 2, generator=g) * 2.6 - 1.3)
+    grid[0, 0, 0] = torch.tensor([-1.0, -1.0])
+    grid[0, 0, 1] = torch.tensor([1.0, 1.0])
+    grid[0, 0, 2] = torch.tensor([5.0, -7.0])
+    grid[0, 0, 3] = torch.tensor([-1.0 + 1.0 / wi, 1.0 - 1.0 / hi])
+    grid.requires_grad_()
+    for delta in (0.0, 1.0):
+        x.grad = grid.grad = None
+        out = F.grid_sample(x + delta, grid) - delta
+        wgt = torch.randn(out.shape, generator=g)
+        (out * wgt).sum().backward()
+        save(f"grid_sample_d{int(delta)}", x=x, grid=grid, delta=delta, out=out, wgt=wgt,
+             grad_x=x.grad, grad_grid=grid.grad)
+
+
+def gen_occ_comp(ns):
+    g = torch.Generator().manual_seed(3)
+    b, t, no, c, h, w = 2, 3, 4, 3, 6, 10
+    lvd = lvd_stub(ns, no)
+    score = torch.randn(b, t, no, generator=g, requires_grad=True)
+    occ = lvd.compute_occ(score)
+    vid = (torch.rand(b, t, no + 1, c + 1, h, w, generator=g) * 2 - 1).requires_grad_()
+    flow = torch.randn(b, t - 1, no + 1, 2, h, w, generator=g)
+    out, alpha, fl = lvd.reduce_comp(vid, occ, flow)
+    w1 = torch.randn(out.shape, generator=g)
+    w2 = torch.randn(alpha.shape, generator=g)
+    ((out * w1).sum() + (alpha * w2).sum()).backward()
+    save("occ_comp", score=score, occ=occ, vid=vid, out=out, alpha=alpha, w1=w1, w2=w2,
+         grad_vid=vid.grad, grad_score=score.grad)
+
+
+def gen_warp_composite(ns):
+    """The synthetic hot path of SURVEY.md 8(d) assembled from the reference's own ops:
+    TPSWarp.forward -> F.grid_sample -> LVD.reduce_comp."""
+    g = torch.Generator().manual_seed(4)
+    for tag, (f, nl, h, w, sigma) in {"small": (3, 5, 16, 24, 0.08), "l8": (2, 8, 32, 32, 0.05),
+                                      "big_warp": (2, 3, 20, 28, 0.5)}.items():
+        ctrl = ns.get_grid(4, 4).view(-1, 2)
+        tps = ns.TPSWarp(h, w, ctrl)
+        lvd = lvd_stub(ns, nl - 1)
+        layers = (torch.rand(f, nl, 4, h, w, generator=g) * 2 - 1).requires_grad_()
+        pts = (ctrl.view(1, 16, 2) + sigma * torch.randn(f * nl, 16, 2, generator=g)).requires_grad_()
+        score = torch.randn(f, 1, nl - 1, generator=g, requires_grad=True)
+        occ = lvd.compute_occ(score)  # f 1 L L
+        grid = tps(pts)
+        warped = F.grid_sample(layers.view(f * nl, 4, h, w), grid).view(f, 1, nl, 4, h, w)
+        rgb, alpha, _ = lvd.reduce_comp(warped, occ, torch.zeros(f, 0, nl, 2, h, w))
+        w1 = torch.randn(rgb.shape, generator=g)
+        w2 = torch.randn(alpha.shape, generator=g)
+        ((rgb * w1).sum() + (alpha * w2).sum()).backward(retain_graph=True)
+        both = dict(grad_layers=layers.grad.clone(), grad_pts=pts.grad.clone(),
+                    grad_score=score.grad.clone())
+        layers.grad = pts.grad = score.grad = None
+        # the benchmark's loss: rgb only
+        rgb.square().mean().backward()
+        save(f"warp_composite_{tag}", layers=layers, pts=pts, score=score, occ=occ[:, 0],
+             ctrl=ctrl, rgb=rgb[:, 0], alpha=alpha[:, 0], w1=w1[:, 0], w2=w2[:, 0],
+             grad_layers=both["grad_layers"], grad_pts=both["grad_pts"],
+             grad_score=both["grad_score"], grad_layers_sq=layers.grad, grad_pts_sq=pts.grad)
+
+
+def gen_inverse_warp(ns):
+    g = torch.Generator().manual_seed(5)
+    ctrl = ns.get_grid(4, 4).view(-1, 2)
+    cases = {"obj": (8, 8, 16, 32, True, 0.6, 0.1), "bg": (16, 32, 16, 32, False, 1.0, 0.06),
+             "obj2": (12, 20, 24, 40, True, 0.5, 0.15)}
+    for tag, (hs, ws, ht, wt, erode, shrink, sigma) in cases.items():
+        inv = ns.InverseWarp(hs, ws, ht, wt)
+        tps = ns.TPSWarp(hs, ws, ctrl)
+        pts = ctrl.view(1, 16, 2) * shrink + sigma * torch.randn(4, 16, 2, generator=g)
+        src_grid = tps(pts).detach().requires_grad_()
+        with R.stable_sort():
+            out = inv(src_grid, erode=erode)
+        wgt = torch.randn(out.shape, generator=g)
+        # holes carry the constant (2W, 2H) offset: they get no gradient; fine
+        (out * wgt).sum().backward()
+        save(f"inverse_warp_{tag}", src_grid=src_grid, out=out, wgt=wgt, grad_src_grid=src_grid.grad,
+             hs=hs, ws=ws, ht=ht, wt=wt, erode=erode)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = R.load()
+    gen_tps(ns)
+    gen_grid_sample(ns)
+    gen_occ_comp(ns)
+    gen_warp_composite(ns)
+    gen_inverse_warp(ns)
+
+
+if __name__ == "__main__":
+    main()

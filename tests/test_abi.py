@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/waldo_hip.h declares.
+No compute call is made here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "waldo_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(waldo_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from waldo_amd import build
+    if not os.path.exists(build.LIB):
+        build.build(verbose=False)
+    return build.LIB
+
+
+def test_header_declares_something():
+    fns = declared_functions()
+    assert "waldo_warp_composite_fwd" in fns and "waldo_warp_composite_bwd" in fns
+    assert len(fns) >= 13
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in waldo_hip.h but not exported"
+
+
+def test_binding_matches_header(lib_path):
+    from waldo_amd import _lib
+    bound = set(_lib.SIGNATURES) | set(_lib.PLAIN)
+    assert bound == set(declared_functions())
+    # argument counts agree with the header prototypes
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, argtypes in _lib.SIGNATURES.items():
+        m = re.search(name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert nargs == len(argtypes), (name, nargs, len(argtypes))
+
+
+def test_plain_calls_without_gpu(lib_path):
+    from waldo_amd import _lib
+    lib = _lib.load()
+    assert lib.waldo_version() >= 1000
+    assert lib.waldo_max_layers() == 32
+
+
+def test_argument_validation_needs_no_gpu(lib_path):
+    """Bad shapes are rejected on the host before any launch, with a message."""
+    from waldo_amd import _lib
+    lib = _lib.load()
+    rc = lib.waldo_warp_composite_fwd(None, None, None, None, None, None, 1, 99, 8, 8, 19, None)
+    assert rc == -1
+    assert b"unsupported shape" in lib.waldo_last_error_string()
+    rc = lib.waldo_grid_sample2d_fwd(None, None, None, 1, 0, 4, 4, 4, 4, 0.0, 1, 1, None)
+    assert rc == -1
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    import waldo_amd
+    from waldo_amd import functional as WF
+    from waldo_amd._lib import WaldoHipError
+    from waldo_amd.tools.utils import get_grid
+    tps = waldo_amd.TPSWarp(8, 8, get_grid(4, 4).view(-1, 2))
+    with pytest.raises(WaldoHipError):
+        tps(get_grid(4, 4).view(1, 16, 2))
+    with pytest.raises(WaldoHipError):
+        WF.grid_sample(torch.zeros(1, 1, 4, 4), torch.zeros(1, 4, 4, 2))
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never route through the oracle."""
+    pkg = os.path.join(ROOT, "waldo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)

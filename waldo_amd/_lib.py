@@ -1,0 +1,141 @@
+"""ctypes binding of the C-ABI HIP library (include/waldo_hip.h).
+
+The product path has NO CPU fallback: if ``libwaldo_hip.so`` is missing or fails to load, every
+op raises.  ``torch`` is imported before the library is opened so that the HIP runtime the
+library binds to (SONAME libamdhip64.so.7) is the one PyTorch-ROCm already loaded -- device
+pointers and streams are then shared between the two.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
+
+_c_f = ctypes.c_void_p  # device pointers travel as integers
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_flt = ctypes.c_float
+_stream = ctypes.c_void_p
+
+# name -> argtypes; mirrors include/waldo_hip.h one to one (tests check the header against this)
+SIGNATURES = {
+    "waldo_tps_mapping_fwd": [_c_f, _c_f, _c_f, _i64, _int, _stream],
+    "waldo_tps_mapping_bwd": [_c_f, _c_f, _c_f, _i64, _int, _stream],
+    "waldo_tps_grid_fwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
+    "waldo_tps_grid_bwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
+    "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
+                                _i64, _stream],
+    "waldo_grid_sample2d_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int,
+                                _flt, _i64, _i64, _stream],
+    "waldo_occ_composite_fwd": [_c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
+    "waldo_occ_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
+    "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
+                                 _stream],
+    "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int,
+                                 _int, _int, _int, _stream],
+}
+PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
+         "waldo_last_error_string": (ctypes.c_char_p, [])}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class WaldoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Open the library (once) and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise WaldoHipError(
+                f"{LIB_PATH} not found: build it with `python -m waldo_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _int
+        for name, (res, argtypes) in PLAIN.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = res
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise WaldoHipError("waldo_amd ops need tensors on the GPU (cuda device); "
+                                "there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise WaldoHipError(f"waldo_amd ops are fp32-only, got {t.dtype}")
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class KernelTimer:
+    """Optional per-entry-point device timing: records an event pair on the launch stream around
+    every C-ABI call (bench.py uses it for the live roofline numbers).  Off by default."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+        return False
+
+    def summary(self):
+        """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
+_timer = None
+
+
+def call(name, *args):
+    """Call an entry point; raise WaldoHipError with the library's message on failure."""
+    lib = load()
+    if _timer is not None:
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        rc = getattr(lib, name)(*args)
+        stop.record()
+        _timer.pairs.setdefault(name, []).append((start, stop))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.waldo_last_error_string()
+        raise WaldoHipError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,132 @@
+// A4/A5: bilinear backward warp, y = grid_sample(x + delta, grid) - delta with the PyTorch
+// defaults (bilinear, zeros, align_corners=False) -- the primitive behind
+// Warper.obj_to_output / bg_to_output / obj_from_input / bg_from_input
+// (models/nets/lvd.py:502-559) and the HD gathers of grid_to_flow_ctx / input_to_output
+// (lvd.py:801,837).  One thread per output pixel, looping over the C channel planes so the tap
+// weights are computed once; a wavefront covers 64 consecutive output pixels.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+__device__ __forceinline__ int64_t in_index(int64_t n, int64_t outer_div, int64_t inner) {
+  return (n / outer_div) * inner + (n % inner);
+}
+
+__global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
+    const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
+    int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta, int64_t outer_div,
+    int64_t inner) {
+  const int64_t n = blockIdx.x / tiles;
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= HWo) return;
+  const float2 g = *reinterpret_cast<const float2*>(grid + (n * HWo + p) * 2);
+  const Taps t = make_taps(g.x, g.y, Hi, Wi);
+  const int64_t HWi = (int64_t)Hi * Wi;
+  const float* in = input + in_index(n, outer_div, inner) * C * HWi;
+  float* out = output + n * C * HWo + p;
+  // sum of the weights of the in-range taps: sample(x + delta) = sample(x) + delta * wsum
+  const float wsum = (t.w00 + t.w01) + (t.w10 + t.w11);
+  const float shift = fmaf(delta, wsum, -delta);
+  for (int c = 0; c < C; ++c) out[(int64_t)c * HWo] = tap_sample(in + (int64_t)c * HWi, t) + shift;
+}
+
+__global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
+    const float* __restrict__ input, const float* __restrict__ grid,
+    const float* __restrict__ grad_output, float* __restrict__ grad_input,
+    float* __restrict__ grad_grid, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles,
+    float delta, int64_t outer_div, int64_t inner) {
+  const int64_t n = blockIdx.x / tiles;
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= HWo) return;
+  const float2 g = *reinterpret_cast<const float2*>(grid + (n * HWo + p) * 2);
+  const Taps t = make_taps(g.x, g.y, Hi, Wi);
+  const int64_t HWi = (int64_t)Hi * Wi;
+  const int64_t nin = in_index(n, outer_div, inner);
+  const float* in = input + nin * C * HWi;
+  const float* go = grad_output + n * C * HWo + p;
+  float gix = 0.0f, giy = 0.0f;
+  const float m00 = t.vx0 * t.vy0, m01 = t.vx1 * t.vy0, m10 = t.vx0 * t.vy1, m11 = t.vx1 * t.vy1;
+  for (int c = 0; c < C; ++c) {
+    const float gv = go[(int64_t)c * HWo];
+    if (grad_grid != nullptr) {
+      const float* pl = in + (int64_t)c * HWi;
+      const float v00 = (pl[t.o00] + delta) * m00, v01 = (pl[t.o01] + delta) * m01;
+      const float v10 = (pl[t.o10] + delta) * m10, v11 = (pl[t.o11] + delta) * m11;
+      const float ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
+      const float top = fmaf(t.fx, v01 - v00, v00);
+      const float bot = fmaf(t.fx, v11 - v10, v10);
+      gix = fmaf(gv, ddx, gix);
+      giy = fmaf(gv, bot - top, giy);
+    }
+    if (grad_input != nullptr) {
+      float* gp = grad_input + (nin * C + c) * HWi;
+      if (t.w00 != 0.0f) atomicAdd(gp + t.o00, gv * t.w00);
+      if (t.w01 != 0.0f) atomicAdd(gp + t.o01, gv * t.w01);
+      if (t.w10 != 0.0f) atomicAdd(gp + t.o10, gv * t.w10);
+      if (t.w11 != 0.0f) atomicAdd(gp + t.o11, gv * t.w11);
+    }
+  }
+  if (grad_grid != nullptr) {
+    float2* o = reinterpret_cast<float2*>(grad_grid + (n * HWo + p) * 2);
+    *o = make_float2(gix * (0.5f * (float)Wi), giy * (0.5f * (float)Hi));
+  }
+}
+
+static int check_gs(const char* fn, int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
+                    int64_t outer_div, int64_t inner) {
+  if (N < 0 || C < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || outer_div < 1 || inner < 1) {
+    set_error("%s: bad shape N=%lld C=%d in=%dx%d out=%dx%d outer_div=%lld inner=%lld", fn,
+              (long long)N, C, Hi, Wi, Ho, Wo, (long long)outer_div, (long long)inner);
+    return WALDO_EINVAL;
+  }
+  const int64_t tiles = ((int64_t)Ho * Wo + kBlock - 1) / kBlock;
+  if ((int64_t)Hi * Wi > 2147483647 || N * tiles > 2147483647) {
+    set_error("%s: problem too large for one launch", fn);
+    return WALDO_EINVAL;
+  }
+  return WALDO_OK;
+}
+
+}  // namespace waldo
+
+using namespace waldo;
+
+extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output,
+                                       int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
+                                       float delta, int64_t outer_div, int64_t inner,
+                                       waldo_stream_t stream) {
+  int rc = check_gs("waldo_grid_sample2d_fwd", N, C, Hi, Wi, Ho, Wo, outer_div, inner);
+  if (rc) return rc;
+  if (N == 0) return WALDO_OK;
+  if (!input || !grid || !output) {
+    set_error("waldo_grid_sample2d_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  const int64_t HWo = (int64_t)Ho * Wo;
+  const int tiles = (int)((HWo + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(grid_sample2d_fwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
+                     (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles, delta,
+                     outer_div, inner);
+  return launch_status("waldo_grid_sample2d_fwd");
+}
+
+extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,
+                                       const float* grad_output, float* grad_input,
+                                       float* grad_grid, int64_t N, int C, int Hi, int Wi, int Ho,
+                                       int Wo, float delta, int64_t outer_div, int64_t inner,
+                                       waldo_stream_t stream) {
+  int rc = check_gs("waldo_grid_sample2d_bwd", N, C, Hi, Wi, Ho, Wo, outer_div, inner);
+  if (rc) return rc;
+  if (N == 0) return WALDO_OK;
+  if (!input || !grid || !grad_output) {
+    set_error("waldo_grid_sample2d_bwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  if (!grad_input && !grad_grid) return WALDO_OK;
+  const int64_t HWo = (int64_t)Ho * Wo;
+  const int tiles = (int)((HWo + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(grid_sample2d_bwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
+                     (hipStream_t)stream, input, grid, grad_output, grad_input, grad_grid, N, C,
+                     Hi, Wi, HWo, tiles, delta, outer_div, inner);
+  return launch_status("waldo_grid_sample2d_bwd");
+}

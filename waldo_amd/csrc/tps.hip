@@ -1,0 +1,208 @@
+// A2: thin-plate-spline grid synthesis (replaces TPSWarp.forward, models/modules/warp.py:49-55).
+//   mapping = K^-1 @ [src_pts; 0]   (tiny; one thread per output element)
+//   grid    = basis @ mapping       (output-bound: 8 B written per pixel per map)
+// The basis is stored transposed (K3, HW): lane i of a wavefront reads pixel p0+i of basis
+// function k, one coalesced 256-B request per k.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+__global__ __launch_bounds__(kBlock) void tps_mapping_fwd_kernel(
+    const float* __restrict__ inv, const float* __restrict__ pts, float* __restrict__ mapping,
+    int64_t B, int N) {
+  const int K3 = N + 3;
+  const int64_t total = B * K3 * 2;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kBlock) {
+    const int c = (int)(e & 1);
+    const int r = (int)((e >> 1) % K3);
+    const int64_t b = (e >> 1) / K3;
+    const float* row = inv + (int64_t)r * K3;
+    const float* x = pts + b * N * 2 + c;
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) acc = fmaf(row[n], x[2 * n], acc);
+    mapping[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tps_mapping_bwd_kernel(
+    const float* __restrict__ inv, const float* __restrict__ gmap, float* __restrict__ gpts,
+    int64_t B, int N) {
+  const int K3 = N + 3;
+  const int64_t total = B * N * 2;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kBlock) {
+    const int c = (int)(e & 1);
+    const int n = (int)((e >> 1) % N);
+    const int64_t b = (e >> 1) / N;
+    const float* g = gmap + b * K3 * 2 + c;
+    float acc = 0.0f;
+    for (int r = 0; r < K3; ++r) acc = fmaf(inv[(int64_t)r * K3 + n], g[2 * r], acc);
+    gpts[e] = acc;
+  }
+}
+
+constexpr int kGridNB = 8;  // maps evaluated per thread per pass over the basis
+
+__global__ __launch_bounds__(kBlock) void tps_grid_fwd_kernel(const float* __restrict__ basis_t,
+                                                              const float* __restrict__ mapping,
+                                                              float* __restrict__ grid, int64_t B,
+                                                              int64_t HW, int K3) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = p < HW;
+  const int64_t pc = live ? p : HW - 1;
+  const int64_t b0 = (int64_t)blockIdx.y * kGridNB;
+  const int nb = (int)min((int64_t)kGridNB, B - b0);
+  float ax[kGridNB], ay[kGridNB];
+#pragma unroll
+  for (int i = 0; i < kGridNB; ++i) ax[i] = ay[i] = 0.0f;
+  for (int k = 0; k < K3; ++k) {
+    const float bv = basis_t[(int64_t)k * HW + pc];
+#pragma unroll
+    for (int i = 0; i < kGridNB; ++i) {
+      if (i < nb) {  // wave-uniform
+        const float* m = mapping + ((b0 + i) * K3 + k) * 2;
+        ax[i] = fmaf(bv, m[0], ax[i]);
+        ay[i] = fmaf(bv, m[1], ay[i]);
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < kGridNB; ++i) {
+      if (i < nb) {
+        float2* o = reinterpret_cast<float2*>(grid + ((b0 + i) * HW + p) * 2);
+        *o = make_float2(ax[i], ay[i]);
+      }
+    }
+  }
+}
+
+constexpr int kGradNB = 4;   // maps per workgroup
+constexpr int kGradPPT = 4;  // pixels per thread (summed in registers before the wave reduce)
+
+__global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __restrict__ basis_t,
+                                                              const float* __restrict__ ggrid,
+                                                              float* __restrict__ gmap, int64_t B,
+                                                              int64_t HW, int K3) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t pbase = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kGradPPT;
+  const int64_t b0 = (int64_t)blockIdx.y * kGradNB;
+  const int nb = (int)min((int64_t)kGradNB, B - b0);
+  float g[kGradPPT][kGradNB][2];
+#pragma unroll
+  for (int q = 0; q < kGradPPT; ++q) {
+    const int64_t p = pbase + q;
+#pragma unroll
+    for (int i = 0; i < kGradNB; ++i) {
+      if (p < HW && i < nb) {
+        const float2 v = *reinterpret_cast<const float2*>(ggrid + ((b0 + i) * HW + p) * 2);
+        g[q][i][0] = v.x;
+        g[q][i][1] = v.y;
+      } else {
+        g[q][i][0] = g[q][i][1] = 0.0f;
+      }
+    }
+  }
+  for (int k = 0; k < K3; ++k) {
+    float part[kGradNB * 2];
+#pragma unroll
+    for (int i = 0; i < kGradNB * 2; ++i) part[i] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kGradPPT; ++q) {
+      const int64_t p = pbase + q;
+      const float bv = (p < HW) ? basis_t[(int64_t)k * HW + p] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < kGradNB; ++i) {
+        part[2 * i] = fmaf(bv, g[q][i][0], part[2 * i]);
+        part[2 * i + 1] = fmaf(bv, g[q][i][1], part[2 * i + 1]);
+      }
+    }
+    const float red = wave_transpose_reduce<kGradNB * 2>(part, lane);
+    const int idx = bitrev6(lane);
+    if (idx < nb * 2) atomicAdd(gmap + ((b0 + (idx >> 1)) * K3 + k) * 2 + (idx & 1), red);
+  }
+}
+
+static int grid_for(int64_t total) {
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  return (int)max((int64_t)1, min(blocks, (int64_t)256 * 16));
+}
+
+}  // namespace waldo
+
+using namespace waldo;
+
+extern "C" int waldo_tps_mapping_fwd(const float* inverse_kernel, const float* src_pts,
+                                     float* mapping, int64_t B, int N, waldo_stream_t stream) {
+  if (B < 0 || N < 1) {
+    set_error("waldo_tps_mapping_fwd: bad shape B=%lld N=%d", (long long)B, N);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!inverse_kernel || !src_pts || !mapping) {
+    set_error("waldo_tps_mapping_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipLaunchKernelGGL(tps_mapping_fwd_kernel, dim3(grid_for(B * (N + 3) * 2)), dim3(kBlock), 0,
+                     (hipStream_t)stream, inverse_kernel, src_pts, mapping, B, N);
+  return launch_status("waldo_tps_mapping_fwd");
+}
+
+extern "C" int waldo_tps_mapping_bwd(const float* inverse_kernel, const float* grad_mapping,
+                                     float* grad_src_pts, int64_t B, int N,
+                                     waldo_stream_t stream) {
+  if (B < 0 || N < 1) {
+    set_error("waldo_tps_mapping_bwd: bad shape B=%lld N=%d", (long long)B, N);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!inverse_kernel || !grad_mapping || !grad_src_pts) {
+    set_error("waldo_tps_mapping_bwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipLaunchKernelGGL(tps_mapping_bwd_kernel, dim3(grid_for(B * N * 2)), dim3(kBlock), 0,
+                     (hipStream_t)stream, inverse_kernel, grad_mapping, grad_src_pts, B, N);
+  return launch_status("waldo_tps_mapping_bwd");
+}
+
+extern "C" int waldo_tps_grid_fwd(const float* basis_t, const float* mapping, float* grid,
+                                  int64_t B, int64_t HW, int K3, waldo_stream_t stream) {
+  if (B < 0 || HW < 1 || K3 < 3 || (B + kGridNB - 1) / kGridNB > 65535) {
+    set_error("waldo_tps_grid_fwd: bad shape B=%lld HW=%lld K3=%d", (long long)B, (long long)HW,
+              K3);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!basis_t || !mapping || !grid) {
+    set_error("waldo_tps_grid_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  dim3 g((unsigned)((HW + kBlock - 1) / kBlock), (unsigned)((B + kGridNB - 1) / kGridNB));
+  hipLaunchKernelGGL(tps_grid_fwd_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, basis_t,
+                     mapping, grid, B, HW, K3);
+  return launch_status("waldo_tps_grid_fwd");
+}
+
+extern "C" int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid,
+                                  float* grad_mapping, int64_t B, int64_t HW, int K3,
+                                  waldo_stream_t stream) {
+  if (B < 0 || HW < 1 || K3 < 3 || (B + kGradNB - 1) / kGradNB > 65535) {
+    set_error("waldo_tps_grid_bwd: bad shape B=%lld HW=%lld K3=%d", (long long)B, (long long)HW,
+              K3);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!basis_t || !grad_grid || !grad_mapping) {
+    set_error("waldo_tps_grid_bwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_mapping, 0, sizeof(float) * B * K3 * 2, st) != hipSuccess)
+    return launch_status("waldo_tps_grid_bwd(memset)");
+  const int64_t per_block = (int64_t)kBlock * kGradPPT;
+  dim3 g((unsigned)((HW + per_block - 1) / per_block), (unsigned)((B + kGradNB - 1) / kGradNB));
+  hipLaunchKernelGGL(tps_grid_bwd_kernel, g, dim3(kBlock), 0, st, basis_t, grad_grid,
+                     grad_mapping, B, HW, K3);
+  return launch_status("waldo_tps_grid_bwd");
+}

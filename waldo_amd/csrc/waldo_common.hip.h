@@ -1,0 +1,129 @@
+// Shared device/host helpers for the gfx950 WIF warp/composite kernels.
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf(), so
+// that the forward and backward kernels (which both re-evaluate the TPS grid and the bilinear
+// taps) produce bit-identical coordinates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/waldo_hip.h"
+
+namespace waldo {
+
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);
+
+constexpr int kWave = 64;   // gfx950 wavefront
+constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
+
+// ---------------------------------------------------------------------------------------
+// Bilinear taps of grid_sample(mode=bilinear, padding_mode=zeros, align_corners=False).
+//   ix = ((x + 1) * W - 1) / 2 ; corners (x0,y0) .. (x0+1,y0+1); a corner outside the image
+//   contributes nothing: its weight is zeroed and its address clamped into the image, so every
+//   load is in bounds.
+// ---------------------------------------------------------------------------------------
+struct Taps {
+  float w00, w01, w10, w11;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1), zero when outside
+  int o00, o01, o10, o11;    // element offsets inside one Hi*Wi plane (always in bounds)
+  float fx, fy;              // fractional parts
+  float vx0, vx1, vy0, vy1;  // 1.0f / 0.0f validity of column x0, x1 and row y0, y1
+};
+
+__device__ __forceinline__ float unnormalize(float c, int size) {
+  return ((c + 1.0f) * (float)size - 1.0f) * 0.5f;
+}
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
+  float ix = unnormalize(gx, Wi);
+  float iy = unnormalize(gy, Hi);
+  // keep the float->int conversion defined for wild / NaN coordinates; anything clamped here has
+  // all four corners outside the image anyway
+  ix = fminf(fmaxf(ix, -2.0f), (float)Wi + 1.0f);
+  iy = fminf(fmaxf(iy, -2.0f), (float)Hi + 1.0f);
+  float x0f = floorf(ix), y0f = floorf(iy);
+  Taps t;
+  t.fx = ix - x0f;
+  t.fy = iy - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  t.vx0 = (x0 >= 0 && x0 < Wi) ? 1.0f : 0.0f;
+  t.vx1 = (x1 >= 0 && x1 < Wi) ? 1.0f : 0.0f;
+  t.vy0 = (y0 >= 0 && y0 < Hi) ? 1.0f : 0.0f;
+  t.vy1 = (y1 >= 0 && y1 < Hi) ? 1.0f : 0.0f;
+  int cx0 = min(max(x0, 0), Wi - 1), cx1 = min(max(x1, 0), Wi - 1);
+  int cy0 = min(max(y0, 0), Hi - 1), cy1 = min(max(y1, 0), Hi - 1);
+  t.o00 = cy0 * Wi + cx0;
+  t.o01 = cy0 * Wi + cx1;
+  t.o10 = cy1 * Wi + cx0;
+  t.o11 = cy1 * Wi + cx1;
+  float wx0 = (1.0f - t.fx) * t.vx0, wx1 = t.fx * t.vx1;
+  float wy0 = (1.0f - t.fy) * t.vy0, wy1 = t.fy * t.vy1;
+  t.w00 = wx0 * wy0;
+  t.w01 = wx1 * wy0;
+  t.w10 = wx0 * wy1;
+  t.w11 = wx1 * wy1;
+  return t;
+}
+
+__device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const Taps& t) {
+  float v00 = plane[t.o00], v01 = plane[t.o01], v10 = plane[t.o10], v11 = plane[t.o11];
+  return fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
+}
+
+// sample + partial derivatives w.r.t. the UNNORMALISED coordinates (ix, iy)
+__device__ __forceinline__ float tap_sample_d(const float* __restrict__ plane, const Taps& t,
+                                              float& ddx, float& ddy) {
+  float v00 = plane[t.o00] * (t.vx0 * t.vy0), v01 = plane[t.o01] * (t.vx1 * t.vy0);
+  float v10 = plane[t.o10] * (t.vx0 * t.vy1), v11 = plane[t.o11] * (t.vx1 * t.vy1);
+  float top = fmaf(t.fx, v01 - v00, v00);
+  float bot = fmaf(t.fx, v11 - v10, v10);
+  ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
+  ddy = bot - top;
+  return fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, plane[t.o00] * t.w00)));
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-level "transpose reduce": every lane holds NV partial sums v[0..NV); on return lane l
+// holds the sum over all 64 lanes of v[bitrev6(l)] (valid when bitrev6(l) < NV).  Costs about NV
+// cross-lane moves instead of 6*NV for NV independent butterflies.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int bitrev6(int l) {
+  return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) |
+         ((l & 32) >> 5);
+}
+
+template <int N, int D>
+struct TransposeReduce {
+  __device__ __forceinline__ static float run(float (&v)[N], int lane) {
+    constexpr int M = (N + 1) / 2;
+    float w[M];
+    const bool hi = (lane & D) != 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float a = v[2 * m];
+      float b = (2 * m + 1 < N) ? v[2 * m + 1] : 0.0f;
+      float keep = hi ? b : a;
+      float send = hi ? a : b;
+      w[m] = keep + __shfl_xor(send, D, kWave);
+    }
+    if constexpr (D == 1) {
+      return w[0];
+    } else {
+      return TransposeReduce<M, D / 2>::run(w, lane);
+    }
+  }
+};
+
+template <int N>
+__device__ __forceinline__ float wave_transpose_reduce(float (&v)[N], int lane) {
+  static_assert(N >= 1 && N <= 64, "at most one value per lane");
+  return TransposeReduce<N, 32>::run(v, lane);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
+}  // namespace waldo

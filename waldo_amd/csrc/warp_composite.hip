@@ -1,0 +1,90 @@
+// Fused WIF hot path -- C-ABI entry points and dispatch over the compiled (LP, K3P) variants.
+// Kernels: warp_composite_kernels.hip.h; one translation unit per padded layer count
+// (warp_composite_lp*.hip) so that the variants compile in parallel.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+constexpr int kMaxLayers = 32;
+constexpr int kMaxK3 = 32;
+
+#define WALDO_DECL_LP(LPV)                                                                      \
+  void wc_fwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
+                      const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,   \
+                      int K3, hipStream_t st);                                                  \
+  void wc_bwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
+                      const float* occ, const float* grad_rgb, const float* grad_alpha,         \
+                      float* grad_layers, float* grad_mapping, float* grad_occ, int F, int L,   \
+                      int H, int W, int K3, hipStream_t st);
+WALDO_DECL_LP(4)
+WALDO_DECL_LP(8)
+WALDO_DECL_LP(12)
+WALDO_DECL_LP(17)
+WALDO_DECL_LP(24)
+WALDO_DECL_LP(32)
+
+static int check_common(const char* fn, int64_t F, int L, int H, int W, int K3) {
+  if (F < 0 || L < 1 || L > kMaxLayers || H < 1 || W < 1 || K3 < 3 || K3 > kMaxK3) {
+    set_error("%s: unsupported shape F=%lld L=%d H=%d W=%d K3=%d (need 1<=L<=%d, 3<=K3<=%d)", fn,
+              (long long)F, L, H, W, K3, kMaxLayers, kMaxK3);
+    return WALDO_EINVAL;
+  }
+  if (F > 65535 || (int64_t)H * W > (int64_t)2147483647 / 4) {
+    set_error("%s: F=%lld (max 65535 per launch) or H*W=%lld too large", fn, (long long)F,
+              (long long)H * W);
+    return WALDO_EINVAL;
+  }
+  return WALDO_OK;
+}
+
+}  // namespace waldo
+
+using namespace waldo;
+
+#define WALDO_CALL_LP(FN, ...)                    \
+  do {                                            \
+    if (L <= 4) FN##4(__VA_ARGS__);               \
+    else if (L <= 8) FN##8(__VA_ARGS__);          \
+    else if (L <= 12) FN##12(__VA_ARGS__);        \
+    else if (L <= 17) FN##17(__VA_ARGS__);        \
+    else if (L <= 24) FN##24(__VA_ARGS__);        \
+    else FN##32(__VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int waldo_max_layers(void) { return kMaxLayers; }
+
+extern "C" int waldo_warp_composite_fwd(const float* layers, const float* basis_t,
+                                        const float* mapping, const float* occ, float* rgb,
+                                        float* alpha, int64_t F, int L, int H, int W, int K3,
+                                        waldo_stream_t stream) {
+  int rc = check_common("waldo_warp_composite_fwd", F, L, H, W, K3);
+  if (rc) return rc;
+  if (F == 0) return WALDO_OK;
+  if (!layers || !basis_t || !mapping || !occ || !rgb) {
+    set_error("waldo_warp_composite_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WALDO_CALL_LP(wc_fwd_lp, K3 == 19, layers, basis_t, mapping, occ, rgb, alpha, (int)F, L, H, W,
+                K3, st);
+  return launch_status("waldo_warp_composite_fwd");
+}
+
+extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_t,
+                                        const float* mapping, const float* occ,
+                                        const float* grad_rgb, const float* grad_alpha,
+                                        float* grad_layers, float* grad_mapping, float* grad_occ,
+                                        int64_t F, int L, int H, int W, int K3,
+                                        waldo_stream_t stream) {
+  int rc = check_common("waldo_warp_composite_bwd", F, L, H, W, K3);
+  if (rc) return rc;
+  if (F == 0) return WALDO_OK;
+  if (!layers || !basis_t || !mapping || !occ || !grad_rgb || !grad_layers) {
+    set_error("waldo_warp_composite_bwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WALDO_CALL_LP(wc_bwd_lp, K3 == 19, layers, basis_t, mapping, occ, grad_rgb, grad_alpha,
+                grad_layers, grad_mapping, grad_occ, (int)F, L, H, W, K3, st);
+  return launch_status("waldo_warp_composite_bwd");
+}

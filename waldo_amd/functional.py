@@ -1,0 +1,237 @@
+"""Autograd wrappers over the C-ABI HIP kernels (include/waldo_hip.h).
+
+Every function here launches hand-written gfx950 kernels on the caller's current HIP stream; no
+function has a CPU or eager-PyTorch fallback (``_lib.check_cuda`` raises on CPU tensors).
+PyTorch is used for memory (output allocation), streams and autograd bookkeeping only.
+"""
+import torch
+
+from . import _lib
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# A2: TPS
+# --------------------------------------------------------------------------------------
+class _TpsMapping(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inverse_kernel, src_pts):
+        _lib.check_cuda(inverse_kernel, src_pts)
+        src_pts = _c(src_pts)
+        inverse_kernel = _c(inverse_kernel)
+        b, n, _ = src_pts.shape
+        mapping = src_pts.new_empty(b, n + 3, 2)
+        with torch.cuda.device(src_pts.device):
+            _lib.call("waldo_tps_mapping_fwd", _lib.ptr(inverse_kernel), _lib.ptr(src_pts),
+                      _lib.ptr(mapping), b, n, _lib.current_stream(src_pts.device))
+        ctx.save_for_backward(inverse_kernel)
+        ctx.n = n
+        return mapping
+
+    @staticmethod
+    def backward(ctx, grad_mapping):
+        (inverse_kernel,) = ctx.saved_tensors
+        grad_mapping = _c(grad_mapping)
+        b = grad_mapping.shape[0]
+        grad_pts = grad_mapping.new_empty(b, ctx.n, 2)
+        with torch.cuda.device(grad_mapping.device):
+            _lib.call("waldo_tps_mapping_bwd", _lib.ptr(inverse_kernel), _lib.ptr(grad_mapping),
+                      _lib.ptr(grad_pts), b, ctx.n, _lib.current_stream(grad_mapping.device))
+        return None, grad_pts
+
+
+class _TpsGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, basis_t, mapping):
+        _lib.check_cuda(basis_t, mapping)
+        mapping = _c(mapping)
+        basis_t = _c(basis_t)
+        b, k3, _ = mapping.shape
+        hw = basis_t.shape[1]
+        grid = mapping.new_empty(b, hw, 2)
+        with torch.cuda.device(mapping.device):
+            _lib.call("waldo_tps_grid_fwd", _lib.ptr(basis_t), _lib.ptr(mapping), _lib.ptr(grid),
+                      b, hw, k3, _lib.current_stream(mapping.device))
+        ctx.save_for_backward(basis_t)
+        ctx.k3 = k3
+        return grid
+
+    @staticmethod
+    def backward(ctx, grad_grid):
+        (basis_t,) = ctx.saved_tensors
+        grad_grid = _c(grad_grid)
+        b, hw, _ = grad_grid.shape
+        grad_mapping = grad_grid.new_empty(b, ctx.k3, 2)  # zero-filled by the launcher
+        with torch.cuda.device(grad_grid.device):
+            _lib.call("waldo_tps_grid_bwd", _lib.ptr(basis_t), _lib.ptr(grad_grid),
+                      _lib.ptr(grad_mapping), b, hw, ctx.k3,
+                      _lib.current_stream(grad_grid.device))
+        return None, grad_mapping
+
+
+def tps_mapping(inverse_kernel, src_pts):
+    """mapping (B, N+3, 2) = K^-1 @ [src_pts; 0]  (models/modules/warp.py:52-53)."""
+    return _TpsMapping.apply(inverse_kernel, src_pts.float())
+
+
+def tps_grid(inverse_kernel, basis_t, src_pts, height, width):
+    """TPSWarp.forward (models/modules/warp.py:49-55): (B, N, 2) -> (B, H, W, 2)."""
+    mapping = tps_mapping(inverse_kernel, src_pts)
+    return _TpsGrid.apply(basis_t, mapping).view(src_pts.shape[0], height, width, 2)
+
+
+# --------------------------------------------------------------------------------------
+# A4/A5: bilinear warp
+# --------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, grid, delta, outer_div, inner):
+        _lib.check_cuda(inp, grid)
+        inp = _c(inp)
+        grid = _c(grid)
+        nin, c, hi, wi = inp.shape
+        n, ho, wo, two = grid.shape
+        assert two == 2
+        if outer_div is None:
+            if nin != n:
+                raise _lib.WaldoHipError(f"grid_sample: batch mismatch {nin} vs {n}")
+            outer_div = inner = max(n, 1)
+        out = inp.new_empty(n, c, ho, wo)
+        with torch.cuda.device(inp.device):
+            _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
+                      c, hi, wi, ho, wo, float(delta), outer_div, inner,
+                      _lib.current_stream(inp.device))
+        ctx.save_for_backward(inp, grid)
+        ctx.cfg = (float(delta), outer_div, inner)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inp, grid = ctx.saved_tensors
+        delta, outer_div, inner = ctx.cfg
+        grad_out = _c(grad_out)
+        nin, c, hi, wi = inp.shape
+        n, ho, wo, _ = grid.shape
+        gi = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None
+        gg = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(inp.device):
+            _lib.call("waldo_grid_sample2d_bwd", _lib.ptr(inp), _lib.ptr(grid),
+                      _lib.ptr(grad_out), _lib.ptr(gi), _lib.ptr(gg), n, c, hi, wi, ho, wo,
+                      delta, outer_div, inner, _lib.current_stream(inp.device))
+        return gi, gg, None, None, None
+
+
+def grid_sample(inp, grid, delta=0.0, broadcast=None):
+    """``F.grid_sample(inp + delta, grid) - delta`` with the PyTorch defaults (bilinear, zeros,
+    align_corners=False).  inp (Nin, C, Hi, Wi), grid (N, Ho, Wo, 2) -> (N, C, Ho, Wo).
+
+    broadcast=(outer_div, inner): input map used by output n is
+    ``(n // outer_div) * inner + n % inner`` -- the reference's ``.expand`` over time
+    (models/nets/lvd.py:544,555) without materialising the copies."""
+    od, inn = broadcast if broadcast is not None else (None, None)
+    return _GridSample.apply(inp, grid, delta, od, inn)
+
+
+# --------------------------------------------------------------------------------------
+# A6: occlusion product
+# --------------------------------------------------------------------------------------
+class _OccComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha, occ, occ_div):
+        _lib.check_cuda(alpha, occ)
+        alpha = _c(alpha)
+        occ = _c(occ)
+        m, nl, hw = alpha.shape
+        out = torch.empty_like(alpha)
+        with torch.cuda.device(alpha.device):
+            _lib.call("waldo_occ_composite_fwd", _lib.ptr(alpha), _lib.ptr(occ), _lib.ptr(out), m,
+                      nl, hw, occ_div, _lib.current_stream(alpha.device))
+        ctx.save_for_backward(alpha, occ)
+        ctx.occ_div = occ_div
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        alpha, occ = ctx.saved_tensors
+        grad_out = _c(grad_out)
+        m, nl, hw = alpha.shape
+        ga = torch.empty_like(alpha)
+        go = torch.zeros_like(occ) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(alpha.device):
+            _lib.call("waldo_occ_composite_bwd", _lib.ptr(alpha), _lib.ptr(occ),
+                      _lib.ptr(grad_out), _lib.ptr(ga), _lib.ptr(go), m, nl, hw, ctx.occ_div,
+                      _lib.current_stream(alpha.device))
+        return ga, go, None
+
+
+def occ_composite(alpha, occ, occ_div=1):
+    """out[m, j] = alpha[m, j] * prod_i (1 - alpha[m, i] * occ[m // occ_div, i, j]).
+    alpha (M, L, h, w) or (M, L, HW) in [0, 1]; occ (M // occ_div, L, L).
+    The (1 - alpha * occ).prod(dim) * alpha pattern of models/nets/lvd.py:651-652,764-765,809."""
+    shape = alpha.shape
+    a3 = alpha.reshape(shape[0], shape[1], -1)
+    return _OccComposite.apply(a3, occ, int(occ_div)).view(shape)
+
+
+# --------------------------------------------------------------------------------------
+# fused hot path
+# --------------------------------------------------------------------------------------
+class _WarpComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layers, mapping, occ, basis_t, want_alpha):
+        _lib.check_cuda(layers, mapping, occ, basis_t)
+        layers, mapping, occ, basis_t = _c(layers), _c(mapping), _c(occ), _c(basis_t)
+        f, nl, c, h, w = layers.shape
+        if c != 4:
+            raise _lib.WaldoHipError("warp_composite expects (F, L, 4, H, W) layers (RGB + alpha)")
+        k3 = mapping.shape[1]
+        if mapping.shape[0] != f * nl or tuple(occ.shape) != (f, nl, nl) or \
+                tuple(basis_t.shape) != (k3, h * w):
+            raise _lib.WaldoHipError(
+                f"warp_composite: inconsistent shapes layers={tuple(layers.shape)} "
+                f"mapping={tuple(mapping.shape)} occ={tuple(occ.shape)} basis_t={tuple(basis_t.shape)}")
+        rgb = layers.new_empty(f, 3, h, w)
+        alpha = layers.new_empty(f, nl, h, w) if want_alpha else None
+        with torch.cuda.device(layers.device):
+            _lib.call("waldo_warp_composite_fwd", _lib.ptr(layers), _lib.ptr(basis_t),
+                      _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(rgb), _lib.ptr(alpha), f, nl, h,
+                      w, k3, _lib.current_stream(layers.device))
+        ctx.save_for_backward(layers, mapping, occ, basis_t)
+        ctx.want_alpha = want_alpha
+        if want_alpha:
+            return rgb, alpha
+        ctx.mark_non_differentiable()
+        return rgb, None
+
+    @staticmethod
+    def backward(ctx, grad_rgb, grad_alpha):
+        layers, mapping, occ, basis_t = ctx.saved_tensors
+        f, nl, _, h, w = layers.shape
+        k3 = mapping.shape[1]
+        grad_rgb = _c(grad_rgb)
+        if grad_alpha is not None:
+            grad_alpha = _c(grad_alpha)
+        gl = torch.zeros_like(layers)
+        gm = torch.zeros_like(mapping) if ctx.needs_input_grad[1] else None
+        go = torch.zeros_like(occ) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(layers.device):
+            _lib.call("waldo_warp_composite_bwd", _lib.ptr(layers), _lib.ptr(basis_t),
+                      _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(grad_rgb), _lib.ptr(grad_alpha),
+                      _lib.ptr(gl), _lib.ptr(gm), _lib.ptr(go), f, nl, h, w, k3,
+                      _lib.current_stream(layers.device))
+        return gl, gm, go, None, None
+
+
+def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=False):
+    """Fused TPS grid -> bilinear warp of each 4-channel layer -> LVD.reduce_comp
+    (models/modules/warp.py:49-55, F.grid_sample, models/nets/lvd.py:100-114).
+
+    layers (F, L, 4, H, W) in [-1, 1]; src_pts (F*L, N, 2); occ (F, L, L);
+    inverse_kernel (N+3, N+3); basis_t (N+3, H*W).  Returns rgb (F, 3, H, W) and, if asked,
+    the composited alpha (F, L, H, W), both in [-1, 1]."""
+    mapping = tps_mapping(inverse_kernel, src_pts)
+    rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha))
+    return (rgb, alpha) if return_alpha else rgb
