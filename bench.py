@@ -51,26 +51,36 @@ def synth(frames, nl, h, w, device, seed):
 def cpu_baseline(nl, h, w, frames, reps):
     """Oracle (kind "port") on the host cores: fwd+bwd frames/s on `frames` frames."""
     from oracle import wif_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     layers, pts, occ, inv, rep = O.make_synthetic(frames, nl, h, w, seed=0)
     layers.requires_grad_()
     pts.requires_grad_()
-    times = []
-    for i in range(reps + 1):
+
+    def once():
         layers.grad = pts.grad = None
         t0 = time.perf_counter()
         rgb, _ = O.warp_composite(layers, pts, occ, inv, rep)
         rgb.square().mean().backward()
-        dt = time.perf_counter() - t0
-        if i > 0:
-            times.append(dt)
-    times.sort()
+        return time.perf_counter() - t0
+
+    # PyTorch-CPU does not scale to every core of a big host on these shapes: probe a few
+    # thread counts once and keep the fastest (this is the reference's best case)
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+    probe = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        once()
+        probe[c] = once()
+        if probe[c] > 4 * min(probe.values()):
+            break
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    times = sorted(once() for _ in range(reps))
     med = times[len(times) // 2]
     return {"value": round(frames / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{frames} frames of the same workload ({nl}x4x{h}x{w}, fwd+bwd), "
-                      f"median of {reps} after 1 warm-up, torch {torch.__version__} CPU, "
-                      f"{cores} threads"}
+                      f"median of {reps} after warm-up, torch {torch.__version__} CPU, "
+                      f"{cores} threads (fastest of {sorted(probe)} probed on {ncpu} logical CPUs)"}
 
 
 def main():

@@ -90,7 +90,8 @@ def tps_init(height, width, tgt_pts):
 def tps_mapping(inverse_kernel, src_pts):
     """mapping = K^-1 [src_pts; 0_{3x2}]  (models/modules/warp.py:52-53)."""
     b = src_pts.shape[0]
-    x = torch.cat([src_pts.float(), src_pts.new_zeros(b, 3, 2).float()], dim=1)
+    src_pts = src_pts.to(inverse_kernel.dtype)
+    x = torch.cat([src_pts, src_pts.new_zeros(b, 3, 2)], dim=1)
     return torch.matmul(inverse_kernel, x)
 
 
@@ -214,10 +215,18 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, tgt_grid_repr, explicit
     return rgb[:, 0], alpha[:, 0]
 
 
-def make_synthetic(frames, nl, h, w, k_side=4, seed=0, sigma=0.05):
-    """Synthetic workload of SURVEY.md 8(d): identical inputs for the CPU and GPU legs."""
+def make_synthetic(frames, nl, h, w, k_side=4, seed=0, sigma=0.05, smooth=0):
+    """Synthetic workload of SURVEY.md 8(d): identical inputs for the CPU and GPU legs.
+    smooth > 0 replaces the white-noise layers by noise drawn at 1/smooth resolution and
+    upsampled bilinearly (natural-image-like spectra: the bilinear interpolant then has no
+    O(1) jumps in its derivative from texel to texel, which white noise has)."""
     g = torch.Generator().manual_seed(seed)
-    layers = torch.rand(frames, nl, 4, h, w, generator=g) * 2 - 1
+    if smooth > 0:
+        lo = torch.rand(frames * nl, 4, max(h // smooth, 2), max(w // smooth, 2), generator=g) * 2 - 1
+        layers = F.interpolate(lo, size=(h, w), mode="bilinear", align_corners=False)
+        layers = layers.view(frames, nl, 4, h, w).contiguous()
+    else:
+        layers = torch.rand(frames, nl, 4, h, w, generator=g) * 2 - 1
     ctrl = get_grid(k_side, k_side).view(1, k_side * k_side, 2)
     pts = ctrl + sigma * torch.randn(frames * nl, k_side * k_side, 2, generator=g)
     occ = compute_occ(torch.randn(frames, 1, nl - 1, generator=g))[:, 0]
@@ -302,6 +311,8 @@ def inverse_warp(src_grid, tgt_shape, niter=5, pad=True, erode=True, kernel_size
     inv_dx = inv_dx[:, n + 1:-(n + 1), n + 1:-(n + 1)]
     inv_dy = inv_dy[:, n + 1:-(n + 1), n + 1:-(n + 1)]
     dt = torch.stack([inv_dx * 2 / w, inv_dy * 2 / h], dim=3)
-    if pad:
-        return get_grid(h, w) + dt
-    return get_grid(h, w)[:, n + 1:-(n + 1), n + 1:-(n + 1)] + dt
+    if not pad:
+        # the reference adds a cropped field to the full-size grid (warp.py:172-173) and fails
+        # with a shape error for pad=False; no call site uses it
+        raise ValueError("inverse_warp: pad=False is unusable in the reference (shape mismatch)")
+    return get_grid(h, w) + dt
