@@ -205,9 +205,10 @@ def _oracle_fused(layers, pts, occ, ctrl, w1, w2, dtype, loss="weights"):
     return rgb.detach(), alpha.detach(), l.grad, p.grad, o.grad
 
 
-def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None):
+def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None, generic=False):
     from waldo_amd import functional as WF
     import waldo_amd
+    WF._FORCE_GENERIC_BWD = generic  # False: tiled backward where it applies (L <= 8, K3 == 19)
     f, nl, _, h, w = layers.shape
     tps = waldo_amd.TPSWarp(h, w, ctrl)
     if buffers is not None:  # as when a reference checkpoint is loaded
@@ -275,11 +276,15 @@ def test_warp_composite_golden_bench_loss(dev, golden):
     dict(f=1, nl=32, h=8, w=16), dict(f=2, nl=8, h=16, w=16, k=3), dict(f=2, nl=3, h=16, w=16, k=5),
     dict(f=40, nl=4, h=16, w=16), dict(f=2, nl=8, h=64, w=96, smooth=8),
     dict(f=2, nl=17, h=32, w=64, smooth=4), dict(f=3, nl=8, h=40, w=56, sigma=0.6),
+    dict(f=1, nl=3, h=96, w=256, sigma=0.3), dict(f=2, nl=8, h=64, w=128, smooth=4),
+    dict(f=2, nl=6, h=72, w=192, sigma=0.02, smooth=4), dict(f=2, nl=8, h=32, w=48, generic=True),
+    dict(f=2, nl=4, h=17, w=33, generic=True),
 ])
 def test_warp_composite_random(dev, cfg):
     """Seeded random cases: every padded-L variant, ragged sizes (H*W not a multiple of the
-    workgroup), other control-point counts (generic K3 path), smooth layers (strict 1e-4 bound)
-    and violent warps (sigma=0.6: folds, most samples out of range)."""
+    workgroup), other control-point counts (generic K3 path), smooth layers (strict 1e-4 bound),
+    violent warps (sigma=0.3-0.6: folds, samples out of range, bounding boxes too large for the
+    LDS image, more than 24 intersecting tiles) and the generic backward kernel."""
     f, nl, h, w = cfg["f"], cfg["nl"], cfg["h"], cfg["w"]
     k = cfg.get("k", 4)
     ctrl = O.get_grid(k, k).view(-1, 2)
@@ -296,7 +301,7 @@ def test_warp_composite_random(dev, cfg):
     w1, w2 = torch.randn(f, 3, h, w), torch.randn(f, nl, h, w)
     ref32 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float32)
     ref64 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float64)
-    hip = _hip_fused(dev, layers, pts, occ, ctrl, w1, w2)
+    hip = _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, generic=cfg.get("generic", False))
     _compare_fused(hip, ref32, ref64)
 
 
@@ -351,25 +356,24 @@ def test_warp_composite_full_size(dev, h, w, nl, smooth):
     ref64 = _oracle_fused(layers, pts, occ, ctrl, None, None, torch.float64, "sq")
     hip = _hip_fused(dev, layers, pts, occ, ctrl, None, None, "sq")
     _compare_fused(hip[:4] + (None,), ref32[:4] + (None,), ref64)
-    # (ii) identity warp: exact up to the TPS fixed-point error (~1e-6 in grid units)
+    # (ii) identity control points and (iii) transparent objects: against the oracle first ...
     tps = waldo_amd.TPSWarp(h, w, ctrl).to(dev)
     ld, od = layers.to(dev), occ.to(dev)
     ident = ctrl.view(1, 16, 2).expand(f * nl, -1, -1).contiguous()
     rgb_i = WF.warp_composite(ld, ident.to(dev), od, tps.inverse_kernel, tps.basis_t)
-    plain, _, _ = O.reduce_comp(layers.unsqueeze(1), occ.unsqueeze(1))
     id64 = _oracle_fused(layers, ident, occ, ctrl, None, None, torch.float64, "sq")[0]
     id32 = _oracle_fused(layers, ident, occ, ctrl, None, None, torch.float32, "sq")[0]
     close(rgb_i, id32, what="identity warp vs oracle", exact=id64)
-    if smooth:
-        # a property, not parity: the TPS fixed point is only reached to ~3e-6 in grid units in
-        # fp32 (reference and build alike), i.e. ~1e-3 px at W=512
-        close(rgb_i, plain[:, 0], tol=1e-3, what="identity warp = plain composite")
-    # (iii) all object alphas at -1 (transparent) => output is layer 0's warped rgb
     l0 = layers.clone()
     l0[:, 1:, 3] = -1.0
     rgb_0 = WF.warp_composite(l0.to(dev), ident.to(dev), od, tps.inverse_kernel, tps.basis_t)
-    if smooth:
-        close(rgb_0, layers[:, 0, :3], tol=1e-3, what="background only")
     bg64 = _oracle_fused(l0, ident, occ, ctrl, None, None, torch.float64, "sq")[0]
     bg32 = _oracle_fused(l0, ident, occ, ctrl, None, None, torch.float32, "sq")[0]
     close(rgb_0, bg32, what="background only vs oracle", exact=bg64)
+    # ... then the size-independent properties themselves.  They hold only approximately, for the
+    # reference as for the build: the TPS fixed point is reached to ~3e-6 in grid units (1e-3 px
+    # at W=512), and at the image border that leaks a little zero padding into the sample.
+    if smooth:
+        plain, _, _ = O.reduce_comp(layers.unsqueeze(1), occ.unsqueeze(1))
+        close(rgb_i, plain[:, 0], tol=2e-2, what="identity warp = plain composite")
+        close(rgb_0, layers[:, 0, :3], tol=2e-2, what="transparent objects = layer 0")

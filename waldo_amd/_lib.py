@@ -12,7 +12,7 @@ import threading
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
+LIB_PATH = os.environ.get("WALDO_HIP_LIB") or os.path.join(_HERE, "lib", "libwaldo_hip.so")
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -34,10 +34,11 @@ SIGNATURES = {
     "waldo_occ_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
                                  _stream],
-    "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int,
-                                 _int, _int, _int, _stream],
+    "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64,
+                                 _i64, _int, _int, _int, _int, _stream],
 }
 PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
+         "waldo_warp_composite_bwd_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int]),
          "waldo_last_error_string": (ctypes.c_char_p, [])}
 
 _lock = threading.Lock()

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
     const float gv = go[(int64_t)c * HWo];
     if (grad_grid != nullptr) {
       const float* pl = in + (int64_t)c * HWi;
-      const float v00 = (pl[t.o00] + delta) * m00, v01 = (pl[t.o01] + delta) * m01;
-      const float v10 = (pl[t.o10] + delta) * m10, v11 = (pl[t.o11] + delta) * m11;
+      const float v00 = (ldb(pl, t.o00) + delta) * m00, v01 = (ldb(pl, t.o01) + delta) * m01;
+      const float v10 = (ldb(pl, t.o10) + delta) * m10, v11 = (ldb(pl, t.o11) + delta) * m11;
       const float ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
       const float top = fmaf(t.fx, v01 - v00, v00);
       const float bot = fmaf(t.fx, v11 - v10, v10);
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
     }
     if (grad_input != nullptr) {
       float* gp = grad_input + (nin * C + c) * HWi;
-      if (t.w00 != 0.0f) atomicAdd(gp + t.o00, gv * t.w00);
-      if (t.w01 != 0.0f) atomicAdd(gp + t.o01, gv * t.w01);
-      if (t.w10 != 0.0f) atomicAdd(gp + t.o10, gv * t.w10);
-      if (t.w11 != 0.0f) atomicAdd(gp + t.o11, gv * t.w11);
+      if (t.w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gv * t.w00);
+      if (t.w01 != 0.0f) atomicAdd(gp + (t.o01 >> 2), gv * t.w01);
+      if (t.w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gv * t.w10);
+      if (t.w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gv * t.w11);
     }
   }
   if (grad_grid != nullptr) {
@@ -80,7 +80,7 @@ static int check_gs(const char* fn, int64_t N, int C, int Hi, int Wi, int Ho, in
     return WALDO_EINVAL;
   }
   const int64_t tiles = ((int64_t)Ho * Wo + kBlock - 1) / kBlock;
-  if ((int64_t)Hi * Wi > 2147483647 || N * tiles > 2147483647) {
+  if ((int64_t)Hi * Wi > 1073741823 || N * tiles > 2147483647) {
     set_error("%s: problem too large for one launch", fn);
     return WALDO_EINVAL;
   }

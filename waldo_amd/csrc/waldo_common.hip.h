@@ -1,7 +1,7 @@
 // Shared device/host helpers for the gfx950 WIF warp/composite kernels.
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf(), so
-// that the forward and backward kernels (which both re-evaluate the TPS grid and the bilinear
-// taps) produce bit-identical coordinates.
+// that the kernels which re-evaluate the TPS grid and the bilinear taps (forward, bounding-box
+// pre-pass, backward) produce bit-identical coordinates.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,13 +20,15 @@ constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
 // Bilinear taps of grid_sample(mode=bilinear, padding_mode=zeros, align_corners=False).
 //   ix = ((x + 1) * W - 1) / 2 ; corners (x0,y0) .. (x0+1,y0+1); a corner outside the image
 //   contributes nothing: its weight is zeroed and its address clamped into the image, so every
-//   load is in bounds.
+//   load is in bounds.  Offsets are unsigned BYTE offsets inside one Hi*Wi plane so that loads
+//   use the scalar-base + 32-bit-VGPR-offset addressing form.
 // ---------------------------------------------------------------------------------------
 struct Taps {
-  float w00, w01, w10, w11;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1), zero when outside
-  int o00, o01, o10, o11;    // element offsets inside one Hi*Wi plane (always in bounds)
-  float fx, fy;              // fractional parts
-  float vx0, vx1, vy0, vy1;  // 1.0f / 0.0f validity of column x0, x1 and row y0, y1
+  float w00, w01, w10, w11;        // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1), zero when outside
+  uint32_t o00, o01, o10, o11;     // byte offsets inside the plane (always in bounds)
+  float fx, fy;                    // fractional parts
+  float vx0, vx1, vy0, vy1;        // 1.0f / 0.0f validity of column x0, x1 and row y0, y1
+  int x0, y0;                      // integer corner (may be -1 .. W / H: unclamped)
 };
 
 __device__ __forceinline__ float unnormalize(float c, int size) {
@@ -46,16 +48,18 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   t.fy = iy - y0f;
   int x0 = (int)x0f, y0 = (int)y0f;
   int x1 = x0 + 1, y1 = y0 + 1;
+  t.x0 = x0;
+  t.y0 = y0;
   t.vx0 = (x0 >= 0 && x0 < Wi) ? 1.0f : 0.0f;
   t.vx1 = (x1 >= 0 && x1 < Wi) ? 1.0f : 0.0f;
   t.vy0 = (y0 >= 0 && y0 < Hi) ? 1.0f : 0.0f;
   t.vy1 = (y1 >= 0 && y1 < Hi) ? 1.0f : 0.0f;
   int cx0 = min(max(x0, 0), Wi - 1), cx1 = min(max(x1, 0), Wi - 1);
   int cy0 = min(max(y0, 0), Hi - 1), cy1 = min(max(y1, 0), Hi - 1);
-  t.o00 = cy0 * Wi + cx0;
-  t.o01 = cy0 * Wi + cx1;
-  t.o10 = cy1 * Wi + cx0;
-  t.o11 = cy1 * Wi + cx1;
+  t.o00 = (uint32_t)(cy0 * Wi + cx0) * 4u;
+  t.o01 = (uint32_t)(cy0 * Wi + cx1) * 4u;
+  t.o10 = (uint32_t)(cy1 * Wi + cx0) * 4u;
+  t.o11 = (uint32_t)(cy1 * Wi + cx1) * 4u;
   float wx0 = (1.0f - t.fx) * t.vx0, wx1 = t.fx * t.vx1;
   float wy0 = (1.0f - t.fy) * t.vy0, wy1 = t.fy * t.vy1;
   t.w00 = wx0 * wy0;
@@ -65,21 +69,28 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   return t;
 }
 
+__device__ __forceinline__ float ldb(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 __device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const Taps& t) {
-  float v00 = plane[t.o00], v01 = plane[t.o01], v10 = plane[t.o10], v11 = plane[t.o11];
+  float v00 = ldb(plane, t.o00), v01 = ldb(plane, t.o01);
+  float v10 = ldb(plane, t.o10), v11 = ldb(plane, t.o11);
   return fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
 }
 
 // sample + partial derivatives w.r.t. the UNNORMALISED coordinates (ix, iy)
 __device__ __forceinline__ float tap_sample_d(const float* __restrict__ plane, const Taps& t,
                                               float& ddx, float& ddy) {
-  float v00 = plane[t.o00] * (t.vx0 * t.vy0), v01 = plane[t.o01] * (t.vx1 * t.vy0);
-  float v10 = plane[t.o10] * (t.vx0 * t.vy1), v11 = plane[t.o11] * (t.vx1 * t.vy1);
+  const float p00 = ldb(plane, t.o00), p01 = ldb(plane, t.o01);
+  const float p10 = ldb(plane, t.o10), p11 = ldb(plane, t.o11);
+  float v00 = p00 * (t.vx0 * t.vy0), v01 = p01 * (t.vx1 * t.vy0);
+  float v10 = p10 * (t.vx0 * t.vy1), v11 = p11 * (t.vx1 * t.vy1);
   float top = fmaf(t.fx, v01 - v00, v00);
   float bot = fmaf(t.fx, v11 - v10, v10);
   ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
   ddy = bot - top;
-  return fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, plane[t.o00] * t.w00)));
+  return fmaf(p11, t.w11, fmaf(p10, t.w10, fmaf(p01, t.w01, p00 * t.w00)));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -123,6 +134,18 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[N], int lane) 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
+  return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
   return v;
 }
 

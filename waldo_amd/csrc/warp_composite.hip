@@ -14,8 +14,8 @@ constexpr int kMaxK3 = 32;
                       int K3, hipStream_t st);                                                  \
   void wc_bwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
                       const float* occ, const float* grad_rgb, const float* grad_alpha,         \
-                      float* grad_layers, float* grad_mapping, float* grad_occ, int F, int L,   \
-                      int H, int W, int K3, hipStream_t st);
+                      float* grad_layers, float* grad_mapping, float* grad_occ,                 \
+                      void* workspace, int F, int L, int H, int W, int K3, hipStream_t st);
 WALDO_DECL_LP(4)
 WALDO_DECL_LP(8)
 WALDO_DECL_LP(12)
@@ -53,6 +53,20 @@ using namespace waldo;
 
 extern "C" int waldo_max_layers(void) { return kMaxLayers; }
 
+// tiled backward: per (frame, layer, 8x64-pixel tile) one int4 bounding box and one (19,2) float
+// partial of the control-point gradient
+static int64_t bwd_workspace_bytes(int64_t F, int L, int H, int W, int K3) {
+  if (K3 != 19 || L > 8) return 0;
+  const int64_t ntiles = (int64_t)((W + 63) / 64) * ((H + 7) / 8);
+  return F * L * ntiles * 16 + F * ntiles * L * 19 * 2 * 4;
+}
+
+extern "C" int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, int H, int W,
+                                                            int K3) {
+  if (F < 0 || L < 1 || H < 1 || W < 1) return 0;
+  return bwd_workspace_bytes(F, L, H, W, K3);
+}
+
 extern "C" int waldo_warp_composite_fwd(const float* layers, const float* basis_t,
                                         const float* mapping, const float* occ, float* rgb,
                                         float* alpha, int64_t F, int L, int H, int W, int K3,
@@ -74,8 +88,8 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
                                         const float* mapping, const float* occ,
                                         const float* grad_rgb, const float* grad_alpha,
                                         float* grad_layers, float* grad_mapping, float* grad_occ,
-                                        int64_t F, int L, int H, int W, int K3,
-                                        waldo_stream_t stream) {
+                                        void* workspace, int64_t workspace_bytes, int64_t F,
+                                        int L, int H, int W, int K3, waldo_stream_t stream) {
   int rc = check_common("waldo_warp_composite_bwd", F, L, H, W, K3);
   if (rc) return rc;
   if (F == 0) return WALDO_OK;
@@ -84,7 +98,16 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
+  const int64_t need = bwd_workspace_bytes(F, L, H, W, K3);
+  if (workspace != nullptr && (need == 0 || workspace_bytes < need)) {
+    if (need != 0) {
+      set_error("waldo_warp_composite_bwd: workspace of %lld bytes given, %lld needed",
+                (long long)workspace_bytes, (long long)need);
+      return WALDO_EINVAL;
+    }
+    workspace = nullptr;  // shape served by the generic kernel, which needs none
+  }
   WALDO_CALL_LP(wc_bwd_lp, K3 == 19, layers, basis_t, mapping, occ, grad_rgb, grad_alpha,
-                grad_layers, grad_mapping, grad_occ, (int)F, L, H, W, K3, st);
+                grad_layers, grad_mapping, grad_occ, workspace, (int)F, L, H, W, K3, st);
   return launch_status("waldo_warp_composite_bwd");
 }

@@ -13,6 +13,10 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# test hook: route waldo_warp_composite_bwd to the generic per-tap-atomics kernel
+_FORCE_GENERIC_BWD = False
+
+
 # --------------------------------------------------------------------------------------
 # A2: TPS
 # --------------------------------------------------------------------------------------
@@ -201,10 +205,7 @@ class _WarpComposite(torch.autograd.Function):
                       w, k3, _lib.current_stream(layers.device))
         ctx.save_for_backward(layers, mapping, occ, basis_t)
         ctx.want_alpha = want_alpha
-        if want_alpha:
-            return rgb, alpha
-        ctx.mark_non_differentiable()
-        return rgb, None
+        return rgb, alpha
 
     @staticmethod
     def backward(ctx, grad_rgb, grad_alpha):
@@ -217,11 +218,14 @@ class _WarpComposite(torch.autograd.Function):
         gl = torch.zeros_like(layers)
         gm = torch.zeros_like(mapping) if ctx.needs_input_grad[1] else None
         go = torch.zeros_like(occ) if ctx.needs_input_grad[2] else None
+        ws_bytes = 0 if _FORCE_GENERIC_BWD else \
+            _lib.load().waldo_warp_composite_bwd_workspace_bytes(f, nl, h, w, k3)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=layers.device) if ws_bytes else None
         with torch.cuda.device(layers.device):
             _lib.call("waldo_warp_composite_bwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(grad_rgb), _lib.ptr(grad_alpha),
-                      _lib.ptr(gl), _lib.ptr(gm), _lib.ptr(go), f, nl, h, w, k3,
-                      _lib.current_stream(layers.device))
+                      _lib.ptr(gl), _lib.ptr(gm), _lib.ptr(go), _lib.ptr(ws), ws_bytes, f, nl, h,
+                      w, k3, _lib.current_stream(layers.device))
         return gl, gm, go, None, None
 
 
