@@ -105,13 +105,15 @@ int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const fl
                              int W, int K3, waldo_stream_t stream);
 /* Backward of the above.
  *   grad_rgb (F,3,H,W); grad_alpha (F,L,H,W) or NULL;
- *   grad_layers (F,L,4,H,W): must be ZERO-FILLED by the caller (texels shared by several
- *       workgroups are accumulated with atomics; the rest is written with plain stores);
- *   grad_mapping (F*L,K3,2): must be ZERO-FILLED by the caller; may be NULL to skip;
- *   grad_occ (F,L,L): must be ZERO-FILLED by the caller; may be NULL to skip;
- *   workspace: scratch of at least waldo_warp_composite_bwd_workspace_bytes() bytes (16-byte
- *       aligned, contents irrelevant) enabling the tiled kernel (K3 == 19, L <= 8); NULL selects
- *       the generic per-tap-atomics kernel, which is also what other shapes use. */
+ *   workspace: scratch of at least waldo_warp_composite_bwd_workspace_bytes() bytes (256-byte
+ *       aligned, contents irrelevant).  Non-NULL selects the two-kernel path (K3 == 19, L <= 8:
+ *       pixel kernel + per-source-tile gather, no global atomics, bitwise reproducible
+ *       grad_layers / grad_mapping); NULL -- and every other shape, for which the size query
+ *       returns 0 -- selects the generic per-tap-atomics kernel.
+ *   grad_layers (F,L,4,H,W): with a workspace it is OVERWRITTEN (every texel written once);
+ *       without, it must be ZERO-FILLED by the caller (accumulated with float atomics);
+ *   grad_mapping (F*L,K3,2): must be ZERO-FILLED by the caller (accumulated into); NULL to skip;
+ *   grad_occ (F,L,L): must be ZERO-FILLED by the caller (float atomics); NULL to skip. */
 int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, int H, int W, int K3);
 int waldo_warp_composite_bwd(const float* layers, const float* basis_t, const float* mapping,
                              const float* occ, const float* grad_rgb, const float* grad_alpha,

@@ -15,6 +15,7 @@ int launch_status(const char* what);
 
 constexpr int kWave = 64;   // gfx950 wavefront
 constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
+constexpr int kTileW = 64;  // pixel tiles are 64 columns wide: one wavefront = one row segment
 
 // ---------------------------------------------------------------------------------------
 // Bilinear taps of grid_sample(mode=bilinear, padding_mode=zeros, align_corners=False).

@@ -29,8 +29,9 @@ static int check_common(const char* fn, int64_t F, int L, int H, int W, int K3) 
               (long long)F, L, H, W, K3, kMaxLayers, kMaxK3);
     return WALDO_EINVAL;
   }
-  if (F > 65535 || (int64_t)H * W > (int64_t)2147483647 / 4) {
-    set_error("%s: F=%lld (max 65535 per launch) or H*W=%lld too large", fn, (long long)F,
+  if (F > 65535 || F * L > 65535 || (int64_t)H * W > (int64_t)2147483647 / 4 || H > 32767 ||
+      W > 32767) {
+    set_error("%s: F*L=%lld (max 65535 per launch) or H*W=%lld too large", fn, (long long)F * L,
               (long long)H * W);
     return WALDO_EINVAL;
   }
@@ -53,12 +54,17 @@ using namespace waldo;
 
 extern "C" int waldo_max_layers(void) { return kMaxLayers; }
 
-// tiled backward: per (frame, layer, 8x64-pixel tile) one int4 bounding box and one (19,2) float
-// partial of the control-point gradient
+// two-kernel backward (K3 == 19, L <= 8): footprint table of the 8x16-pixel cells (box + bound),
+// one 16-byte record per (frame, layer, pixel), control-point partials of the 4x64 pixel tiles
+// (same layout as bwd2_layout in warp_composite_kernels.hip.h)
 static int64_t bwd_workspace_bytes(int64_t F, int L, int H, int W, int K3) {
   if (K3 != 19 || L > 8) return 0;
-  const int64_t ntiles = (int64_t)((W + 63) / 64) * ((H + 7) / 8);
-  return F * L * ntiles * 16 + F * ntiles * L * 19 * 2 * 4;
+  const int64_t nt1 = (int64_t)((W + 63) / 64) * ((H + 3) / 4);
+  const int64_t ncells = (int64_t)((W + 15) / 16) * ((H + 7) / 8);
+  const int64_t box = ((F * L * ncells * 16 + 255) / 256) * 256;
+  const int64_t bnd = ((F * L * ncells * 4 + 255) / 256) * 256;
+  const int64_t rec = ((F * L * (int64_t)H * W * 16 + 255) / 256) * 256;
+  return box + bnd + rec + F * nt1 * L * 19 * 2 * 4;
 }
 
 extern "C" int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, int H, int W,

@@ -31,7 +31,6 @@ namespace waldo {
 
 constexpr int kMaxLayers = 32;
 constexpr int kMaxK3 = 32;
-constexpr int kTileW = 64;  // one wavefront = 64 consecutive pixels of a row
 constexpr int kFwdGroup = 4;  // layers whose tap loads are issued together (forward)
 constexpr int kBwdGroup = 2;  // same, tiled backward
 
@@ -296,128 +295,83 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// tiled backward: bounding-box pre-pass
-//   bbox[((f*L + l)*ntiles + tile)] = (x_min, x_max, y_min, y_max) inclusive, over the IN-RANGE
-//   taps of the tile's pixels; empty = (1, 0, 1, 0).
-// ---------------------------------------------------------------------------------------
-template <int LP, int K3P, bool EXL, bool EXK>
-__global__ __launch_bounds__(kBlock) void warp_composite_bbox_kernel(
-    const float* __restrict__ basis_t, const float* __restrict__ mapping, int4* __restrict__ bbox,
-    int F, int Lrt, int H, int W, int K3rt, int rows_per_tile, int ntx, int ntiles) {
-  const int L = EXL ? LP : Lrt;
-  const int K3 = EXK ? K3P : K3rt;
-  const int64_t HW = (int64_t)H * W;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x, f = blockIdx.y;
-  __shared__ int red[4][LP][4];
-  int xmin[LP], xmax[LP], ymin[LP], ymax[LP];
-#pragma unroll
-  for (int l = 0; l < LP; ++l) {
-    xmin[l] = ymin[l] = 1 << 30;
-    xmax[l] = ymax[l] = -(1 << 30);
-  }
-  for (int r = wave; r < rows_per_tile; r += 4) {
-    const PixelMap pm = pixel_of(tile, r, lane, H, W, rows_per_tile, ntx);
-    float bas[K3P];
-    load_basis<K3P, EXK>(bas, basis_t, HW, pm.p, K3);
-#pragma unroll
-    for (int l = 0; l < LP; ++l) {
-      const int lc = EXL ? l : min(l, L - 1);
-      float gx, gy;
-      tps_eval<K3P, EXK>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, gx, gy);
-      const Taps t = make_taps(gx, gy, H, W);
-      if (pm.live) {
-        const bool anyx = (t.vx0 + t.vx1) > 0.0f, anyy = (t.vy0 + t.vy1) > 0.0f;
-        if (anyx && anyy) {
-          const int xa = t.vx0 > 0.0f ? t.x0 : t.x0 + 1, xb = t.vx1 > 0.0f ? t.x0 + 1 : t.x0;
-          const int ya = t.vy0 > 0.0f ? t.y0 : t.y0 + 1, yb = t.vy1 > 0.0f ? t.y0 + 1 : t.y0;
-          xmin[l] = min(xmin[l], xa);
-          xmax[l] = max(xmax[l], xb);
-          ymin[l] = min(ymin[l], ya);
-          ymax[l] = max(ymax[l], yb);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < LP; ++l) {
-    const int a = wave_min_i(xmin[l]), b = wave_max_i(xmax[l]);
-    const int c = wave_min_i(ymin[l]), d = wave_max_i(ymax[l]);
-    if (lane == 0) {
-      red[wave][l][0] = a;
-      red[wave][l][1] = b;
-      red[wave][l][2] = c;
-      red[wave][l][3] = d;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < L) {
-    const int l = threadIdx.x;
-    int a = 1 << 30, b = -(1 << 30), c = 1 << 30, d = -(1 << 30);
-    for (int w = 0; w < 4; ++w) {
-      a = min(a, red[w][l][0]);
-      b = max(b, red[w][l][1]);
-      c = min(c, red[w][l][2]);
-      d = max(d, red[w][l][3]);
-    }
-    if (a > b || c > d) {
-      a = 1; b = 0; c = 1; d = 0;
-    }
-    bbox[((int64_t)f * L + l) * ntiles + tile] = make_int4(a, b, c, d);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// tiled backward (K3 == 19, L <= 8)
+// two-kernel backward (K3 == 19, L <= 8)
 //
-// Hardware facts this kernel is built around (measured on MI355X, tools_dev/lds_atomic_bench.hip):
+//   K1  warp_composite_bwd_px_kernel    pixel-major, 4x64-pixel tiles, all layers of a pixel in one
+//       thread: re-sample with derivatives, composite backward, control-point gradient as an f32
+//       MFMA contraction basis^T x grid-grad (per-tile partial, summed by a tiny second kernel),
+//       and per (pixel, layer) a 16-byte RECORD (a'_l, d loss/d s_l3, grid x, grid y) that is all
+//       the splat needs; it also maintains, per (frame, layer, 32x64 splat tile), the bounding box
+//       of the source texels the tile's bilinear footprints touch (packed 16-bit wave min/max,
+//       then integer global atomics).
+//   K2  warp_composite_splat_kernel (warp_composite_splat.hip)   layer-plane-major, 32x64-pixel
+//       tiles: scatter-add of the tile's tap contributions into a FIXED-POINT LDS image of the
+//       bounding box, flushed with PLAIN stores where no other tile's box covers the texel and
+//       float atomics only on the shared rims.
+//
+// Hardware facts this is built around (measured on MI355X, tools_dev/*.hip):
 //   * ds_add_f32 (LDS float atomic) retires ~3 cycles PER LANE (195 cycles per wave-instruction);
-//     ds_add_u32 / ds_add_rtn_u32 / ds_wrxchg_rtn_b32 run at the ds_write_b32 rate (~5 cycles per
-//     wave-instruction).  The per-layer scatter image is therefore accumulated in 32-bit FIXED
-//     POINT with a per-(tile, layer) power-of-two scale chosen so that no texel can overflow;
-//     integer sums are also order-independent, so texels owned by one workgroup are bitwise
-//     reproducible.
-//   * __syncthreads() waits for outstanding global stores / atomics (vmcnt(0)); the layer loop
-//     uses a raw s_barrier behind an LDS-only wait so that a layer's flush overlaps the next
-//     layer's scatter.
-//   * global float atomics from thousands of waves into the same few hundred addresses run ~14x
-//     below the streaming atomic rate: the control-point gradient is reduced inside the workgroup
-//     and stored as a per-tile partial, summed by a second tiny kernel (deterministic).
+//     ds_add_u32 / ds_add_rtn_u32 / ds_wrxchg_rtn_b32 run at the ds_write_b32 rate (~5 cycles).
+//     The scatter image is therefore 32-bit fixed point with a per-tile power-of-two scale chosen
+//     so that no texel can overflow; integer sums are order-independent (bitwise reproducible).
+//   * thousands of waves adding floats to the same few hundred addresses run ~14x below the
+//     streaming atomic rate: the control-point gradient uses per-tile partials + a reduce.
+//   * an 8-row tile shares ~70% of its bounding box with its vertical neighbours (skew of the
+//     warp over 64 columns + the 1-texel bilinear overlap), and shared texels need atomics; the
+//     splat therefore runs on taller tiles than the register-heavy pixel kernel can afford,
+//     which is what the records buy.
 // ---------------------------------------------------------------------------------------
-#ifndef WALDO_BWD_PP
-#define WALDO_BWD_PP 1
+#ifndef WALDO_PX_WAVES
+#define WALDO_PX_WAVES 4
 #endif
-#ifndef WALDO_BWD_WAVES
-#define WALDO_BWD_WAVES 8
+constexpr int kPxWaves = WALDO_PX_WAVES;       // wavefronts per workgroup of K1 (4: two workgroups
+                                               // per CU at 256 VGPRs overlap each other's phases)
+constexpr int kPxThreads = kPxWaves * kWave;
+constexpr int kPxRows = kPxWaves;              // tile = kPxWaves rows x 64 columns, one pixel per thread
+#ifndef WALDO_PX_GROUP
+#define WALDO_PX_GROUP 4
 #endif
-constexpr int kBwdPP = WALDO_BWD_PP;        // pixel rows per thread
-constexpr int kBwdWaves = WALDO_BWD_WAVES;  // wavefronts per workgroup = pixel rows per pass
-constexpr int kBwdThreads = kBwdWaves * kWave;
-constexpr int kBwdRows = kBwdWaves * kBwdPP;  // tile = kBwdRows x 64 pixels
-constexpr int kBwdPix = kBwdRows * kTileW;
-constexpr int kMaxTex = 1280;    // texels of one layer's bounding box kept in LDS (x4 channels)
-constexpr int kMaxNb = 24;       // other tiles whose box intersects ours, per layer
+constexpr int kPxGroup = WALDO_PX_GROUP;       // layers whose tap loads are in flight together
+constexpr int kPxPix = kPxRows * kTileW;
+constexpr int kCellRows = 8, kCellCols = 16;   // cell of the footprint table (see warp_composite_splat.hip)
 constexpr int kGmapK3 = 19;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using short2_ = __attribute__((ext_vector_type(2))) short;
 
-// LDS-only barrier: waits for this wave's LDS traffic, not for its global stores / atomics
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// bytes of workspace per frame/layer/tile (host side uses the same numbers)
-constexpr int64_t kBboxBytes = 16;
 __host__ __device__ constexpr int64_t gmap_partial_floats(int L) { return (int64_t)L * kGmapK3 * 2; }
 
+__device__ __forceinline__ int pk_min(int a, int b) {
+  short2_ x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  short2_ r = __builtin_elementwise_min(x, y);
+  int o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+
+// component-wise minimum of two packed int16 values over each group of 16 consecutive lanes
+__device__ __forceinline__ int group16_pk_min(int v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v = pk_min(v, __shfl_xor(v, d, kWave));
+  return v;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
 template <int LP, bool EXL, bool GOCC>
-__global__ __launch_bounds__(kBwdThreads, kBwdThreads / 256) void warp_composite_bwd2_kernel(
+__global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
-    const int4* __restrict__ bbox, float* __restrict__ gmap_partial,
-    float* __restrict__ grad_layers, float* __restrict__ grad_occ, int F, int Lrt, int H, int W,
-    int ntx, int ntiles) {
+    float4* __restrict__ records, int* __restrict__ cellbox, unsigned* __restrict__ cellbound,
+    float* __restrict__ gmap_partial, float* __restrict__ grad_occ, int F, int Lrt, int H, int W,
+    int ntx, int ntiles, int ncx, int ncells) {
   constexpr int K3 = kGmapK3;
   constexpr int NC = 2 * LP;                 // columns of the grid-gradient matrix (layer, xy)
   constexpr int NT = (NC + 15) / 16;         // 16-column MFMA tiles
@@ -428,167 +382,160 @@ __global__ __launch_bounds__(kBwdThreads, kBwdThreads / 256) void warp_composite
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int tile = blockIdx.x, f = blockIdx.y;
 
-  // One LDS array (cdna guide: a second __shared__ object can de-pipeline the kernel).
-  //   [0, kUnion)        phase 1: gg (grid gradients, [pixel][GGP]) then the per-wave MFMA
-  //                      accumulators; phase 2: the two fixed-point scatter images
-  //   then persistent:   neighbour boxes of every layer, their counts, per-wave bound partials
-  constexpr int kGGFloats = kBwdPix * GGP;
-  constexpr int kAccFloats = kBwdWaves * 2 * NT * 256;
-  constexpr int kImgWords = 2 * 4 * kMaxTex;
-  constexpr int kUnion0 = kGGFloats > kImgWords ? kGGFloats : kImgWords;
-  constexpr int kUnion = kUnion0 > kAccFloats ? kUnion0 : kAccFloats;
-  constexpr int kNbWords = LP * kMaxNb * 4;
-  __shared__ __attribute__((aligned(16))) float lds[kUnion + kNbWords + LP + kBwdWaves * LP];
+  constexpr int kGGFloats = kPxPix * GGP;
+  constexpr int kAccFloats = kPxWaves * 2 * NT * 256;
+  __shared__ __attribute__((aligned(16))) float lds[kGGFloats > kAccFloats ? kGGFloats : kAccFloats];
   float* gg = lds;
-  int* img = reinterpret_cast<int*>(lds);
-  int* nbl = reinterpret_cast<int*>(lds + kUnion);
-  int* nbcount = nbl + kNbWords;
-  float* bpart = lds + kUnion + kNbWords + LP;  // [wave][LP] partial bounds
 
-  // ------------------------------------------------ neighbour boxes of every layer, once
-  if (threadIdx.x < LP) nbcount[threadIdx.x] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int l = 0; l < LP; ++l) {
-    if (EXL || l < L) {
-      const int4 bb = bbox[((int64_t)f * L + l) * ntiles + tile];
-      for (int t = threadIdx.x; t < ntiles; t += kBwdThreads) {
-        const int4 ob = bbox[((int64_t)f * L + l) * ntiles + t];
-        const bool hit = t != tile && ob.x <= ob.y && max(ob.x, bb.x) <= min(ob.y, bb.y) &&
-                         max(ob.z, bb.z) <= min(ob.w, bb.w);
-        if (hit) {
-          const int slot = atomicAdd(&nbcount[l], 1);
-          if (slot < kMaxNb) {
-            int* nb = nbl + (l * kMaxNb + slot) * 4;
-            nb[0] = ob.x;
-            nb[1] = ob.y;
-            nb[2] = ob.z;
-            nb[3] = ob.w;
-          }
-        }
-      }
-    }
-  }
-
-  // ------------------------------------------------------------------ phase 1: per pixel
-  float ap_[kBwdPP][LP], gsa_[kBwdPP][LP], gx_[kBwdPP][LP], gy_[kBwdPP][LP], gc_[kBwdPP][3];
-  bool live_[kBwdPP];
-  float bound_[LP];  // sum over this thread's pixels of max_c |contribution| per layer
-#pragma unroll
-  for (int l = 0; l < LP; ++l) bound_[l] = 0.0f;
+  const PixelMap pm = pixel_of(tile, wave, lane, H, W, kPxRows, ntx);
+  const float livef = pm.live ? 1.0f : 0.0f;
+  const int64_t p = pm.p;
   const float* oc = occ + (int64_t)f * L * L;
-#pragma unroll
-  for (int q = 0; q < kBwdPP; ++q) {
-    const PixelMap pm = pixel_of(tile, kBwdWaves * q + wave, lane, H, W, kBwdRows, ntx);
-    live_[q] = pm.live;
-    const float livef = pm.live ? 1.0f : 0.0f;
-    const int64_t p = pm.p;
+  float gxs[LP], gys[LP], ap[LP];
+  {
     float bas[K3];
     load_basis<K3, true>(bas, basis_t, HW, p, K3);
-    const float g0 = grad_rgb[(int64_t)f * 3 * HW + p] * livef;
-    const float g1 = grad_rgb[(int64_t)f * 3 * HW + HW + p] * livef;
-    const float g2 = grad_rgb[(int64_t)f * 3 * HW + 2 * HW + p] * livef;
-    gc_[q][0] = g0;
-    gc_[q][1] = g1;
-    gc_[q][2] = g2;
-    const float gmax = fmaxf(fabsf(g0), fmaxf(fabsf(g1), fabsf(g2)));
-    float a[LP], G[LP], dxr[LP], dxa[LP], dyr[LP], dya[LP];
     // (A) grid of every layer first: the basis registers die before the tap loads start
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
       const int lc = EXL ? l : min(l, L - 1);
-      tps_eval<K3, true>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, gx_[q][l], gy_[q][l]);
+      tps_eval<K3, true>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, gxs[l], gys[l]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // (B) taps with derivatives, kBwdGroup layers at a time
-#pragma unroll
-    for (int l = 0; l < LP; ++l) {
-      const int lc = EXL ? l : min(l, L - 1);
-      const Taps t = make_taps(gx_[q][l], gy_[q][l], H, W);
-      const float* base = layers + ((int64_t)f * L + lc) * 4 * HW;
-      float sx[4], sy[4], sv[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, t, sx[c], sy[c]);
-      const bool pad = !EXL && l >= L;
-      a[l] = pad ? 0.0f : (sv[3] + 1.0f) * 0.5f;
-      G[l] = g0 * (sv[0] + 1.0f) + g1 * (sv[1] + 1.0f) + g2 * (sv[2] + 1.0f);
-      dxr[l] = fmaf(g2, sx[2], fmaf(g1, sx[1], g0 * sx[0]));
-      dyr[l] = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
-      dxa[l] = sx[3];
-      dya[l] = sy[3];
-      if (grad_alpha != nullptr && !pad)
-        G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + lc) * HW + p], G[l]);
-      if ((l % kBwdGroup) == kBwdGroup - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    a[0] = 1.0f;
-    float ga[LP];
-#pragma unroll
-    for (int l = 0; l < LP; ++l) ga[l] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int jc = EXL ? j : min(j, L - 1);
-      float tfac[LP], ex[LP];
-      float pre = 1.0f;
-#pragma unroll
-      for (int i = 0; i < LP; ++i) {
-        const int ic = EXL ? i : min(i, L - 1);
-        tfac[i] = 1.0f - a[i] * oc[ic * L + jc];
-        ex[i] = pre;
-        pre *= tfac[i];
-      }
-      float suf = 1.0f;
-#pragma unroll
-      for (int i = LP - 1; i >= 0; --i) {
-        ex[i] *= suf;
-        suf *= tfac[i];
-      }
-      ap_[q][j] = a[j] * pre;  // 0 for padding layers
-      const float gap = G[j];  // d loss / d a'_j
-      ga[j] = fmaf(gap, pre, ga[j]);
-      const float gaj = gap * a[j];
-      float gocc[LP];
-#pragma unroll
-      for (int m = 0; m < LP; ++m) {
-        const int mc = EXL ? m : min(m, L - 1);
-        ga[m] = fmaf(-gaj * oc[mc * L + jc], ex[m], ga[m]);
-        gocc[m] = -gaj * a[m] * ex[m];
-      }
-      if (GOCC && (EXL || j < L)) {  // compile-time: the reduction costs ~60 registers
-        const float redv = wave_transpose_reduce<LP>(gocc, lane);
-        const int m = bitrev6(lane);
-        if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j, redv);
-      }
-    }
-    // a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Grid gradient of every layer.
-    const int pix = q * kBwdThreads + threadIdx.x;
-#pragma unroll
-    for (int l = 0; l < LP; ++l) {
-      const bool pad = !EXL && l >= L;
-      gsa_[q][l] = (l >= 1 && !pad) ? 0.5f * ga[l] : 0.0f;
-      const float gix = fmaf(gsa_[q][l], dxa[l], ap_[q][l] * dxr[l]);
-      const float giy = fmaf(gsa_[q][l], dya[l], ap_[q][l] * dyr[l]);
-      gg[pix * GGP + 2 * l] = gix * (0.5f * (float)W);
-      gg[pix * GGP + 2 * l + 1] = giy * (0.5f * (float)H);
-      // |tap contribution| <= max(|a'_l| max_c |g_c|, |gsa_l|): bilinear weights are <= 1
-      bound_[l] += pm.live ? fmaxf(fabsf(ap_[q][l]) * gmax, fabsf(gsa_[q][l])) : 0.0f;
-    }
-#pragma unroll
-    for (int c = NC; c < GGC; ++c) gg[pix * GGP + c] = 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
   }
-  // per-wave partial of the per-layer bounds (fixed butterfly: deterministic)
+  const float g0 = grad_rgb[(int64_t)f * 3 * HW + p] * livef;
+  const float g1 = grad_rgb[(int64_t)f * 3 * HW + HW + p] * livef;
+  const float g2 = grad_rgb[(int64_t)f * 3 * HW + 2 * HW + p] * livef;
+  float a[LP], G[LP], dxr[LP], dxa[LP], dyr[LP], dya[LP];
+  // footprint-table cell of this lane's 16-pixel group (8 rows x 16 columns of pixels)
+  const int tx = tile % ntx, ty = tile / ntx;
+  const int prow = ty * kPxRows + wave, pcol = tx * kTileW + lane;
+  const int cell = (prow / kCellRows) * ncx + min(pcol, W - 1) / kCellCols;
+  const bool leader = (lane & (kCellCols - 1)) == 0;
+  const float gmax = fmaxf(fabsf(g0), fmaxf(fabsf(g1), fabsf(g2)));
+  // (B) taps with derivatives; footprint box of every layer.  (No sched_barrier grouping here:
+  // with the cross-lane box reduction in the loop, hipcc 7.2 mis-schedules the alpha-gradient
+  // chain across a sched_barrier -- caught by the L == 8 parity tests.)
 #pragma unroll
   for (int l = 0; l < LP; ++l) {
-    const float sblk = wave_sum(bound_[l]);
-    if (lane == 0) bpart[wave * LP + l] = sblk;
+    const int lc = EXL ? l : min(l, L - 1);
+    const Taps t = make_taps(gxs[l], gys[l], H, W);
+    const float* base = layers + ((int64_t)f * L + lc) * 4 * HW;
+    float sx[4], sy[4], sv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, t, sx[c], sy[c]);
+    const bool pad = !EXL && l >= L;
+    a[l] = pad ? 0.0f : (sv[3] + 1.0f) * 0.5f;
+    G[l] = g0 * (sv[0] + 1.0f) + g1 * (sv[1] + 1.0f) + g2 * (sv[2] + 1.0f);
+    dxr[l] = fmaf(g2, sx[2], fmaf(g1, sx[1], g0 * sx[0]));
+    dyr[l] = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
+    dxa[l] = sx[3];
+    dya[l] = sy[3];
+    if (grad_alpha != nullptr && !pad)
+      G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + lc) * HW + p], G[l]);
+    // a wave can have 63 vector-memory operations outstanding: issue the 16 tap loads of
+    // kPxGroup layers together, and make the next group's addresses depend on this group's
+    // results so that the registers of at most one group of loads are live at a time
+    if ((l % kPxGroup) == kPxGroup - 1 && l + 1 < LP)
+      asm volatile("" : "+v"(gxs[l + 1]), "+v"(gys[l + 1]) : "v"(a[l]), "v"(G[l]), "v"(dxa[l]), "v"(dya[l]));
+    if (!pad) {  // compile-time for exact L
+      // in-range corner of the footprint, as (x, y) packed in 16+16 bits; lanes without any
+      // in-range tap carry the neutral element.  Stored negated for the upper corner so that
+      // both reduce with a minimum.
+      const bool anyx = (t.vx0 + t.vx1) > 0.0f, anyy = (t.vy0 + t.vy1) > 0.0f;
+      const bool has = pm.live && anyx && anyy;
+      const int xa = t.vx0 > 0.0f ? t.x0 : t.x0 + 1, xb = t.vx1 > 0.0f ? t.x0 + 1 : t.x0;
+      const int ya = t.vy0 > 0.0f ? t.y0 : t.y0 + 1, yb = t.vy1 > 0.0f ? t.y0 + 1 : t.y0;
+      int lo = has ? (int)(((unsigned)ya << 16) | ((unsigned)xa & 0xffffu)) : 0x7fff7fff;
+      int hi = has ? (int)(((unsigned)(-yb) << 16) | ((unsigned)(-xb) & 0xffffu)) : 0x7fff7fff;
+#ifndef ABL_K1_NOBOX
+      lo = group16_pk_min(lo);
+      hi = group16_pk_min(hi);
+#else
+      asm volatile("" : "+v"(lo), "+v"(hi));
+#endif
+      if (leader && lo != 0x7fff7fff) {
+        int* bb = cellbox + (((int64_t)f * L + l) * ncells + cell) * 4;
+        atomicMin(bb + 0, (int)(short)(lo & 0xffff));   // x min
+        atomicMin(bb + 1, (int)(short)(hi & 0xffff));   // -(x max)
+        atomicMin(bb + 2, lo >> 16);                    // y min
+        atomicMin(bb + 3, hi >> 16);                    // -(y max)
+      }
+    }
   }
-  __syncthreads();  // gg rows, bpart and the neighbour lists are complete
+  a[0] = 1.0f;
+  float ga[LP];
+#pragma unroll
+  for (int l = 0; l < LP; ++l) ga[l] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    const int jc = EXL ? j : min(j, L - 1);
+    float tfac[LP], ex[LP];
+    float pre = 1.0f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+      const int ic = EXL ? i : min(i, L - 1);
+      tfac[i] = 1.0f - a[i] * oc[ic * L + jc];
+      ex[i] = pre;
+      pre *= tfac[i];
+    }
+    float suf = 1.0f;
+#pragma unroll
+    for (int i = LP - 1; i >= 0; --i) {
+      ex[i] *= suf;
+      suf *= tfac[i];
+    }
+    ap[j] = a[j] * pre;      // 0 for padding layers
+    const float gap = G[j];  // d loss / d a'_j
+    ga[j] = fmaf(gap, pre, ga[j]);
+    const float gaj = gap * a[j];
+    float gocc[LP];
+#pragma unroll
+    for (int m = 0; m < LP; ++m) {
+      const int mc = EXL ? m : min(m, L - 1);
+      ga[m] = fmaf(-gaj * oc[mc * L + jc], ex[m], ga[m]);
+      gocc[m] = -gaj * a[m] * ex[m];
+    }
+    if (GOCC && (EXL || j < L)) {  // compile-time: the reduction costs ~60 registers
+      const float redv = wave_transpose_reduce<LP>(gocc, lane);
+      const int m = bitrev6(lane);
+      if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j, redv);
+    }
+  }
+  // a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Records + grid gradient of every layer.
+  const int pix = threadIdx.x;
+#pragma unroll
+  for (int l = 0; l < LP; ++l) {
+    const bool pad = !EXL && l >= L;
+    const float gsa = (l >= 1 && !pad) ? 0.5f * ga[l] : 0.0f;
+    const float gix = fmaf(gsa, dxa[l], ap[l] * dxr[l]);
+    const float giy = fmaf(gsa, dya[l], ap[l] * dyr[l]);
+    gg[pix * GGP + 2 * l] = gix * (0.5f * (float)W);
+    gg[pix * GGP + 2 * l + 1] = giy * (0.5f * (float)H);
+    if (!pad) {
+      // |tap contribution| <= max(|a'_l| max_c |g_c|, |g_alpha|): bilinear weights are <= 1.  The
+      // table keeps the largest 16-pixel row sum of the cell (atomicMax on the bits of a
+      // non-negative float is order-independent: the splat's fixed-point scale is deterministic)
+      const float bnd = group16_sum(pm.live ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f);
+      if (leader && prow < H && pcol < W)
+        atomicMax(cellbound + ((int64_t)f * L + l) * ncells + cell, __float_as_uint(bnd));
+    }
+#ifndef ABL_K1_NOREC
+    if (pm.live && !pad)
+      records[((int64_t)f * L + l) * HW + p] = make_float4(ap[l], gsa, gxs[l], gys[l]);
+#else
+    asm volatile("" :: "v"(ap[l]), "v"(gsa), "v"(gxs[l]), "v"(gys[l]));
+#endif
+  }
+#pragma unroll
+  for (int c = NC; c < GGC; ++c) gg[pix * GGP + c] = 0.0f;
+  __syncthreads();  // gg rows are complete
 
   // ------------------------------------------- control-point gradient: basis^T x gg on the MFMA
   // D[k][col] = sum_pix basis[k][pix] * gg[pix][col]; v_mfma_f32_16x16x4_f32: A[row=lane&15]
   // [kk=lane>>4], B[kk=lane>>4][col=lane&15], D[row=(lane>>4)*4+reg][col=lane&15].  Each wave
-  // contracts the pixels it produced; the 8 wave results are summed through LDS and stored as
-  // this tile's partial (no atomics).
+  // contracts the pixels it produced; the 8 wave results are summed through LDS in a fixed order
+  // and stored as this tile's partial (no atomics, deterministic).
+#ifndef ABL_K1_NOMFMA
   if (gmap_partial != nullptr) {
     f32x4 acc[2][NT];
 #pragma unroll
@@ -597,26 +544,23 @@ __global__ __launch_bounds__(kBwdThreads, kBwdThreads / 256) void warp_composite
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int arow = lane & 15, kk = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < kBwdPP; ++q) {
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const int pl = 4 * s4 + kk;  // column of the contracted pixel inside this wave's row
+      const PixelMap pq = pixel_of(tile, wave, pl, H, W, kPxRows, ntx);
+      const int px = wave * kWave + pl;
+      float av[2];
 #pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        const int pl = 4 * s4 + kk;  // column of the contracted pixel inside this wave's row
-        const PixelMap pm = pixel_of(tile, kBwdWaves * q + wave, pl, H, W, kBwdRows, ntx);
-        const int pix = q * kBwdThreads + wave * kWave + pl;
-        float av[2];
+      for (int mt = 0; mt < 2; ++mt) {
+        const int k = mt * 16 + arow;
+        const float v = basis_t[(int64_t)min(k, K3 - 1) * HW + pq.p];
+        av[mt] = (k < K3) ? v : 0.0f;  // dead pixels carry gg == 0
+      }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const int k = mt * 16 + arow;
-          const float v = basis_t[(int64_t)min(k, K3 - 1) * HW + pm.p];
-          av[mt] = (k < K3) ? v : 0.0f;  // dead pixels carry gg == 0
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = gg[px * GGP + nt * 16 + arow];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float bv = gg[pix * GGP + nt * 16 + arow];
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv, acc[mt][nt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv, acc[mt][nt], 0, 0, 0);
       }
     }
     __syncthreads();  // every wave is done reading gg: reuse its bytes for the accumulators
@@ -628,10 +572,10 @@ __global__ __launch_bounds__(kBwdThreads, kBwdThreads / 256) void warp_composite
         for (int r = 0; r < 4; ++r)
           lds[((wave * 2 + mt) * NT + nt) * 256 + r * 64 + lane] = acc[mt][nt][r];
     __syncthreads();
-    for (int o = threadIdx.x; o < 2 * NT * 256; o += kBwdThreads) {
+    for (int o = threadIdx.x; o < 2 * NT * 256; o += kPxThreads) {
       float sum = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kBwdWaves; ++w) sum += lds[w * 2 * NT * 256 + o];  // fixed order
+      for (int w = 0; w < kPxWaves; ++w) sum += lds[w * 2 * NT * 256 + o];  // fixed order
       const int mt = o / (NT * 256), nt = (o / 256) % NT, r = (o >> 6) & 3, ln = o & 63;
       const int k = mt * 16 + (ln >> 4) * 4 + r;
       const int col = nt * 16 + (ln & 15);
@@ -641,123 +585,7 @@ __global__ __launch_bounds__(kBwdThreads, kBwdThreads / 256) void warp_composite
                      (col & 1)] = sum;
     }
   }
-  __syncthreads();  // gg / accumulators are dead; their bytes become the scatter images
-
-  // ------------------------------------------------------------------ phase 2: per layer
-  for (int e = threadIdx.x; e < kImgWords; e += kBwdThreads) img[e] = 0;
-  __syncthreads();
-
-#pragma unroll
-  for (int l = 0; l < LP; ++l) {
-    if (!EXL && l >= L) break;  // uniform
-    const int buf = l & 1;
-    int* im = img + buf * 4 * kMaxTex;
-    const int* nb = nbl + l * kMaxNb * 4;
-    const int4 bb = bbox[((int64_t)f * L + l) * ntiles + tile];
-    const int bx0 = bb.x, by0 = bb.z;
-    const int bw = bb.y - bb.x + 1, bh = bb.w - bb.z + 1;
-    const bool empty = bw <= 0 || bh <= 0;
-    const bool in_lds = !empty && bw * bh <= kMaxTex;
-    float* gbase = grad_layers + ((int64_t)f * L + l) * 4 * HW;
-    // fixed-point scale: B = sum over the tile's pixels of max_c |contribution| bounds the
-    // magnitude of ANY texel sum; scale = 2^(29 - floor(log2 B)) keeps B * scale < 2^30
-    float B = 0.0f;
-#pragma unroll
-    for (int w = 0; w < kBwdWaves; ++w) B += bpart[w * LP + l];
-    const int eB = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;
-    const int es = min(29 - eB, 126);
-    const float scale = __uint_as_float((unsigned)(127 + es) << 23);
-    const float inv_scale = __uint_as_float((unsigned)(127 - es) << 23);
-    const bool any = B > 0.0f;
-
-    // scatter this thread's taps
-#pragma unroll
-    for (int q = 0; q < kBwdPP; ++q) {
-      if (!live_[q] || !any) continue;
-      // re-derive the taps from the stored grid point; `opaque` stops the compiler from keeping
-      // all 14 tap values of every layer alive since phase 1 instead (register spills)
-      const Taps t = make_taps(opaque(gx_[q][l]), opaque(gy_[q][l]), H, W);
-      float gv[4];
-      gv[0] = ap_[q][l] * gc_[q][0];
-      gv[1] = ap_[q][l] * gc_[q][1];
-      gv[2] = ap_[q][l] * gc_[q][2];
-      gv[3] = gsa_[q][l];
-      if (in_lds) {
-        const int lx = t.x0 - bx0, ly = t.y0 - by0;  // taps with non-zero weight lie in the box
-        const int o00 = ly * bw + lx;
-        const bool t00 = t.w00 != 0.0f, t01 = t.w01 != 0.0f, t10 = t.w10 != 0.0f, t11 = t.w11 != 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          int* pc = im + c * kMaxTex;
-          const float gs = gv[c] * scale;
-          if (t00) atomicAdd(pc + o00, __float2int_rn(gs * t.w00));
-          if (t01) atomicAdd(pc + o00 + 1, __float2int_rn(gs * t.w01));
-          if (t10) atomicAdd(pc + o00 + bw, __float2int_rn(gs * t.w10));
-          if (t11) atomicAdd(pc + o00 + bw + 1, __float2int_rn(gs * t.w11));
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float* pl = gbase + c * HW;
-          if (t.w00 != 0.0f) atomicAdd(pl + (t.o00 >> 2), gv[c] * t.w00);
-          if (t.w01 != 0.0f) atomicAdd(pl + (t.o01 >> 2), gv[c] * t.w01);
-          if (t.w10 != 0.0f) atomicAdd(pl + (t.o10 >> 2), gv[c] * t.w10);
-          if (t.w11 != 0.0f) atomicAdd(pl + (t.o11 >> 2), gv[c] * t.w11);
-        }
-      }
-    }
-    lds_barrier();
-    // flush: plain stores where the texel is ours alone, atomics on shared rims; re-zero the image
-    if (in_lds) {
-      const int nnb = nbcount[l];
-      const bool all_shared = nnb > kMaxNb;
-      const int nn = min(nnb, kMaxNb);
-      const float rcp_bw = 1.0f / (float)bw;
-      constexpr int kIter = (kMaxTex + kBwdThreads - 1) / kBwdThreads;  // texels per thread
-      int ex_[kIter], ey_[kIter];
-      unsigned sharedmask = all_shared ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int it = 0; it < kIter; ++it) {
-        const int e = threadIdx.x + it * kBwdThreads;
-        // e, bw < 2^11: (e + 0.5) / bw is never within fp32 rounding of an integer
-        const int r = (int)(((float)e + 0.5f) * rcp_bw);
-        ex_[it] = bx0 + (e - r * bw);
-        ey_[it] = by0 + r;
-      }
-      for (int n = 0; n < nn; ++n) {  // neighbour box: wave-uniform, read once per thread
-        const int nx0 = __builtin_amdgcn_readfirstlane(nb[n * 4 + 0]);
-        const int nx1 = __builtin_amdgcn_readfirstlane(nb[n * 4 + 1]);
-        const int ny0 = __builtin_amdgcn_readfirstlane(nb[n * 4 + 2]);
-        const int ny1 = __builtin_amdgcn_readfirstlane(nb[n * 4 + 3]);
-#pragma unroll
-        for (int it = 0; it < kIter; ++it) {
-          const bool hit = ex_[it] >= nx0 && ex_[it] <= nx1 && ey_[it] >= ny0 && ey_[it] <= ny1;
-          sharedmask |= hit ? (1u << it) : 0u;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < kIter; ++it) {
-        const int e = threadIdx.x + it * kBwdThreads;
-        if (e < bw * bh) {
-          float* dst = gbase + (int64_t)ey_[it] * W + ex_[it];
-          const bool shared = (sharedmask >> it) & 1u;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int iv = im[c * kMaxTex + e];  // row-major inside the box
-            im[c * kMaxTex + e] = 0;
-            const float v = (float)iv * inv_scale;
-            if (shared) {
-              if (iv != 0) atomicAdd(dst + c * HW, v);
-            } else {
-              dst[c * HW] = v;
-            }
-          }
-        }
-      }
-    }
-    // no second barrier: image `buf` is next written by layer l+2, i.e. after the barrier of
-    // layer l+1, which every thread reaches only after finishing this flush
-  }
+#endif
 }
 
 // second stage of the control-point gradient: grad_mapping[f,l,k,c] += sum_tile partial
@@ -781,6 +609,11 @@ static __global__ __launch_bounds__(kBlock) void warp_composite_gmap_reduce_kern
   for (; t < ntiles; ++t) s0 += src[(int64_t)t * per];
   grad_mapping[e] += (s0 + s1) + (s2 + s3);
 }
+
+// K2 (compiled once, warp_composite_splat.hip)
+void launch_splat(const float* records, const float* grad_rgb, const int* cellbox,
+                  const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
+                  hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // host launchers
@@ -826,10 +659,23 @@ static void launch_bwd(const float* layers, const float* basis_t, const float* m
                      grad_occ, F, L, H, W, K3);
 }
 
-// tiled backward; `workspace` = [F*L*ntiles int4 boxes | F*ntiles*L*38 float partials]
-static inline int64_t bwd2_workspace_bytes(int64_t F, int L, int H, int W) {
-  const TileGeom g = tile_geom(H, W, kBwdRows);
-  return F * L * g.ntiles * kBboxBytes + F * g.ntiles * gmap_partial_floats(L) * 4;
+// two-kernel backward; workspace = [cell boxes | cell bounds | records | control-point partials]
+struct Bwd2Layout {
+  int64_t box_bytes, bound_bytes, rec_bytes, part_bytes;
+  TileGeom g1;
+  int ncx, ncells;
+};
+
+static inline Bwd2Layout bwd2_layout(int64_t F, int L, int H, int W) {
+  Bwd2Layout o;
+  o.g1 = tile_geom(H, W, kPxRows);
+  o.ncx = (W + kCellCols - 1) / kCellCols;
+  o.ncells = o.ncx * ((H + kCellRows - 1) / kCellRows);
+  o.box_bytes = ((F * L * o.ncells * 16 + 255) / 256) * 256;
+  o.bound_bytes = ((F * L * o.ncells * 4 + 255) / 256) * 256;
+  o.rec_bytes = ((F * L * (int64_t)H * W * 16 + 255) / 256) * 256;
+  o.part_bytes = F * o.g1.ntiles * gmap_partial_floats(L) * 4;
+  return o;
 }
 
 template <int LP>
@@ -837,20 +683,24 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
                         const float* occ, const float* grad_rgb, const float* grad_alpha,
                         void* workspace, float* grad_layers, float* grad_mapping, float* grad_occ,
                         int F, int L, int H, int W, hipStream_t st) {
-  const TileGeom g = tile_geom(H, W, kBwdRows);
-  dim3 grid(g.ntiles, F);
-  int4* bb = reinterpret_cast<int4*>(workspace);
+  const Bwd2Layout lo = bwd2_layout(F, L, H, W);
+  char* ws = reinterpret_cast<char*>(workspace);
+  int* boxes = reinterpret_cast<int*>(ws);
+  unsigned* bounds = reinterpret_cast<unsigned*>(ws + lo.box_bytes);
+  float4* rec = reinterpret_cast<float4*>(ws + lo.box_bytes + lo.bound_bytes);
   float* part = grad_mapping == nullptr
                     ? nullptr
-                    : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
-                                               (int64_t)F * L * g.ntiles * kBboxBytes);
+                    : reinterpret_cast<float*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes);
+  // boxes are (min x, -max x, min y, -max y): every component starts at a large positive value;
+  // bounds start at +0.0f
+  (void)hipMemsetAsync(boxes, 0x7f, (size_t)lo.box_bytes, st);
+  (void)hipMemsetAsync(bounds, 0, (size_t)lo.bound_bytes, st);
+  dim3 grid(lo.g1.ntiles, F);
   auto go = [&](auto exl, auto gocc) {
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
-    hipLaunchKernelGGL((warp_composite_bbox_kernel<LP, 19, EXL, true>), grid, dim3(kBlock), 0, st,
-                       basis_t, mapping, bb, F, L, H, W, 19, kBwdRows, g.ntx, g.ntiles);
-    hipLaunchKernelGGL((warp_composite_bwd2_kernel<LP, EXL, GOCC>), grid, dim3(kBwdThreads), 0, st,
-                       layers, basis_t, mapping, occ, grad_rgb, grad_alpha, bb, part, grad_layers,
-                       grad_occ, F, L, H, W, g.ntx, g.ntiles);
+    hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,
+                       layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
+                       grad_occ, F, L, H, W, lo.g1.ntx, lo.g1.ntiles, lo.ncx, lo.ncells);
   };
   using T = std::true_type;
   using N = std::false_type;
@@ -862,8 +712,10 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   if (part != nullptr) {
     const int64_t n = (int64_t)F * gmap_partial_floats(L);
     hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, part, grad_mapping, F, L, g.ntiles);
+                       dim3(kBlock), 0, st, part, grad_mapping, F, L, lo.g1.ntiles);
   }
+  launch_splat(reinterpret_cast<const float*>(rec), grad_rgb, boxes, bounds, grad_layers, F, L, H,
+               W, st);
 }
 
 }  // namespace waldo

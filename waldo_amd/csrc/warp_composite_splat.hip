@@ -1,0 +1,204 @@
+// K2 of the two-kernel backward: gradient w.r.t. one layer plane, gathered per SOURCE tile.
+//
+// Restates the input-gradient of F.grid_sample (bilinear, zeros, align_corners=False) -- the
+// four-corner scatter of grad * weight that the reference gets from autograd through
+// models/nets/lvd.py:548,559 -- for the records the pixel kernel (K1) left behind:
+//   record (a'_l, g_alpha, grid x, grid y) per (frame, layer, pixel); the contribution of pixel p
+//   to channel c < 3 of layer l is a'_l * grad_rgb[c][p], to the alpha channel g_alpha.
+//
+// One workgroup OWNS one 32x64-texel tile S of one layer's gradient plane: it is the only writer
+// of those texels, so the whole plane is written with plain, row-coalesced stores -- no global
+// atomics, no zero-fill of the output, and a bitwise reproducible result.  The pixels that can
+// touch S are found through K1's cell table: per 8x16-pixel cell the bounding box of the texels
+// its bilinear footprints reach (the warp's skew over 16 columns is small, so the boxes are
+// tight) and an upper bound of the cell's contribution magnitudes.  The workgroup visits the
+// cells whose box intersects S, re-derives the taps of their pixels from the records and sums
+// the taps that fall into S in a 32-bit FIXED-POINT LDS image: integer LDS atomics run at the
+// plain ds_write rate on gfx950 while ds_add_f32 retires ~3 cycles per lane
+// (tools_dev/lds_atomic_bench*.hip); integer sums are also order-independent.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+constexpr int kSrcRows = 32, kSrcCols = 64;          // S tile
+constexpr int kSrcTex = kSrcRows * kSrcCols;          // 2048 texels (x4 channels)
+constexpr int kCellRows = 8, kCellCols = 16;          // K1's cell (must match the pixel kernel)
+constexpr int kCellPix = kCellRows * kCellCols;       // 128
+constexpr int kG2Waves = 8;
+constexpr int kG2Threads = kG2Waves * kWave;          // 512
+constexpr int kMaxHit = 192;                          // cells listed per tile (else: slow scan)
+
+__device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
+  const int4 r = reinterpret_cast<const int4*>(cellbox)[idx];
+  return make_int4(r.x, -r.y, r.z, -r.w);  // (x min, x max, y min, y max); empty: x min > x max
+}
+
+// LDS image of S: [channel][row][kPitch] int32.  kPitch = 80 = 16 (mod 32): the LDS serves a
+// wave-instruction as two 32-lane halves over 32 banks; a wave covers 4 pixel rows x 16 columns,
+// so with this pitch the two rows of a half land on disjoint bank ranges (pitch 64 is a 4-way
+// conflict).  Behind the image, one dump word per lane takes the taps that fall outside S.
+constexpr int kPitch = 80;
+constexpr int kImgWords = kSrcRows * kPitch;           // per channel
+constexpr int kDump = 4 * kImgWords;                   // + lane
+
+// taps of one candidate pixel into the S image.  Branch-free: a tap outside S (or outside the
+// layer, or with zero weight) adds 0 to the lane's own dump word -- never to a shared address,
+// where same-address adds would serialise.
+__device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const Taps& t,
+                                            const float4 rec, float g0, float g1, float g2,
+                                            float scale, int sx0, int sy0) {
+  const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
+  const bool cx0 = lx0 >= 0 && lx0 < kSrcCols, cx1 = lx0 + 1 >= 0 && lx0 + 1 < kSrcCols;
+  const bool cy0 = ly0 >= 0 && ly0 < kSrcRows, cy1 = ly0 + 1 >= 0 && ly0 + 1 < kSrcRows;
+  const bool in00 = on && cx0 && cy0 && t.w00 != 0.0f, in01 = on && cx1 && cy0 && t.w01 != 0.0f;
+  const bool in10 = on && cx0 && cy1 && t.w10 != 0.0f, in11 = on && cx1 && cy1 && t.w11 != 0.0f;
+  const int base = ly0 * kPitch + lx0;
+  const int dump = kDump + lane;
+  float gv[4];
+  gv[0] = rec.x * g0;
+  gv[1] = rec.x * g1;
+  gv[2] = rec.x * g2;
+  gv[3] = rec.y;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int cb = base + c * kImgWords;
+    const float gs = gv[c] * scale;
+    atomicAdd(img + (in00 ? cb : dump), in00 ? __float2int_rn(gs * t.w00) : 0);
+    atomicAdd(img + (in01 ? cb + 1 : dump), in01 ? __float2int_rn(gs * t.w01) : 0);
+    atomicAdd(img + (in10 ? cb + kPitch : dump), in10 ? __float2int_rn(gs * t.w10) : 0);
+    atomicAdd(img + (in11 ? cb + kPitch + 1 : dump), in11 ? __float2int_rn(gs * t.w11) : 0);
+  }
+}
+
+// does any tap of this pixel fall into S?
+__device__ __forceinline__ bool touches(const Taps& t, int sx0, int sy0) {
+  const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
+  return lx0 >= -1 && lx0 < kSrcCols && ly0 >= -1 && ly0 < kSrcRows;
+}
+
+__global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
+    const float4* __restrict__ records, const float* __restrict__ grad_rgb,
+    const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
+    float* __restrict__ grad_layers, int L, int H, int W, int nsx, int ncx, int ncells) {
+  const int64_t HW = (int64_t)H * W;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int64_t fl = blockIdx.y;  // f * L + l
+  const int64_t f = fl / L;
+  const int sx0 = (blockIdx.x % nsx) * kSrcCols, sy0 = (blockIdx.x / nsx) * kSrcRows;
+  const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
+
+  __shared__ __attribute__((aligned(16))) int lds[4 * kImgWords + kWave + kMaxHit + 2 * kG2Waves + 4];
+  int* img = lds;
+  int* hitlist = lds + 4 * kImgWords + kWave;
+  int* wcount = hitlist + kMaxHit;                      // hits per wave (current chunk)
+  float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);
+
+  for (int e = threadIdx.x; e < 4 * kImgWords + kWave; e += kG2Threads) img[e] = 0;
+
+  // ---- cells whose box reaches S, listed in cell order (deterministic), and the sum of their
+  // contribution bounds.  Chunks of kG2Threads cells; ballot-based compaction inside a wave.
+  int nhit = 0;
+  float bsum = 0.0f;
+  const float cell_rows = (float)kCellRows;
+  for (int c0 = 0; c0 < ncells; c0 += kG2Threads) {
+    const int c = c0 + threadIdx.x;
+    bool hit = false;
+    float bnd = 0.0f;
+    if (c < ncells) {
+      const int4 ob = load_box(cellbox, fl * ncells + c);
+      hit = ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
+      // K1 publishes the largest 16-pixel row sum of the cell; a cell has kCellRows rows
+      if (hit) bnd = __uint_as_float(cellbound[fl * ncells + c]) * cell_rows;
+    }
+    const unsigned long long m = __ballot(hit);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    float wsum = bnd;  // fixed butterfly: deterministic
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
+    if (lane == 0) {
+      wcount[wave] = __popcll(m);
+      wbound[wave] = wsum;
+    }
+    __syncthreads();
+    int base = nhit;
+#pragma unroll
+    for (int w = 0; w < kG2Waves; ++w) {
+      if (w < wave) base += wcount[w];
+      nhit += wcount[w];
+      bsum += wbound[w];
+    }
+    if (hit && base + before < kMaxHit) hitlist[base + before] = c;
+    __syncthreads();
+  }
+  // fixed-point scale: bsum bounds the magnitude of ANY texel sum (bilinear weights are <= 1);
+  // scale = 2^(29 - floor(log2 bsum)) keeps |sum| * scale < 2^30
+  const int eB = (int)((__float_as_uint(bsum) >> 23) & 0xffu) - 127;
+  const int es = min(29 - eB, 126);
+  const float scale = __uint_as_float((unsigned)(127 + es) << 23);
+  const float inv_scale = __uint_as_float((unsigned)(127 - es) << 23);
+  const float* gplane = grad_rgb + f * 3 * HW;
+  const float4* rplane = records + fl * HW;
+
+  if (bsum > 0.0f) {
+    if (nhit <= kMaxHit) {
+      // candidates: 128 pixels per listed cell; a wave takes 4 rows x 16 columns of one cell
+      const int total = nhit * kCellPix;
+      for (int i = threadIdx.x; i < total; i += kG2Threads) {
+        const int c = hitlist[i >> 7];
+        const int within = i & (kCellPix - 1);
+        const int py = (c / ncx) * kCellRows + (within >> 4);
+        const int px = (c % ncx) * kCellCols + (within & 15);
+        // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
+        const bool livep = py < H && px < W;
+        const unsigned p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
+        const float4 rec = rplane[p];
+        const Taps t = make_taps(rec.z, rec.w, H, W);
+        const bool any = livep && touches(t, sx0, sy0);
+        if (__ballot(any) == 0ull) continue;  // wave-uniform
+        splat_pixel(img, lane, any, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p], scale,
+                    sx0, sy0);
+      }
+    } else {
+      // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
+      for (int c = 0; c < ncells; ++c) {
+        const int4 ob = load_box(cellbox, fl * ncells + c);
+        const bool hit = ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
+        if (!hit || threadIdx.x >= kCellPix) continue;
+        const int py = (c / ncx) * kCellRows + (threadIdx.x >> 4);
+        const int px = (c % ncx) * kCellCols + (threadIdx.x & 15);
+        if (py < H && px < W) {
+          const unsigned p = (unsigned)(__mul24(py, W) + px);
+          const float4 rec = rplane[p];
+          const Taps t = make_taps(rec.z, rec.w, H, W);
+          splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
+                      scale, sx0, sy0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- S is ours alone: plain row-coalesced stores (zeros included)
+  float* gbase = grad_layers + fl * 4 * HW;
+  for (int e = threadIdx.x; e < kSrcTex; e += kG2Threads) {
+    const int y = sy0 + (e >> 6), x = sx0 + (e & 63);
+    if (y < H && x < W) {
+      const unsigned doff = (unsigned)(__mul24(y, W) + x);
+      const int li = (e >> 6) * kPitch + (e & 63);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) (gbase + c * HW)[doff] = (float)img[c * kImgWords + li] * inv_scale;
+    }
+  }
+}
+
+void launch_splat(const float* records, const float* grad_rgb, const int* cellbox,
+                  const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
+                  hipStream_t st) {
+  const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
+  const int ncx = (W + kCellCols - 1) / kCellCols, ncy = (H + kCellRows - 1) / kCellRows;
+  dim3 grid(nsx * nsy, F * L);
+  hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
+                     reinterpret_cast<const float4*>(records), grad_rgb, cellbox, cellbound,
+                     grad_layers, L, H, W, nsx, ncx, ncx * ncy);
+}
+
+}  // namespace waldo

@@ -215,12 +215,14 @@ class _WarpComposite(torch.autograd.Function):
         grad_rgb = _c(grad_rgb)
         if grad_alpha is not None:
             grad_alpha = _c(grad_alpha)
-        gl = torch.zeros_like(layers)
         gm = torch.zeros_like(mapping) if ctx.needs_input_grad[1] else None
         go = torch.zeros_like(occ) if ctx.needs_input_grad[2] else None
         ws_bytes = 0 if _FORCE_GENERIC_BWD else \
             _lib.load().waldo_warp_composite_bwd_workspace_bytes(f, nl, h, w, k3)
         ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=layers.device) if ws_bytes else None
+        # with a workspace the two-kernel path writes every texel of grad_layers exactly once;
+        # the generic kernel accumulates with atomics into a zero-filled buffer
+        gl = torch.empty_like(layers) if ws_bytes else torch.zeros_like(layers)
         with torch.cuda.device(layers.device):
             _lib.call("waldo_warp_composite_bwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(grad_rgb), _lib.ptr(grad_alpha),
