@@ -57,10 +57,12 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   t.vy1 = (y1 >= 0 && y1 < Hi) ? 1.0f : 0.0f;
   int cx0 = min(max(x0, 0), Wi - 1), cx1 = min(max(x1, 0), Wi - 1);
   int cy0 = min(max(y0, 0), Hi - 1), cy1 = min(max(y1, 0), Hi - 1);
-  t.o00 = (uint32_t)(cy0 * Wi + cx0) * 4u;
-  t.o01 = (uint32_t)(cy0 * Wi + cx1) * 4u;
-  t.o10 = (uint32_t)(cy1 * Wi + cx0) * 4u;
-  t.o11 = (uint32_t)(cy1 * Wi + cx1) * 4u;
+  // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): Hi, Wi < 2^15
+  const int r0 = __mul24(cy0, Wi), r1 = __mul24(cy1, Wi);
+  t.o00 = (uint32_t)(r0 + cx0) * 4u;
+  t.o01 = (uint32_t)(r0 + cx1) * 4u;
+  t.o10 = (uint32_t)(r1 + cx0) * 4u;
+  t.o11 = (uint32_t)(r1 + cx1) * 4u;
   float wx0 = (1.0f - t.fx) * t.vx0, wx1 = t.fx * t.vx1;
   float wy0 = (1.0f - t.fy) * t.vy0, wy1 = t.fy * t.vy1;
   t.w00 = wx0 * wy0;

@@ -365,27 +365,37 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 template <int LP, bool EXL, bool GOCC>
-__global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
+__global__ __launch_bounds__(kPxThreads, GOCC ? 2 : 4) void warp_composite_bwd_px_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
-    float4* __restrict__ records, int* __restrict__ cellbox, unsigned* __restrict__ cellbound,
+    float2* __restrict__ rec_g, float2* __restrict__ rec_a, int* __restrict__ cellbox,
+    unsigned* __restrict__ cellbound,
     float* __restrict__ gmap_partial, float* __restrict__ grad_occ, int F, int Lrt, int H, int W,
     int ntx, int ntiles, int ncx, int ncells) {
   constexpr int K3 = kGmapK3;
   constexpr int NC = 2 * LP;                 // columns of the grid-gradient matrix (layer, xy)
   constexpr int NT = (NC + 15) / 16;         // 16-column MFMA tiles
   constexpr int GGC = NT * 16;               // padded column count of gg
-  constexpr int GGP = GGC + 1;               // odd LDS row pitch: conflict-free lane-strided writes
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int tile = blockIdx.x, f = blockIdx.y;
 
-  constexpr int kGGFloats = kPxPix * GGP;
+  // LDS, one array, column-major per pixel with pitch kPxPix + 1 (bank = (row + pixel) mod 32:
+  // conflict-free both for a wave writing its 64 pixels of one row and for the MFMA operand reads):
+  //   rows 0 .. 4*LP-1   the parked tap derivatives (d s_rgb.g / dx, d s_a / dx, .. / dy) of every
+  //                      layer -- they are only needed after the composite, and keeping them in
+  //                      registers is what pushed this kernel to 256 VGPRs / 2 waves per SIMD;
+  //   rows 0 .. GGC-1    afterwards: the grid gradients gg (MFMA B operand);
+  //   then               the per-wave MFMA accumulators.
+  constexpr int PP1 = kPxPix + 1;
+  constexpr int kParkRows = 4 * LP > GGC ? 4 * LP : GGC;
   constexpr int kAccFloats = kPxWaves * 2 * NT * 256;
-  __shared__ __attribute__((aligned(16))) float lds[kGGFloats > kAccFloats ? kGGFloats : kAccFloats];
+  constexpr int kLdsFloats = kParkRows * PP1 > kAccFloats ? kParkRows * PP1 : kAccFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* gg = lds;
+  const int pix = threadIdx.x;
 
   const PixelMap pm = pixel_of(tile, wave, lane, H, W, kPxRows, ntx);
   const float livef = pm.live ? 1.0f : 0.0f;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
   const float g0 = grad_rgb[(int64_t)f * 3 * HW + p] * livef;
   const float g1 = grad_rgb[(int64_t)f * 3 * HW + HW + p] * livef;
   const float g2 = grad_rgb[(int64_t)f * 3 * HW + 2 * HW + p] * livef;
-  float a[LP], G[LP], dxr[LP], dxa[LP], dyr[LP], dya[LP];
+  float a[LP], G[LP];
   // footprint-table cell of this lane's 16-pixel group (8 rows x 16 columns of pixels)
   const int tx = tile % ntx, ty = tile / ntx;
   const int prow = ty * kPxRows + wave, pcol = tx * kTileW + lane;
@@ -426,17 +436,19 @@ __global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
     const bool pad = !EXL && l >= L;
     a[l] = pad ? 0.0f : (sv[3] + 1.0f) * 0.5f;
     G[l] = g0 * (sv[0] + 1.0f) + g1 * (sv[1] + 1.0f) + g2 * (sv[2] + 1.0f);
-    dxr[l] = fmaf(g2, sx[2], fmaf(g1, sx[1], g0 * sx[0]));
-    dyr[l] = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
-    dxa[l] = sx[3];
-    dya[l] = sy[3];
+    lds[(4 * l + 0) * PP1 + pix] = fmaf(g2, sx[2], fmaf(g1, sx[1], g0 * sx[0]));
+    lds[(4 * l + 1) * PP1 + pix] = sx[3];
+    lds[(4 * l + 2) * PP1 + pix] = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
+    lds[(4 * l + 3) * PP1 + pix] = sy[3];
+    // the grid point is final: half of the record goes out now, its registers are free afterwards
+    if (pm.live && !pad) rec_g[((int64_t)f * L + l) * HW + p] = make_float2(gxs[l], gys[l]);
     if (grad_alpha != nullptr && !pad)
       G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + lc) * HW + p], G[l]);
     // a wave can have 63 vector-memory operations outstanding: issue the 16 tap loads of
     // kPxGroup layers together, and make the next group's addresses depend on this group's
     // results so that the registers of at most one group of loads are live at a time
     if ((l % kPxGroup) == kPxGroup - 1 && l + 1 < LP)
-      asm volatile("" : "+v"(gxs[l + 1]), "+v"(gys[l + 1]) : "v"(a[l]), "v"(G[l]), "v"(dxa[l]), "v"(dya[l]));
+      asm volatile("" : "+v"(gxs[l + 1]), "+v"(gys[l + 1]) : "v"(a[l]), "v"(G[l]));
     if (!pad) {  // compile-time for exact L
       // in-range corner of the footprint, as (x, y) packed in 16+16 bits; lanes without any
       // in-range tap carry the neutral element.  Stored negated for the upper corner so that
@@ -501,16 +513,18 @@ __global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
       if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j, redv);
     }
   }
-  // a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Records + grid gradient of every layer.
-  const int pix = threadIdx.x;
+  // a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Second half of the records, cell
+  // bounds, and the grid gradient of every layer (read this thread's parked derivatives, then
+  // overwrite the same LDS column with gg -- no other thread touches this column).
+  float ggx[LP], ggy[LP];
 #pragma unroll
   for (int l = 0; l < LP; ++l) {
     const bool pad = !EXL && l >= L;
     const float gsa = (l >= 1 && !pad) ? 0.5f * ga[l] : 0.0f;
-    const float gix = fmaf(gsa, dxa[l], ap[l] * dxr[l]);
-    const float giy = fmaf(gsa, dya[l], ap[l] * dyr[l]);
-    gg[pix * GGP + 2 * l] = gix * (0.5f * (float)W);
-    gg[pix * GGP + 2 * l + 1] = giy * (0.5f * (float)H);
+    const float dxr = lds[(4 * l + 0) * PP1 + pix], dxa = lds[(4 * l + 1) * PP1 + pix];
+    const float dyr = lds[(4 * l + 2) * PP1 + pix], dya = lds[(4 * l + 3) * PP1 + pix];
+    ggx[l] = fmaf(gsa, dxa, ap[l] * dxr) * (0.5f * (float)W);
+    ggy[l] = fmaf(gsa, dya, ap[l] * dyr) * (0.5f * (float)H);
     if (!pad) {
       // |tap contribution| <= max(|a'_l| max_c |g_c|, |g_alpha|): bilinear weights are <= 1.  The
       // table keeps the largest 16-pixel row sum of the cell (atomicMax on the bits of a
@@ -518,16 +532,16 @@ __global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
       const float bnd = group16_sum(pm.live ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f);
       if (leader && prow < H && pcol < W)
         atomicMax(cellbound + ((int64_t)f * L + l) * ncells + cell, __float_as_uint(bnd));
+      if (pm.live) rec_a[((int64_t)f * L + l) * HW + p] = make_float2(ap[l], gsa);
     }
-#ifndef ABL_K1_NOREC
-    if (pm.live && !pad)
-      records[((int64_t)f * L + l) * HW + p] = make_float4(ap[l], gsa, gxs[l], gys[l]);
-#else
-    asm volatile("" :: "v"(ap[l]), "v"(gsa), "v"(gxs[l]), "v"(gys[l]));
-#endif
   }
 #pragma unroll
-  for (int c = NC; c < GGC; ++c) gg[pix * GGP + c] = 0.0f;
+  for (int l = 0; l < LP; ++l) {
+    gg[(2 * l) * PP1 + pix] = ggx[l];
+    gg[(2 * l + 1) * PP1 + pix] = ggy[l];
+  }
+#pragma unroll
+  for (int c = NC; c < GGC; ++c) gg[c * PP1 + pix] = 0.0f;
   __syncthreads();  // gg rows are complete
 
   // ------------------------------------------- control-point gradient: basis^T x gg on the MFMA
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(kPxThreads, 2) void warp_composite_bwd_px_kernel(
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float bv = gg[px * GGP + nt * 16 + arow];
+        const float bv = gg[(nt * 16 + arow) * PP1 + px];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv, acc[mt][nt], 0, 0, 0);
@@ -611,7 +625,7 @@ static __global__ __launch_bounds__(kBlock) void warp_composite_gmap_reduce_kern
 }
 
 // K2 (compiled once, warp_composite_splat.hip)
-void launch_splat(const float* records, const float* grad_rgb, const int* cellbox,
+void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st);
 
@@ -673,7 +687,7 @@ static inline Bwd2Layout bwd2_layout(int64_t F, int L, int H, int W) {
   o.ncells = o.ncx * ((H + kCellRows - 1) / kCellRows);
   o.box_bytes = ((F * L * o.ncells * 16 + 255) / 256) * 256;
   o.bound_bytes = ((F * L * o.ncells * 4 + 255) / 256) * 256;
-  o.rec_bytes = ((F * L * (int64_t)H * W * 16 + 255) / 256) * 256;
+  o.rec_bytes = 2 * (((F * L * (int64_t)H * W * 8 + 255) / 256) * 256);
   o.part_bytes = F * o.g1.ntiles * gmap_partial_floats(L) * 4;
   return o;
 }
@@ -687,7 +701,8 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   char* ws = reinterpret_cast<char*>(workspace);
   int* boxes = reinterpret_cast<int*>(ws);
   unsigned* bounds = reinterpret_cast<unsigned*>(ws + lo.box_bytes);
-  float4* rec = reinterpret_cast<float4*>(ws + lo.box_bytes + lo.bound_bytes);
+  float2* rec_g = reinterpret_cast<float2*>(ws + lo.box_bytes + lo.bound_bytes);
+  float2* rec_a = reinterpret_cast<float2*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes / 2);
   float* part = grad_mapping == nullptr
                     ? nullptr
                     : reinterpret_cast<float*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes);
@@ -699,7 +714,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   auto go = [&](auto exl, auto gocc) {
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
     hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,
-                       layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
+                       layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
                        grad_occ, F, L, H, W, lo.g1.ntx, lo.g1.ntiles, lo.ncx, lo.ncells);
   };
   using T = std::true_type;
@@ -714,8 +729,8 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, st, part, grad_mapping, F, L, lo.g1.ntiles);
   }
-  launch_splat(reinterpret_cast<const float*>(rec), grad_rgb, boxes, bounds, grad_layers, F, L, H,
-               W, st);
+  launch_splat(reinterpret_cast<const float*>(rec_g), reinterpret_cast<const float*>(rec_a), grad_rgb,
+               boxes, bounds, grad_layers, F, L, H, W, st);
 }
 
 }  // namespace waldo

@@ -3,7 +3,7 @@
 // Restates the input-gradient of F.grid_sample (bilinear, zeros, align_corners=False) -- the
 // four-corner scatter of grad * weight that the reference gets from autograd through
 // models/nets/lvd.py:548,559 -- for the records the pixel kernel (K1) left behind:
-//   record (a'_l, g_alpha, grid x, grid y) per (frame, layer, pixel); the contribution of pixel p
+//   records (grid x, grid y) and (a'_l, g_alpha) per (frame, layer, pixel); the contribution of pixel p
 //   to channel c < 3 of layer l is a'_l * grad_rgb[c][p], to the alpha channel g_alpha.
 //
 // One workgroup OWNS one 32x64-texel tile S of one layer's gradient plane: it is the only writer
@@ -77,7 +77,8 @@ __device__ __forceinline__ bool touches(const Taps& t, int sx0, int sy0) {
 }
 
 __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
-    const float4* __restrict__ records, const float* __restrict__ grad_rgb,
+    const float2* __restrict__ rec_g, const float2* __restrict__ rec_a,
+    const float* __restrict__ grad_rgb,
     const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
     float* __restrict__ grad_layers, int L, int H, int W, int nsx, int ncx, int ncells) {
   const int64_t HW = (int64_t)H * W;
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const float scale = __uint_as_float((unsigned)(127 + es) << 23);
   const float inv_scale = __uint_as_float((unsigned)(127 - es) << 23);
   const float* gplane = grad_rgb + f * 3 * HW;
-  const float4* rplane = records + fl * HW;
+  const float2* rgp = rec_g + fl * HW;
+  const float2* rap = rec_a + fl * HW;
 
   if (bsum > 0.0f) {
     if (nhit <= kMaxHit) {
@@ -151,10 +153,12 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
         const bool livep = py < H && px < W;
         const unsigned p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
-        const float4 rec = rplane[p];
-        const Taps t = make_taps(rec.z, rec.w, H, W);
+        const float2 rg = rgp[p];
+        const Taps t = make_taps(rg.x, rg.y, H, W);
         const bool any = livep && touches(t, sx0, sy0);
-        if (__ballot(any) == 0ull) continue;  // wave-uniform
+        if (__ballot(any) == 0ull) continue;  // wave-uniform: (a', g_alpha) not even loaded
+        const float2 ra = rap[p];
+        const float4 rec = make_float4(ra.x, ra.y, rg.x, rg.y);
         splat_pixel(img, lane, any, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p], scale,
                     sx0, sy0);
       }
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         const int px = (c % ncx) * kCellCols + (threadIdx.x & 15);
         if (py < H && px < W) {
           const unsigned p = (unsigned)(__mul24(py, W) + px);
-          const float4 rec = rplane[p];
+          const float2 rg = rgp[p], ra = rap[p];
+          const float4 rec = make_float4(ra.x, ra.y, rg.x, rg.y);
           const Taps t = make_taps(rec.z, rec.w, H, W);
           splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
                       scale, sx0, sy0);
@@ -190,14 +195,15 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   }
 }
 
-void launch_splat(const float* records, const float* grad_rgb, const int* cellbox,
+void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
   const int ncx = (W + kCellCols - 1) / kCellCols, ncy = (H + kCellRows - 1) / kCellRows;
   dim3 grid(nsx * nsy, F * L);
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
-                     reinterpret_cast<const float4*>(records), grad_rgb, cellbox, cellbound,
+                     reinterpret_cast<const float2*>(rec_g), reinterpret_cast<const float2*>(rec_a),
+                     grad_rgb, cellbox, cellbound,
                      grad_layers, L, H, W, nsx, ncx, ncx * ncy);
 }
 
