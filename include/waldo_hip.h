@@ -57,6 +57,31 @@ int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid, float* grad
                        int64_t B, int64_t HW, int K3, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A3. Grid inversion by forward splat + hole filling -- replaces InverseWarp.forward
+ *     (models/modules/warp.py:71-174; num_perm == 1, kernel_size == 3, pad == True) and its autograd.
+ *   src_grid (B,Hs,Ws,2) layer->image grid;  src_id (Hs,Ws,2), tgt_id (H,W,2) the identity grids
+ *   (reference buffers `src_grid`, `tgt_grid`);  gauss3x3 (9) the reference buffer `kernel`;
+ *   out (B,H,W,2) image->layer grid.  Hp = H + 2*(niter+1), Wp likewise.
+ * Among several samples landing on one cell the lowest sample index wins (the reference's answer
+ * under a stable sort; its own tie-break is implementation-defined).
+ * Work / saved buffers, all caller-allocated, contents irrelevant on entry:
+ *   dxy (B,2,H*W) f32, cell (B,H*W) i32, winner (B,H*W) i32, field_a / field_b (B,2,Hp*Wp) f32,
+ *   fill_iter (B,Hp*Wp) u8, denom (B,Hp*Wp) f32, mask_a / mask_b (B,Hp*Wp) u8.
+ * The backward needs cell, winner, fill_iter, denom and mask_a (final mask) as the forward left
+ * them, plus gfield (B,2,Hp*Wp) f32 scratch; grad_src_grid (B,Hs,Ws,2) is overwritten.
+ * ------------------------------------------------------------------------------------- */
+int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id, const float* tgt_id,
+                           const float* gauss3x3, float* out, float* dxy, int* cell, int* winner,
+                           float* field_a, float* field_b, unsigned char* fill_iter, float* denom,
+                           unsigned char* mask_a, unsigned char* mask_b, int64_t B, int Hs, int Ws,
+                           int H, int W, int niter, int erode, waldo_stream_t stream);
+int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3, const int* cell,
+                           const int* winner, const unsigned char* fill_iter, const float* denom,
+                           const unsigned char* mask, float* gfield, float* grad_src_grid,
+                           int64_t B, int Hs, int Ws, int H, int W, int niter,
+                           waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A4/A5. Bilinear backward warp -- replaces F.grid_sample(x + delta, grid) - delta with the
  *     defaults (bilinear, zeros, align_corners=False) as used by Warper.obj_to_output /
  *     bg_to_output / obj_from_input / bg_from_input (models/nets/lvd.py:502-559).
@@ -120,6 +145,21 @@ int waldo_warp_composite_bwd(const float* layers, const float* basis_t, const fl
                              float* grad_layers, float* grad_mapping, float* grad_occ,
                              void* workspace, int64_t workspace_bytes, int64_t F, int L, int H,
                              int W, int K3, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A12. Fusion epilogue of WIF.forward with ii_score (models/nets/wif.py:49-54).
+ *   vid (N,Tc,C,HW)  the UNet INPUT after the permute of wif.py:39 (N = B*T), C >= 5
+ *   net (N,Tc,Co,HW) the UNet output, Co >= 4 (channels 0-2 residual, 3 score)
+ *   out (N,3,HW) = sum_tc (sigmoid(vid_4 + 5) * vid_{0..2} + net_{0..2}) * softmax_tc(net_3)
+ *   ab == 0 drops the sigmoid term (opt.ii_ab false, wif.py:53).
+ * Backward: grad_vid (N,Tc,C,HW) / grad_net (N,Tc,Co,HW) are OVERWRITTEN (zero on the channels
+ * the epilogue does not read); either may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int waldo_wif_fuse_fwd(const float* vid, const float* net, float* out, int64_t N, int Tc, int C,
+                       int Co, int64_t HW, int ab, waldo_stream_t stream);
+int waldo_wif_fuse_bwd(const float* vid, const float* net, const float* out, const float* grad_out,
+                       float* grad_vid, float* grad_net, int64_t N, int Tc, int C, int Co,
+                       int64_t HW, int ab, waldo_stream_t stream);
 
 #ifdef __cplusplus
 }

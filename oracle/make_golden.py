@@ -140,6 +140,49 @@ def gen_inverse_warp(ns):
              hs=hs, ws=ws, ht=ht, wt=wt, erode=erode)
 
 
+def gen_warper(ns):
+    """Warper.forward -> grid_to_flow_ctx -> input_to_output (the inference chain of
+    LVD decode_output, lvd.py:141-153) and grid_to_flow (training), plus WIF.forward's fusion."""
+    g = torch.Generator().manual_seed(6)
+    opt = R.warper_opt(num_obj=2, weight_cls=True, min_cls=0.05)
+    ref = ns.Warper(opt)
+    b, t, no, nl = 1, 3, 2, 3
+    obj_pose = ns.get_grid(2, 2).view(1, 1, 1, 4, 2) * 0.5 + 0.15 * torch.randn(b, t, no, 4, 2, generator=g)
+    bg_pose = ns.get_grid(2, 4).view(1, 1, 1, 8, 2) + 0.05 * torch.randn(b, t, 1, 8, 2, generator=g)
+    with R.stable_sort():
+        grid = ref(obj_pose, bg_pose)
+    hd, wd, h, w, ho, wo = 32, 64, 16, 32, 8, 8
+    inp = torch.randn(b, t, 3 + nl, hd, wd, generator=g)
+    score = torch.randn(b, t, no, generator=g)
+    occ = lvd_stub(ns, no).compute_occ(score)
+    obj_alpha = torch.rand(b, no, 1, ho, wo, generator=g) * 2 - 1
+    bg_alpha = torch.ones(b, 1, h, w)
+    cls = torch.rand(b, no, nl, generator=g).softmax(-1)
+    ctx_ts = torch.tensor([[[0, 1], [1, 0]]])
+    pred_ts = torch.tensor([2, 1])
+    fc = ref.grid_to_flow_ctx(inp, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+    ft = ref.grid_to_flow(inp, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+    out, raw = ref.input_to_output(inp, fc[3], fc[0], ctx_ts)
+    save("warper_chain", obj_pose=obj_pose, bg_pose=bg_pose, tgo=grid[0], sgo=grid[1], tgb=grid[2],
+         sgb=grid[3], inp=inp, occ=occ, obj_alpha=obj_alpha, bg_alpha=bg_alpha, cls=cls,
+         ctx_ts=ctx_ts, pred_ts=pred_ts, c_flow=fc[0], c_alpha=fc[2], c_alpha_ctx=fc[3],
+         c_disocc=fc[4], t_flow=ft[0], t_alpha=ft[2], t_alpha_ctx=ft[3], t_disocc=ft[4], out=out,
+         raw=raw)
+    # WIF.forward with a 1x1-conv stand-in for the UNet
+    bb, tc, tt, c, hh, ww = 2, 3, 2, 12, 8, 16
+    vid = torch.randn(bb, tc, tt, c, hh, ww, generator=g)
+    wif = ns.WIF.__new__(ns.WIF)
+    torch.nn.Module.__init__(wif)
+    wif.score, wif.ab = True, True
+    lin = torch.nn.Conv2d(c, 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.3)
+        lin.bias.copy_(torch.randn(5, generator=g) * 0.1)
+    wif.unet = lin
+    y = wif(vid)
+    save("wif_forward", vid=vid, weight=lin.weight, bias=lin.bias, out=y)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
@@ -148,6 +191,7 @@ def main():
     gen_occ_comp(ns)
     gen_warp_composite(ns)
     gen_inverse_warp(ns)
+    gen_warper(ns)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,250 @@
+"""GPU parity of the rows around the fused path: InverseWarp (A3), Warper (A9/A10/A13/A14),
+compute_occ / reduce_comp (A6) and the WIF fusion epilogue (A12) -- against golden vectors from
+the reference and against the CPU oracle on seeded inputs.  Tolerance 1e-4 (north star)."""
+import types
+
+import pytest
+import torch
+
+from oracle import warper_oracle as WO
+from oracle import wif_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL, rel=False, what=""):
+    if a is None or b is None:
+        assert a is None and b is None, what
+        return
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-30) if rel else 1.0
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
+
+
+def opt_ns(**over):
+    d = dict(latent_shape=[2, 4], obj_shape=[2, 2], time_dropout=False, num_obj=3, patch_size=4,
+             scale_factor=1, dim=16, aspect_ratio=2, load_dim=32, num_perm_grid=1,
+             normalize_alpha=False, use_lyt_filtering=False, use_lyt_opacity=False,
+             weight_cls=False, min_cls=0.0, include_self=False, no_filter=False, allow_ghost=False)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+# ----------------------------------------------------------------------------- A3
+@pytest.mark.parametrize("tag", ["obj", "bg", "obj2"])
+def test_inverse_warp_golden(dev, golden, tag):
+    import waldo_amd
+    g = golden(f"inverse_warp_{tag}")
+    mod = waldo_amd.InverseWarp(int(g["hs"]), int(g["ws"]), int(g["ht"]), int(g["wt"])).to(dev)
+    sg = g["src_grid"].to(dev).requires_grad_()
+    out = mod(sg, erode=bool(g["erode"]))
+    close(out, g["out"], what="out")
+    (out * g["wgt"].to(dev)).sum().backward()
+    close(sg.grad, g["grad_src_grid"], rel=True, what="grad_src_grid")
+
+
+@pytest.mark.parametrize("cfg", [(8, 8, 16, 32, 5, True), (16, 32, 16, 32, 5, False), (64, 64, 128, 256, 5, True),
+                                 (7, 9, 13, 21, 3, True), (8, 8, 8, 8, 0, False), (4, 4, 40, 40, 8, True)])
+def test_inverse_warp_random(dev, cfg):
+    """Object- and background-shaped maps (incl. the recipe's 64x64 -> 128x256), ragged sizes,
+    niter 0 and > 5, strong shrink (most of the target unfilled) -- bit-level cell decisions
+    (round-half-even, lowest index wins) make any slip an O(1) error."""
+    import waldo_amd
+    hs, ws, ht, wt, niter, erode = cfg
+    torch.manual_seed(hs * 31 + wt)
+    ctrl = O.get_grid(4, 4).view(-1, 2)
+    inv, rep = O.tps_init(hs, ws, ctrl)
+    pts = ctrl.view(1, 16, 2) * 0.6 + 0.12 * torch.randn(3, 16, 2)
+    sg = O.tps_grid(inv, rep, pts, hs, ws).requires_grad_()
+    ref = O.inverse_warp(sg, (ht, wt), niter=niter, erode=erode)
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    mod = waldo_amd.InverseWarp(hs, ws, ht, wt).to(dev)
+    s2 = sg.detach().to(dev).requires_grad_()
+    out = mod(s2, niter=niter, erode=erode)
+    close(out, ref, what="out")
+    (out * wgt.to(dev)).sum().backward()
+    close(s2.grad, sg.grad, rel=True, what="grad")
+
+
+def test_inverse_warp_identity_and_errors(dev):
+    import waldo_amd
+    mod = waldo_amd.InverseWarp(12, 20, 12, 20).to(dev)
+    ident = O.get_grid(12, 20).to(dev)
+    close(mod(ident, erode=False), ident.cpu(), 1e-6, what="identity")
+    with pytest.raises(ValueError):
+        mod(ident, pad=False)
+    with pytest.raises(NotImplementedError):
+        waldo_amd.InverseWarp(8, 8, 8, 8, num_perm=2).to(dev)(O.get_grid(8, 8).to(dev))
+    assert mod(torch.zeros(0, 12, 20, 2, device=dev)).shape == (0, 12, 20, 2)
+
+
+# ----------------------------------------------------------------------------- A6
+def test_compute_occ_and_reduce_comp_golden(dev, golden):
+    from waldo_amd.nets import compute_occ, reduce_comp
+    g = golden("occ_comp")
+    score = g["score"].to(dev).requires_grad_()
+    occ = compute_occ(score)
+    close(occ, g["occ"], 1e-6, what="occ")
+    vid = g["vid"].to(dev).requires_grad_()
+    out, alpha, _ = reduce_comp(vid, occ)
+    close(out, g["out"], what="out")
+    close(alpha, g["alpha"], what="alpha")
+    ((out * g["w1"].to(dev)).sum() + (alpha * g["w2"].to(dev)).sum()).backward()
+    close(vid.grad, g["grad_vid"], rel=True, what="grad_vid")
+    close(score.grad, g["grad_score"], rel=True, what="grad_score")
+
+
+# ----------------------------------------------------------------------------- A9 / A10 / A13 / A14
+def _warper_inputs(cfg, b, t, nl, seed):
+    g = torch.Generator().manual_seed(seed)
+    no = cfg.num_obj
+    lo = cfg.obj_shape[0] * cfg.obj_shape[1]
+    lb = cfg.latent_shape[0] * cfg.latent_shape[1]
+    obj_pose = O.get_grid(*cfg.obj_shape).view(1, 1, 1, lo, 2) * 0.5 + 0.15 * torch.randn(b, t, no, lo, 2, generator=g)
+    bg_pose = O.get_grid(*cfg.latent_shape).view(1, 1, 1, lb, 2) + 0.05 * torch.randn(b, t, 1, lb, 2, generator=g)
+    (hd, wd), (h, w), (ho, wo) = cfg.src_shape_hd, cfg.src_shape, cfg.tgt_shape
+    # smooth "frames": the chain samples them at flow-displaced positions
+    lo_res = torch.randn(b * t, 3 + nl, hd // 4, wd // 4, generator=g)
+    inp = torch.nn.functional.interpolate(lo_res, size=(hd, wd), mode="bilinear").view(b, t, 3 + nl, hd, wd)
+    occ = O.compute_occ(torch.randn(b, t, no, generator=g))
+    obj_alpha = torch.rand(b, no, 1, ho, wo, generator=g) * 2 - 1
+    bg_alpha = torch.ones(b, 1, h, w)
+    cls = torch.rand(b, no, nl, generator=g).softmax(-1)
+    return obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls
+
+
+def test_warper_chain_golden(dev, golden):
+    """Warper.forward -> grid_to_flow[_ctx] -> input_to_output vs the reference's own outputs."""
+    from waldo_amd.nets import Warper
+    g = golden("warper_chain")
+    wp = Warper(opt_ns(num_obj=2, weight_cls=True, min_cls=0.05)).to(dev)
+    d = {k: v.to(dev) for k, v in g.items()}
+    grid = wp(d["obj_pose"], d["bg_pose"])
+    for a, name in zip(grid, ("tgo", "sgo", "tgb", "sgb")):
+        close(a, g[name], what=name)
+    args = (d["inp"], grid, d["occ"], d["obj_alpha"], d["bg_alpha"], d["cls"], d["ctx_ts"], d["pred_ts"])
+    for pre, r in (("c_", wp.grid_to_flow_ctx(*args)), ("t_", wp.grid_to_flow(*args))):
+        close(r[0], g[pre + "flow"], what=pre + "flow")
+        assert r[1] is None  # load_dim > 0: alpha_unflt withheld, as in the reference
+        close(r[2], g[pre + "alpha"], what=pre + "alpha")
+        close(r[3], g[pre + "alpha_ctx"], what=pre + "alpha_ctx")
+        close(r[4], g[pre + "disocc"], what=pre + "disocc")
+    out, raw = wp.input_to_output(d["inp"], d["c_alpha_ctx"], d["c_flow"], d["ctx_ts"])
+    close(out, g["out"], 3e-4, what="out")   # white-noise frames sampled at fp32-noisy positions
+    close(raw, g["raw"], 3e-4, what="raw")
+
+
+@pytest.mark.parametrize("over", [dict(), dict(weight_cls=True, min_cls=0.1), dict(load_dim=0),
+                                  dict(allow_ghost=True), dict(no_filter=True),
+                                  dict(num_obj=7, obj_shape=[4, 4], latent_shape=[4, 8], dim=32, load_dim=64)])
+def test_warper_against_oracle(dev, over):
+    """Every Warper method, fwd and bwd, on seeded inputs; the last case is recipe-shaped
+    (16 object / 32 background control points, 8 layers, x2 high-res)."""
+    from waldo_amd.nets import Warper
+    opt = opt_ns(**over)
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    b, t, nl = 2, 4, 5
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=3)
+    ctx_ts = torch.tensor([[[0, 1], [1, 0]], [[1, 1], [0, 0]]])
+    pred_ts = torch.tensor([2, 3])
+    # (i) the four grids.  The TPS grids agree to fp32 rounding; the INVERTED grids are a
+    # discontinuous function of them (round-to-cell, winner election), so they are compared on
+    # IDENTICAL inputs: the HIP inversion of the oracle's TPS grids vs the oracle's inversion.
+    with torch.no_grad():
+        grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
+        grid_h = wp(obj_pose.to(dev), bg_pose.to(dev))
+        close(grid_h[0], grid_o[0], what="tgo")
+        close(grid_h[2], grid_o[2], what="tgb")
+        no, (h, w), (ho, wo) = cfg.num_obj, cfg.src_shape, cfg.tgt_shape
+        close(wp.invert_obj(grid_o[0].reshape(-1, ho, wo, 2).to(dev)).view(b, t, no, h, w, 2), grid_o[1], 1e-6, what="sgo")
+        close(wp.invert_bg(grid_o[2].reshape(-1, h, w, 2).to(dev), erode=False).view(b, t, h, w, 2), grid_o[3], 1e-6, what="sgb")
+    # (ii) the chain downstream of the grids, fwd and bwd, on the oracle's grids
+    leaves = [x.clone().requires_grad_() for x in (*grid_o, obj_alpha)]
+    ro = WO.grid_to_flow_ctx(cfg, inp, leaves[:4], occ, leaves[4], bg_alpha, cls, ctx_ts, pred_ts)
+    out_o, raw_o = WO.input_to_output(cfg, inp, ro[3], ro[0], ctx_ts)
+    torch.manual_seed(1)
+    wgt = torch.randn(out_o.shape)
+    (out_o * wgt).sum().backward()
+    dl = [x.clone().to(dev).requires_grad_() for x in (*grid_o, obj_alpha)]
+    grid_h = dl[:4]
+    args = (inp.to(dev), grid_h, occ.to(dev), dl[4], bg_alpha.to(dev), cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
+    rh = wp.grid_to_flow_ctx(*args)
+    for x, y, name in zip(rh, ro, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
+        close(x, y, what="ctx:" + name)
+    out_h, raw_h = wp.input_to_output(inp.to(dev), rh[3], rh[0], ctx_ts.to(dev))
+    # frames sampled at positions that are themselves the fp32 result of the chain above: 3e-4
+    close(out_h, out_o, 3e-4, what="out")
+    close(raw_h, raw_o, 3e-4, what="raw")
+    (out_h * wgt.to(dev)).sum().backward()
+    for x, y, name in zip(dl, leaves, ("grad tgo", "grad sgo", "grad tgb", "grad sgb", "grad obj_alpha")):
+        close(x.grad, y.grad, tol=2e-3, rel=True, what=name)
+    grid_o = [x.detach() for x in leaves[:4]]
+    grid_h = [x.detach() for x in dl[:4]]
+    # training variant and the helpers
+    rt_o = WO.grid_to_flow(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+    rt_h = wp.grid_to_flow(inp.to(dev), grid_h, occ.to(dev), obj_alpha.to(dev), bg_alpha.to(dev),
+                           cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
+    for x, y, name in zip(rt_h, rt_o, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
+        close(x, y, what="train:" + name)
+    gd = [x.detach() for x in grid_h]
+    go = [x.detach() for x in grid_o]
+    close(wp.grid_to_bg_flow_from_ref_to_pred(gd, 2, 1), WO.grid_to_bg_flow_from_ref_to_pred(cfg, go, 2, 1), what="A14a")
+    close(wp.grid_to_obj_flow_from_ref_to_pred(gd, 2, 1, 2), WO.grid_to_obj_flow_from_ref_to_pred(cfg, go, 2, 1, 2), what="A14b")
+    close(wp.grid_to_bg_flow_from_ctx_to_ref(gd, 2, 3), WO.grid_to_bg_flow_from_ctx_to_ref(cfg, go, 2, 3), what="A14c")
+    h, w = cfg.src_shape
+    x5 = torch.randn(b, t, 4, h, w)
+    for x, y in zip(wp.layer_from_input(x5.to(dev), gd), WO.layer_from_input(cfg, x5, go)):
+        close(x, y, what="layer_from_input")
+    for x, y in zip(wp.alpha_to_alpha(obj_alpha.to(dev), bg_alpha.to(dev), gd, occ.to(dev)),
+                    WO.alpha_to_alpha(cfg, obj_alpha, bg_alpha, go, occ)):
+        close(x, y, what="alpha_to_alpha")
+
+
+def test_warper_state_dict_names(dev):
+    """Buffer names / shapes survive, so a reference checkpoint's warper.* entries load."""
+    from waldo_amd.nets import Warper
+    names = {k: tuple(v.shape) for k, v in Warper(opt_ns()).state_dict().items()}
+    expect = {"src_pts", "tgt_pts", "src_grid", "src_grid_hd", "tgt_grid", "tps_obj.inverse_kernel",
+              "tps_obj.pad", "tps_obj.tgt_grid_repr", "invert_obj.kernel", "invert_obj.src_grid",
+              "invert_obj.tgt_grid", "invert_obj.x_grid", "invert_obj.y_grid", "invert_obj.perm",
+              "tps_bg.inverse_kernel", "tps_bg.pad", "tps_bg.tgt_grid_repr", "invert_bg.kernel",
+              "invert_bg.src_grid", "invert_bg.tgt_grid", "invert_bg.x_grid", "invert_bg.y_grid",
+              "invert_bg.perm"}
+    assert set(names) == expect
+    assert names["tps_bg.tgt_grid_repr"] == (16 * 32, 8 + 3) and names["invert_obj.perm"] == (1, 16 * 32)
+
+
+# ----------------------------------------------------------------------------- A12
+def test_wif_forward_golden(dev, golden):
+    from waldo_amd.nets import WIF
+    g = golden("wif_forward")
+    lin = torch.nn.Conv2d(12, 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(g["weight"])
+        lin.bias.copy_(g["bias"])
+    wif = WIF(types.SimpleNamespace(ii_score=True, ii_ab=True), unet=lin).to(dev)
+    close(wif(g["vid"].to(dev)), g["out"], what="wif")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 5, 3, 5, 4), (2, 3, 4, 40, 16, 32, 5), (1, 2, 5, 8, 33, 65, 4)])
+@pytest.mark.parametrize("ab", [True, False])
+def test_wif_fuse_random(dev, shape, ab):
+    from waldo_amd import functional as WF
+    b, t, tc, c, h, w, co = shape
+    torch.manual_seed(c)
+    vid = torch.randn(b, t, tc, c, h, w, requires_grad=True)
+    net = torch.randn(b, t, tc, co, h, w, requires_grad=True)
+    ref = WO.wif_fuse(vid, net, ab=ab)
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    v2, n2 = vid.detach().to(dev).requires_grad_(), net.detach().to(dev).requires_grad_()
+    out = WF.wif_fuse(v2, n2, ab=ab)
+    close(out, ref, what="out")
+    (out * wgt.to(dev)).sum().backward()
+    close(v2.grad, vid.grad, rel=True, what="grad_vid")
+    close(n2.grad, net.grad, rel=True, what="grad_net")

@@ -107,3 +107,33 @@ def test_tps_identity_fixed_point():
     inv, rep = O.tps_init(10, 14, ctrl)
     grid = O.tps_grid(inv, rep, ctrl.view(1, 16, 2), 10, 14)
     assert (grid - O.get_grid(10, 14)).abs().max() < 1e-5
+
+
+def test_warper_chain(golden):
+    """Warper.forward -> grid_to_flow[_ctx] -> input_to_output against the reference's outputs."""
+    from oracle import warper_oracle as WO
+    g = golden("warper_chain")
+    cfg = WO.WarperCfg((2, 4), (2, 2), 2, 4, 1, 16, 2, 32, weight_cls=True, min_cls=0.05)
+    grid = WO.warper_grids(cfg, g["obj_pose"], g["bg_pose"])
+    for a, name in zip(grid, ("tgo", "sgo", "tgb", "sgb")):
+        close(a, g[name], 1e-6)
+    args = (g["inp"], grid, g["occ"], g["obj_alpha"], g["bg_alpha"], g["cls"], g["ctx_ts"], g["pred_ts"])
+    fc = WO.grid_to_flow_ctx(cfg, *args)
+    ft = WO.grid_to_flow(cfg, *args)
+    for pre, r in (("c_", fc), ("t_", ft)):
+        close(r[0], g[pre + "flow"], 2e-6)
+        close(r[2], g[pre + "alpha"], 2e-6)
+        close(r[3], g[pre + "alpha_ctx"], 2e-6)
+        close(r[4], g[pre + "disocc"], 2e-6)
+    out, raw = WO.input_to_output(cfg, g["inp"], g["c_alpha_ctx"], g["c_flow"], g["ctx_ts"])
+    close(out, g["out"], 2e-6)
+    close(raw, g["raw"], 2e-6)
+
+
+def test_wif_forward(golden):
+    from oracle import warper_oracle as WO
+    g = golden("wif_forward")
+    vid = g["vid"].permute(0, 2, 1, 3, 4, 5)
+    b, t, tc, c, h, w = vid.shape
+    net = torch.nn.functional.conv2d(vid.reshape(-1, c, h, w), g["weight"], g["bias"])
+    close(WO.wif_fuse(vid, net.reshape(b, t, tc, 5, h, w)), g["out"], 1e-6)

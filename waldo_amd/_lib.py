@@ -26,12 +26,17 @@ SIGNATURES = {
     "waldo_tps_mapping_bwd": [_c_f, _c_f, _c_f, _i64, _int, _stream],
     "waldo_tps_grid_fwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
     "waldo_tps_grid_bwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
+    "waldo_inverse_warp_fwd": [_c_f] * 14 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
+    "waldo_inverse_warp_bwd": [_c_f] * 9 + [_i64, _int, _int, _int, _int, _int, _stream],
     "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
                                 _i64, _stream],
     "waldo_grid_sample2d_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int,
                                 _flt, _i64, _i64, _stream],
     "waldo_occ_composite_fwd": [_c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
     "waldo_occ_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
+    "waldo_wif_fuse_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _stream],
+    "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
+                           _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
                                  _stream],
     "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64,

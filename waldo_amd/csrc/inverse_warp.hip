@@ -1,0 +1,383 @@
+// A3: grid inversion by forward splat + hole filling -- replaces InverseWarp.forward
+// (models/modules/warp.py:71-174, num_perm == 1, kernel_size == 3, pad == True) and its autograd.
+//
+//   1. displacement d = src_grid - identity, bilinearly resized to the target raster
+//      (F.interpolate, align_corners=False)                                       warp.py:75-79
+//   2. every resized sample s lands on cell round-half-even(position + d); among several samples
+//      on one cell the LOWEST sample index wins (the reference keeps the first of each run after a
+//      sort; which one that is depends on the sort's stability -- the build fixes it to the
+//      stable-sort answer, see oracle/ref_import.py:stable_sort)                  warp.py:80-123
+//      -> integer atomicMin on the sample index, no sort
+//   3. field = -d of the winner, padded by niter+1; niter Jacobi passes: the 4-neighbour ring of
+//      the filled set takes the Gaussian-weighted mean of its filled 3x3 neighbours warp.py:125-151
+//   4. optional erosion of the mask, niter passes                                 warp.py:153-162
+//   5. unfilled cells sample far out of range (offset 2W, 2H px); crop            warp.py:164-174
+// The integer path (cells, winners, masks) carries no gradient; the value path is linear and is
+// differentiated exactly by replaying the passes in reverse with the stored fill order.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+constexpr int kNoWinner = 0x7f7f7f7f;  // hipMemsetAsync(0x7f)
+
+// ---- step 1+2: resized displacement, target cell, winner election
+__global__ __launch_bounds__(kBlock) void iw_splat_kernel(
+    const float* __restrict__ src_grid, const float* __restrict__ src_id, float* __restrict__ dxy,
+    int* __restrict__ cell, int* __restrict__ winner, int Hs, int Ws, int H, int W) {
+  const int64_t b = blockIdx.y;
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  const int HW = H * W;
+  if (s >= HW) return;
+  const int y = s / W, x = s - y * W;
+  // PyTorch upsample_bilinear2d source index (align_corners=False)
+  const float sh = (float)Hs / (float)H, sw = (float)Ws / (float)W;
+  const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f);
+  const float fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + ((y0 < Hs - 1) ? 1 : 0), x1 = x0 + ((x0 < Ws - 1) ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const float* g = src_grid + b * Hs * Ws * 2;
+  float d[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float v00 = g[(y0 * Ws + x0) * 2 + c] - src_id[(y0 * Ws + x0) * 2 + c];
+    const float v01 = g[(y0 * Ws + x1) * 2 + c] - src_id[(y0 * Ws + x1) * 2 + c];
+    const float v10 = g[(y1 * Ws + x0) * 2 + c] - src_id[(y1 * Ws + x0) * 2 + c];
+    const float v11 = g[(y1 * Ws + x1) * 2 + c] - src_id[(y1 * Ws + x1) * 2 + c];
+    d[c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+  const float dx = d[0] * (float)W / 2.0f, dy = d[1] * (float)H / 2.0f;
+  dxy[(b * 2 + 0) * HW + s] = dx;
+  dxy[(b * 2 + 1) * HW + s] = dy;
+  const float txf = rintf((float)x + dx), tyf = rintf((float)y + dy);  // round half to even
+  int c = -1;
+  if (txf >= 0.0f && tyf >= 0.0f && txf <= (float)(W - 1) && tyf <= (float)(H - 1)) {
+    c = (int)tyf * W + (int)txf;
+    atomicMin(winner + b * HW + c, s);
+  }
+  cell[b * HW + s] = c;
+}
+
+// ---- step 3a: padded field of the winners
+__global__ __launch_bounds__(kBlock) void iw_gather_kernel(const float* __restrict__ dxy,
+                                                           const int* __restrict__ winner,
+                                                           float* __restrict__ field,
+                                                           unsigned char* __restrict__ fill_iter,
+                                                           int H, int W, int pad) {
+  const int64_t b = blockIdx.y;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  const int yp = e / Wp, xp = e - yp * Wp;
+  const int y = yp - pad, x = xp - pad;
+  float vx = 0.0f, vy = 0.0f;
+  unsigned char it = 255;
+  if (y >= 0 && y < H && x >= 0 && x < W) {
+    const int w = winner[b * HW + y * W + x];
+    if (w != kNoWinner) {
+      vx = -dxy[(b * 2 + 0) * HW + w];
+      vy = -dxy[(b * 2 + 1) * HW + w];
+      it = 0;
+    }
+  }
+  field[(b * 2 + 0) * HWp + e] = vx;
+  field[(b * 2 + 1) * HWp + e] = vy;
+  fill_iter[b * HWp + e] = it;
+}
+
+// ---- step 3b: one Jacobi fill pass `iter` (1-based): cells filled so far have fill_iter < iter
+__global__ __launch_bounds__(kBlock) void iw_fill_kernel(const float* __restrict__ fin,
+                                                         float* __restrict__ fout,
+                                                         unsigned char* __restrict__ fill_iter,
+                                                         float* __restrict__ denom,
+                                                         const float* __restrict__ kern, int Hp,
+                                                         int Wp, int iter) {
+  const int64_t b = blockIdx.y;
+  const int HWp = Hp * Wp;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  const int y = e / Wp, x = e - y * Wp;
+  const unsigned char* fi = fill_iter + b * HWp;
+  const float* fx = fin + (b * 2 + 0) * HWp;
+  const float* fy = fin + (b * 2 + 1) * HWp;
+  float vx = fx[e], vy = fy[e];
+  if (fi[e] == 255) {
+    // 4-neighbour ring of the set filled before this pass (neighbours outside the array: none)
+    const bool up = y > 0 && fi[e - Wp] < iter, dn = y < Hp - 1 && fi[e + Wp] < iter;
+    const bool lf = x > 0 && fi[e - 1] < iter, rt = x < Wp - 1 && fi[e + 1] < iter;
+    if (up || dn || lf || rt) {
+      float sx = 0.0f, sy = 0.0f, sm = 0.0f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+            const int n = yy * Wp + xx;
+            if (fi[n] < iter) {  // unfilled cells hold 0 and contribute nothing
+              const float k = kern[(dy + 1) * 3 + (dx + 1)];
+              sx = fmaf(k, fx[n], sx);
+              sy = fmaf(k, fy[n], sy);
+              sm += k;
+            }
+          }
+        }
+      vx = sx / sm;
+      vy = sy / sm;
+      denom[b * HWp + e] = sm;
+    }
+  }
+  fout[(b * 2 + 0) * HWp + e] = vx;
+  fout[(b * 2 + 1) * HWp + e] = vy;
+}
+
+// marks the cells filled in pass `iter` (separate launch: the pass reads fill_iter of neighbours)
+__global__ __launch_bounds__(kBlock) void iw_mark_kernel(unsigned char* __restrict__ fill_iter,
+                                                         const float* __restrict__ denom, int Hp,
+                                                         int Wp, int iter) {
+  const int64_t b = blockIdx.y;
+  const int HWp = Hp * Wp;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  unsigned char* fi = fill_iter + b * HWp;
+  if (fi[e] != 255) return;
+  const int y = e / Wp, x = e - y * Wp;
+  const bool up = y > 0 && fi[e - Wp] < iter, dn = y < Hp - 1 && fi[e + Wp] < iter;
+  const bool lf = x > 0 && fi[e - 1] < iter, rt = x < Wp - 1 && fi[e + 1] < iter;
+  // a neighbour marked in THIS launch carries `iter`, which is not < iter: no race on the decision
+  if (up || dn || lf || rt) fi[e] = (unsigned char)iter;
+}
+
+// ---- step 4: one erosion pass on the mask (1 = filled)
+__global__ __launch_bounds__(kBlock) void iw_erode_kernel(const unsigned char* __restrict__ min_,
+                                                          unsigned char* __restrict__ mout, int Hp,
+                                                          int Wp) {
+  const int64_t b = blockIdx.y;
+  const int HWp = Hp * Wp;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  const int y = e / Wp, x = e - y * Wp;
+  const unsigned char* m = min_ + b * HWp;
+  unsigned char v = m[e];
+  if (v) {
+    const bool hole = (y > 0 && !m[e - Wp]) || (y < Hp - 1 && !m[e + Wp]) || (x > 0 && !m[e - 1]) ||
+                      (x < Wp - 1 && !m[e + 1]);
+    if (hole) v = 0;
+  }
+  mout[b * HWp + e] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void iw_mask_init_kernel(const unsigned char* __restrict__ fill_iter,
+                                                              unsigned char* __restrict__ mask,
+                                                              int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e < n) mask[e] = fill_iter[e] != 255;
+}
+
+// ---- step 5
+__global__ __launch_bounds__(kBlock) void iw_finalize_kernel(const float* __restrict__ field,
+                                                             const unsigned char* __restrict__ mask,
+                                                             const float* __restrict__ tgt_id,
+                                                             float* __restrict__ out, int H, int W,
+                                                             int pad) {
+  const int64_t b = blockIdx.y;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= HW) return;
+  const int y = s / W, x = s - y * W;
+  const int e = (y + pad) * Wp + (x + pad);
+  const bool m = mask[b * HWp + e] != 0;
+  const float vx = m ? field[(b * 2 + 0) * HWp + e] : 2.0f * (float)W;
+  const float vy = m ? field[(b * 2 + 1) * HWp + e] : 2.0f * (float)H;
+  out[(b * HW + s) * 2 + 0] = tgt_id[s * 2 + 0] + vx * 2.0f / (float)W;
+  out[(b * HW + s) * 2 + 1] = tgt_id[s * 2 + 1] + vy * 2.0f / (float)H;
+}
+
+// ---- backward
+__global__ __launch_bounds__(kBlock) void iw_bwd_init_kernel(const float* __restrict__ gout,
+                                                             const unsigned char* __restrict__ mask,
+                                                             float* __restrict__ gfield, int H, int W,
+                                                             int pad) {
+  const int64_t b = blockIdx.y;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  const int yp = e / Wp, xp = e - yp * Wp;
+  const int y = yp - pad, x = xp - pad;
+  float gx = 0.0f, gy = 0.0f;
+  if (y >= 0 && y < H && x >= 0 && x < W && mask[b * HWp + e]) {
+    gx = gout[(b * HW + y * W + x) * 2 + 0] * 2.0f / (float)W;
+    gy = gout[(b * HW + y * W + x) * 2 + 1] * 2.0f / (float)H;
+  }
+  gfield[(b * 2 + 0) * HWp + e] = gx;
+  gfield[(b * 2 + 1) * HWp + e] = gy;
+}
+
+// reverse of fill pass `iter`: cells filled earlier collect k * g / denom from the cells of this pass
+__global__ __launch_bounds__(kBlock) void iw_bwd_fill_kernel(float* __restrict__ gfield,
+                                                             const unsigned char* __restrict__ fill_iter,
+                                                             const float* __restrict__ denom,
+                                                             const float* __restrict__ kern, int Hp,
+                                                             int Wp, int iter) {
+  const int64_t b = blockIdx.y;
+  const int HWp = Hp * Wp;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= HWp) return;
+  const unsigned char* fi = fill_iter + b * HWp;
+  if (fi[e] >= iter) return;  // only earlier-filled cells fed pass `iter`
+  const int y = e / Wp, x = e - y * Wp;
+  float* gx = gfield + (b * 2 + 0) * HWp;
+  float* gy = gfield + (b * 2 + 1) * HWp;
+  float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+        const int n = yy * Wp + xx;
+        if (fi[n] == iter) {
+          // this cell sits at offset (-dy, -dx) in n's stencil; the Gaussian is symmetric
+          const float k = kern[(1 - dy) * 3 + (1 - dx)] / denom[b * HWp + n];
+          ax = fmaf(k, gx[n], ax);
+          ay = fmaf(k, gy[n], ay);
+        }
+      }
+    }
+  gx[e] += ax;  // cells of pass `iter` are only read here, cells before it only written: in place
+  gy[e] += ay;
+}
+
+// d loss / d (dx, dy) of the winners, then the adjoint of the bilinear resize
+__global__ __launch_bounds__(kBlock) void iw_bwd_splat_kernel(
+    const float* __restrict__ gfield, const int* __restrict__ cell, const int* __restrict__ winner,
+    float* __restrict__ gsrc, int Hs, int Ws, int H, int W, int pad) {
+  const int64_t b = blockIdx.y;
+  const int HW = H * W, Wp = W + 2 * pad, HWp = (H + 2 * pad) * Wp;
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= HW) return;
+  const int c = cell[b * HW + s];
+  if (c < 0 || winner[b * HW + c] != s) return;
+  const int cy = c / W, cx = c - cy * W;
+  const int e = (cy + pad) * Wp + (cx + pad);
+  // field = -d(px);  d(px) = d(normalised) * size / 2
+  const float gdx = -gfield[(b * 2 + 0) * HWp + e] * (float)W / 2.0f;
+  const float gdy = -gfield[(b * 2 + 1) * HWp + e] * (float)H / 2.0f;
+  const int y = s / W, x = s - y * W;
+  const float sh = (float)Hs / (float)H, sw = (float)Ws / (float)W;
+  const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f);
+  const float fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + ((y0 < Hs - 1) ? 1 : 0), x1 = x0 + ((x0 < Ws - 1) ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  float* g = gsrc + b * Hs * Ws * 2;
+  atomicAdd(g + (y0 * Ws + x0) * 2 + 0, hy * hx * gdx);
+  atomicAdd(g + (y0 * Ws + x0) * 2 + 1, hy * hx * gdy);
+  atomicAdd(g + (y0 * Ws + x1) * 2 + 0, hy * lx * gdx);
+  atomicAdd(g + (y0 * Ws + x1) * 2 + 1, hy * lx * gdy);
+  atomicAdd(g + (y1 * Ws + x0) * 2 + 0, ly * hx * gdx);
+  atomicAdd(g + (y1 * Ws + x0) * 2 + 1, ly * hx * gdy);
+  atomicAdd(g + (y1 * Ws + x1) * 2 + 0, ly * lx * gdx);
+  atomicAdd(g + (y1 * Ws + x1) * 2 + 1, ly * lx * gdy);
+}
+
+static int check_iw(const char* fn, int64_t B, int Hs, int Ws, int H, int W, int niter) {
+  if (B < 0 || Hs < 1 || Ws < 1 || H < 1 || W < 1 || niter < 0 || niter > 200 || B > 65535 ||
+      (int64_t)(H + 2 * niter + 2) * (W + 2 * niter + 2) > 2147483647 / 4) {
+    set_error("%s: bad shape B=%lld src=%dx%d tgt=%dx%d niter=%d (B <= 65535, niter <= 200)", fn,
+              (long long)B, Hs, Ws, H, W, niter);
+    return WALDO_EINVAL;
+  }
+  return WALDO_OK;
+}
+
+}  // namespace waldo
+
+using namespace waldo;
+
+extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id,
+                                      const float* tgt_id, const float* gauss3x3, float* out,
+                                      float* dxy, int* cell, int* winner, float* field_a,
+                                      float* field_b, unsigned char* fill_iter, float* denom,
+                                      unsigned char* mask_a, unsigned char* mask_b, int64_t B,
+                                      int Hs, int Ws, int H, int W, int niter, int erode,
+                                      waldo_stream_t stream) {
+  int rc = check_iw("waldo_inverse_warp_fwd", B, Hs, Ws, H, W, niter);
+  if (rc) return rc;
+  if (B == 0) return WALDO_OK;
+  if (!src_grid || !src_id || !tgt_id || !gauss3x3 || !out || !dxy || !cell || !winner ||
+      !field_a || !field_b || !fill_iter || !denom || !mask_a || !mask_b) {
+    set_error("waldo_inverse_warp_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int pad = niter + 1;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int HW = H * W, HWp = Hp * Wp;
+  dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
+  (void)hipMemsetAsync(winner, 0x7f, sizeof(int) * (size_t)B * HW, st);
+  hipLaunchKernelGGL(iw_splat_kernel, gs, dim3(kBlock), 0, st, src_grid, src_id, dxy, cell, winner,
+                     Hs, Ws, H, W);
+  hipLaunchKernelGGL(iw_gather_kernel, gp, dim3(kBlock), 0, st, dxy, winner, field_a, fill_iter, H,
+                     W, pad);
+  float* fin = field_a;
+  float* fout = field_b;
+  for (int it = 1; it <= niter; ++it) {
+    hipLaunchKernelGGL(iw_fill_kernel, gp, dim3(kBlock), 0, st, fin, fout, fill_iter, denom,
+                       gauss3x3, Hp, Wp, it);
+    hipLaunchKernelGGL(iw_mark_kernel, gp, dim3(kBlock), 0, st, fill_iter, denom, Hp, Wp, it);
+    float* t = fin;
+    fin = fout;
+    fout = t;
+  }
+  const int64_t n = (int64_t)B * HWp;
+  hipLaunchKernelGGL(iw_mask_init_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, st, fill_iter, mask_a, n);
+  unsigned char* mi = mask_a;
+  unsigned char* mo = mask_b;
+  if (erode) {
+    for (int it = 0; it < niter; ++it) {
+      hipLaunchKernelGGL(iw_erode_kernel, gp, dim3(kBlock), 0, st, mi, mo, Hp, Wp);
+      unsigned char* t = mi;
+      mi = mo;
+      mo = t;
+    }
+  }
+  // the final mask is left in mask_a for the backward
+  if (mi != mask_a)
+    (void)hipMemcpyAsync(mask_a, mi, (size_t)n, hipMemcpyDeviceToDevice, st);
+  hipLaunchKernelGGL(iw_finalize_kernel, gs, dim3(kBlock), 0, st, fin, mask_a, tgt_id, out, H, W,
+                     pad);
+  return launch_status("waldo_inverse_warp_fwd");
+}
+
+extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3,
+                                      const int* cell, const int* winner,
+                                      const unsigned char* fill_iter, const float* denom,
+                                      const unsigned char* mask, float* gfield,
+                                      float* grad_src_grid, int64_t B, int Hs, int Ws, int H, int W,
+                                      int niter, waldo_stream_t stream) {
+  int rc = check_iw("waldo_inverse_warp_bwd", B, Hs, Ws, H, W, niter);
+  if (rc) return rc;
+  if (B == 0) return WALDO_OK;
+  if (!grad_out || !gauss3x3 || !cell || !winner || !fill_iter || !denom || !mask || !gfield ||
+      !grad_src_grid) {
+    set_error("waldo_inverse_warp_bwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int pad = niter + 1;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int HW = H * W, HWp = Hp * Wp;
+  dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
+  hipLaunchKernelGGL(iw_bwd_init_kernel, gp, dim3(kBlock), 0, st, grad_out, mask, gfield, H, W, pad);
+  for (int it = niter; it >= 1; --it)
+    hipLaunchKernelGGL(iw_bwd_fill_kernel, gp, dim3(kBlock), 0, st, gfield, fill_iter, denom,
+                       gauss3x3, Hp, Wp, it);
+  (void)hipMemsetAsync(grad_src_grid, 0, sizeof(float) * (size_t)B * Hs * Ws * 2, st);
+  hipLaunchKernelGGL(iw_bwd_splat_kernel, gs, dim3(kBlock), 0, st, gfield, cell, winner,
+                     grad_src_grid, Hs, Ws, H, W, pad);
+  return launch_status("waldo_inverse_warp_bwd");
+}

@@ -88,6 +88,61 @@ def tps_grid(inverse_kernel, basis_t, src_pts, height, width):
 
 
 # --------------------------------------------------------------------------------------
+# A3: grid inversion
+# --------------------------------------------------------------------------------------
+class _InverseWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src_grid, src_id, tgt_id, gauss, niter, erode):
+        _lib.check_cuda(src_grid, src_id, tgt_id, gauss)
+        src_grid, src_id, tgt_id, gauss = _c(src_grid), _c(src_id), _c(tgt_id), _c(gauss)
+        b, hs, ws, _ = src_grid.shape
+        h, w = tgt_id.shape[-3], tgt_id.shape[-2]
+        pad = niter + 1
+        hwp = (h + 2 * pad) * (w + 2 * pad)
+        dev = src_grid.device
+        out = src_grid.new_empty(b, h, w, 2)
+        dxy = src_grid.new_empty(b, 2, h * w)
+        cell = torch.empty(b, h * w, dtype=torch.int32, device=dev)
+        winner = torch.empty(b, h * w, dtype=torch.int32, device=dev)
+        field_a = src_grid.new_empty(b, 2, hwp)
+        field_b = src_grid.new_empty(b, 2, hwp)
+        fill_iter = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
+        denom = src_grid.new_empty(b, hwp)
+        mask_a = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
+        mask_b = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("waldo_inverse_warp_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
+                      _lib.ptr(tgt_id), _lib.ptr(gauss), _lib.ptr(out), _lib.ptr(dxy),
+                      _lib.ptr(cell), _lib.ptr(winner), _lib.ptr(field_a), _lib.ptr(field_b),
+                      _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask_a), _lib.ptr(mask_b), b,
+                      hs, ws, h, w, niter, int(bool(erode)), _lib.current_stream(dev))
+        ctx.save_for_backward(gauss, cell, winner, fill_iter, denom, mask_a)
+        ctx.cfg = (b, hs, ws, h, w, niter)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gauss, cell, winner, fill_iter, denom, mask = ctx.saved_tensors
+        b, hs, ws, h, w, niter = ctx.cfg
+        grad_out = _c(grad_out)
+        gfield = grad_out.new_empty(b, 2, fill_iter.shape[1])
+        gsrc = grad_out.new_empty(b, hs, ws, 2)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("waldo_inverse_warp_bwd", _lib.ptr(grad_out), _lib.ptr(gauss), _lib.ptr(cell),
+                      _lib.ptr(winner), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask),
+                      _lib.ptr(gfield), _lib.ptr(gsrc), b, hs, ws, h, w, niter,
+                      _lib.current_stream(grad_out.device))
+        return gsrc, None, None, None, None, None
+
+
+def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True):
+    """InverseWarp.forward (models/modules/warp.py:71-174; num_perm == 1, 3x3 kernel, pad).
+    src_grid (B, Hs, Ws, 2) -> (B, H, W, 2); src_id / tgt_id are the identity grids of the two
+    rasters, gauss3x3 the normalised Gaussian (the reference module's buffers)."""
+    return _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode))
+
+
+# --------------------------------------------------------------------------------------
 # A4/A5: bilinear warp
 # --------------------------------------------------------------------------------------
 class _GridSample(torch.autograd.Function):
@@ -178,6 +233,47 @@ def occ_composite(alpha, occ, occ_div=1):
     shape = alpha.shape
     a3 = alpha.reshape(shape[0], shape[1], -1)
     return _OccComposite.apply(a3, occ, int(occ_div)).view(shape)
+
+
+# --------------------------------------------------------------------------------------
+# A12: WIF fusion epilogue
+# --------------------------------------------------------------------------------------
+class _WifFuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vid, net, ab):
+        _lib.check_cuda(vid, net)
+        vid, net = _c(vid), _c(net)
+        b, t, tc, c, h, w = vid.shape
+        co = net.shape[3]
+        if tuple(net.shape) != (b, t, tc, co, h, w):
+            raise _lib.WaldoHipError(f"wif_fuse: shapes {tuple(vid.shape)} vs {tuple(net.shape)}")
+        out = vid.new_empty(b, t, 3, h, w)
+        with torch.cuda.device(vid.device):
+            _lib.call("waldo_wif_fuse_fwd", _lib.ptr(vid), _lib.ptr(net), _lib.ptr(out), b * t, tc,
+                      c, co, h * w, int(bool(ab)), _lib.current_stream(vid.device))
+        ctx.save_for_backward(vid, net, out)
+        ctx.ab = int(bool(ab))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vid, net, out = ctx.saved_tensors
+        b, t, tc, c, h, w = vid.shape
+        co = net.shape[3]
+        grad_out = _c(grad_out)
+        gv = torch.empty_like(vid) if ctx.needs_input_grad[0] else None
+        gn = torch.empty_like(net) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(vid.device):
+            _lib.call("waldo_wif_fuse_bwd", _lib.ptr(vid), _lib.ptr(net), _lib.ptr(out),
+                      _lib.ptr(grad_out), _lib.ptr(gv), _lib.ptr(gn), b * t, tc, c, co, h * w,
+                      ctx.ab, _lib.current_stream(vid.device))
+        return gv, gn, None
+
+
+def wif_fuse(vid, net_out, ab=True):
+    """Fusion epilogue of WIF.forward with ii_score (models/nets/wif.py:49-54).
+    vid (B, T, Tc, C, H, W): the UNet input after the permute; net_out (B, T, Tc, 4|5, H, W)."""
+    return _WifFuse.apply(vid, net_out, ab)
 
 
 # --------------------------------------------------------------------------------------

@@ -66,8 +66,16 @@ class TPSWarp(nn.Module):
 
 class InverseWarp(nn.Module):
     """Grid inversion by forward splat + hole filling (reference: models/modules/warp.py:58-174).
-    Buffers keep the reference's names.  The HIP implementation lands with SURVEY.md row A3; until
-    then ``forward`` raises instead of silently running anything on the CPU."""
+
+    ``forward(src_grid, niter=5, pad=True, erode=True)``: (B, Hs, Ws, 2) layer->image grid ->
+    (B, H, W, 2) image->layer grid, by ``waldo_inverse_warp_fwd`` (winner election with an integer
+    atomicMin instead of the reference's two sorts; Jacobi fill passes; erosion; crop), with an
+    exact backward w.r.t. the displacement values.  Buffers keep the reference's names.
+
+    Differences from the reference, on purpose: among colliding samples the lowest sample index
+    wins (the reference's result under a stable sort; its own depends on torch.sort's
+    implementation); ``num_perm > 1`` (random tie-break averaging, unused by every script) and
+    ``pad=False`` (which fails with a shape error in the reference) raise."""
 
     def __init__(self, src_height, src_width, tgt_height, tgt_width, kernel_size=3, num_perm=1):
         super().__init__()
@@ -83,4 +91,11 @@ class InverseWarp(nn.Module):
         self.register_buffer("perm", torch.stack([torch.randperm(tgt_height * tgt_width) for _ in range(num_perm)]))
 
     def forward(self, src_grid, niter=5, pad=True, erode=True):
-        raise NotImplementedError("InverseWarp HIP kernels are not built yet (SURVEY.md A3)")
+        if self.num_perm != 1 or self.kernel_size != 3:
+            raise NotImplementedError("InverseWarp: only num_perm == 1, kernel_size == 3 (what the "
+                                      "reference's scripts use) is implemented")
+        if not pad:
+            raise ValueError("InverseWarp: pad=False fails with a shape error in the reference "
+                             "(warp.py:169-173); not supported")
+        return WF.inverse_warp(src_grid, self.src_grid[0], self.tgt_grid[0], self.kernel.view(9),
+                               niter=niter, erode=erode)

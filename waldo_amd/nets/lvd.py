@@ -1,0 +1,327 @@
+"""Host-side mirror of the hot-path part of the reference's models/nets/lvd.py.
+
+``Warper`` keeps the reference's constructor, method names, argument meaning, return tuples and
+persistent buffer names (``src_pts, tgt_pts, src_grid, src_grid_hd, tgt_grid`` + the four
+sub-modules ``tps_obj, invert_obj, tps_bg, invert_bg``), so ``LVD`` / ``Synthesizer`` can
+construct and call it unchanged and a reference checkpoint's ``warper.*`` entries load as they
+are.  Every resampling (``F.grid_sample`` in the reference), every occlusion product
+(``(1 - alpha * occ).prod(dim)``), the TPS grids and the grid inversion run in the hand-written
+gfx950 kernels of ``waldo_amd.functional``; what is left in PyTorch is indexing, concatenation,
+the small softmax / mean of the layout filter and the bilinear ``F.interpolate`` rescale (the
+"next" row f1 of SURVEY.md section 8 fuses those too).  No CPU path: tensors must live on the GPU.
+
+The occlusion products never materialise the reference's (L, L, h, w) broadcast, so the
+``fast`` / ``restrict_to_ctx`` memory switches of the reference only change WHAT is returned
+(``alpha_unflt`` is None when ``load_dim > 0``, as in the reference), not how it is computed.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as WF
+from ..modules.warp import InverseWarp, TPSWarp
+from ..tools.utils import get_grid
+
+
+def compute_occ(occ_score, eps=1e-6):
+    """Pairwise occlusion matrix, reference LVD.compute_occ (models/nets/lvd.py:59-68).
+    occ_score (B, T, No) -> (B, T, No+1, No+1): occ[i, j] = s_i / (s_i + s_j) - [i == j] / 2 with
+    s = exp(-score^2) + eps; first column ones (objects occlude the background), first row zeros."""
+    b, t, no = occ_score.shape
+    s = torch.exp(-occ_score * occ_score) + eps
+    pair = s.unsqueeze(3) / (s.unsqueeze(3) + s.unsqueeze(2))
+    pair = pair - 0.5 * torch.eye(no, device=occ_score.device, dtype=occ_score.dtype)
+    occ = occ_score.new_zeros(b, t, no + 1, no + 1)
+    occ[:, :, 1:, 1:] = pair
+    occ[:, :, 1:, 0] = 1.0
+    return occ
+
+
+def reduce_comp(vid, occ, flow=None):
+    """Canonical over-composite, reference LVD.reduce_comp (models/nets/lvd.py:100-114).
+    vid (B, T, L, C+1, H, W) in [-1, 1], occ (B, T, L, L) -> composited vid (B, T, C, H, W),
+    alpha' (B, T, L, H, W) (both in [-1, 1]) and the composited flow."""
+    b, t, nl = vid.shape[:3]
+    v = (vid + 1) / 2
+    alpha = torch.cat([torch.ones_like(v[:, :, :1, -1]), v[:, :, 1:, -1]], dim=2)  # bg alpha = 1
+    h, w = alpha.shape[-2:]
+    alpha = WF.occ_composite(alpha.reshape(b * t, nl, h, w), occ.reshape(b * t, nl, nl)).view(b, t, nl, h, w)
+    out = (alpha.unsqueeze(3) * v[:, :, :, :-1]).sum(dim=2)
+    fl = None
+    if flow is not None:
+        fl = (alpha[:, :-1].unsqueeze(3) * flow).sum(dim=2)
+    return 2 * out - 1, 2 * alpha - 1, fl
+
+
+def scale(tensor, scale_factor, mode="bilinear"):
+    """Reference ``scale`` (lvd.py:175-179): F.interpolate on the trailing (C, h, w) of any rank."""
+    if tensor is None or scale_factor == 1:
+        return tensor
+    lead = tensor.shape[:-3]
+    out = F.interpolate(tensor.reshape(-1, *tensor.shape[-3:]), scale_factor=scale_factor, mode=mode)
+    return out.reshape(*lead, *out.shape[-3:])
+
+
+def gather_time(tensor, ts):
+    """Reference ``gather_time`` (lvd.py:462-467): tensor (B, T, ...), ts (B, Tc, Tp)."""
+    b, tc, tp = ts.shape
+    idx = ts.reshape(b, tc * tp, *([1] * (tensor.ndim - 2))).expand(-1, -1, *tensor.shape[2:])
+    return tensor.gather(1, idx).reshape(b, tc, tp, *tensor.shape[2:])
+
+
+class Warper(nn.Module):
+    """Reference: models/nets/lvd.py:469-870.  ``opt`` fields read: latent_shape, obj_shape,
+    time_dropout, num_obj, patch_size, scale_factor, dim, aspect_ratio, load_dim, num_perm_grid,
+    normalize_alpha, use_lyt_filtering, use_lyt_opacity, weight_cls, min_cls, include_self,
+    no_filter, allow_ghost."""
+
+    def __init__(self, opt, repeat_border=False):
+        super().__init__()
+        src_pts = get_grid(*opt.latent_shape).view(-1, 2)
+        tgt_pts = get_grid(*opt.obj_shape).view(-1, 2)
+        self.time_dropout = opt.time_dropout
+        self.num_obj = opt.num_obj
+        self.latent_obj_size = opt.obj_shape[0] * opt.obj_shape[1]
+        self.latent_size = opt.latent_shape[0] * opt.latent_shape[1]
+        self.tgt_shape = [int(opt.obj_shape[0] * opt.patch_size * opt.scale_factor),
+                          int(opt.obj_shape[1] * opt.patch_size * opt.scale_factor)]
+        self.src_shape = [opt.dim, int(opt.dim * opt.aspect_ratio)]
+        self.src_shape_hd = [opt.load_dim, int(opt.load_dim * opt.aspect_ratio)] if opt.load_dim > 0 else self.src_shape
+        self.register_buffer("src_pts", src_pts)
+        self.register_buffer("tgt_pts", tgt_pts)
+        self.register_buffer("src_grid", get_grid(*self.src_shape))
+        self.register_buffer("src_grid_hd", get_grid(*self.src_shape_hd))
+        self.register_buffer("tgt_grid", get_grid(*self.tgt_shape))
+        self.tps_obj = TPSWarp(*self.tgt_shape, tgt_pts)
+        self.invert_obj = InverseWarp(*self.tgt_shape, *self.src_shape, num_perm=opt.num_perm_grid)
+        self.normalize_alpha = opt.normalize_alpha
+        self.use_lyt_filtering = opt.use_lyt_filtering
+        self.use_lyt_opacity = opt.use_lyt_opacity
+        self.weight_cls = opt.weight_cls
+        self.min_cls = opt.min_cls
+        self.include_self = opt.include_self
+        self.fast = opt.load_dim == 0
+        self.scale_hd = opt.load_dim / opt.dim if opt.load_dim > 0 else 1
+        self.tps_bg = TPSWarp(*self.src_shape, src_pts)
+        self.invert_bg = InverseWarp(*self.src_shape, *self.src_shape, num_perm=opt.num_perm_grid)
+        self.no_filter = opt.no_filter
+        self.allow_ghost = opt.allow_ghost
+
+    # ------------------------------------------------------------------ image -> layer space
+    def layer_from_input(self, input, grid):
+        return self.obj_from_input(input, grid), self.bg_from_input(input, grid)
+
+    def obj_from_input(self, input, grid):
+        tgt_grid_obj = grid[0]
+        b, t = input.shape[:2]
+        c = input.size(-3)
+        ho, wo = self.tgt_shape
+        h, w = self.src_shape
+        no = self.num_obj
+        g = tgt_grid_obj.reshape(b * t * no, ho, wo, 2)
+        if input.ndim == 5:  # one image per frame, shared by the objects: broadcast, no copies
+            out = WF.grid_sample(input.reshape(b * t, c, h, w), g, broadcast=(no, 1))
+        else:
+            out = WF.grid_sample(input[:, :, 1:].reshape(b * t * no, c, h, w), g)
+        return out.view(b, t, no, c, ho, wo)
+
+    def bg_from_input(self, input, grid):
+        tgt_grid_bg = grid[2]
+        b, t = input.shape[:2]
+        c = input.size(-3)
+        h, w = self.src_shape
+        src = input if input.ndim == 5 else input[:, :, :1]
+        return WF.grid_sample(src.reshape(b * t, c, h, w), tgt_grid_bg.reshape(b * t, h, w, 2)).view(b, t, c, h, w)
+
+    # ------------------------------------------------------------------ layer -> image space
+    def layer_to_output(self, obj, bg, grid, delta_bg=1, delta_obj=1):
+        output = self.obj_to_output(obj, grid, delta_obj)
+        return torch.cat([self.bg_to_output(bg, grid, delta_bg), output], dim=2)
+
+    def obj_to_output(self, obj, grid, delta_obj=1):
+        src_grid_obj = grid[1]
+        b, t, no = src_grid_obj.shape[:3]
+        c1 = obj.size(-3)
+        ho, wo = self.tgt_shape
+        h, w = self.src_shape
+        g = src_grid_obj.reshape(b * t * no, h, w, 2)
+        if obj.ndim == 5:  # (B, No, C+1, Ho, Wo) shared over time (lvd.py:544): n_in = b*No + o
+            out = WF.grid_sample(obj.reshape(b * no, c1, ho, wo), g, delta=delta_obj, broadcast=(t * no, no))
+        else:
+            out = WF.grid_sample(obj.reshape(b * t * no, c1, ho, wo), g, delta=delta_obj)
+        return out.view(b, t, no, c1, h, w)
+
+    def bg_to_output(self, bg, grid, delta_bg=1, eps=1e-6):
+        src_grid_bg = grid[3]
+        b, t = src_grid_bg.shape[:2]
+        c1 = bg.size(-3)
+        h, w = self.src_shape
+        g = src_grid_bg.reshape(b * t, h, w, 2)
+        if bg.ndim == 4:  # (B, C+1, H, W) shared over time (lvd.py:555): n_in = b
+            out = WF.grid_sample(bg.reshape(b, c1, h, w), g, delta=delta_bg, broadcast=(t, 1))
+        else:
+            out = WF.grid_sample(bg.reshape(b * t, c1, h, w), g, delta=delta_bg)
+        return out.view(b, t, 1, c1, h, w)
+
+    def _occ_product(self, alpha, occ):
+        """alpha (..., L, h, w) in [0, 1], occ (..., L, L) with the same leading dims ->
+        alpha_j * prod_i (1 - alpha_i occ[i, j])."""
+        lead = alpha.shape[:-3]
+        nl, h, w = alpha.shape[-3:]
+        out = WF.occ_composite(alpha.reshape(-1, nl, h, w), occ.reshape(-1, nl, nl))
+        return out.view(*lead, nl, h, w)
+
+    def alpha_to_alpha(self, obj_alpha, bg_alpha, grid, occ):
+        """Reference lvd.py:561-573 (only reached through the unused ``decode_layer`` mode)."""
+        src_grid_obj = grid[1]
+        b, t, no = src_grid_obj.shape[:3]
+        a = ((self.layer_to_output(obj_alpha, bg_alpha, grid) + 1) / 2).squeeze(3)   # B T L H W
+        occ = occ.reshape(b, t, no + 1, no + 1)
+        factor = torch.stack([(1 - a * occ[:, :, :, j, None, None]).prod(dim=2) for j in range(no + 1)],
+                             dim=2).unsqueeze(3)                                  # prod_i (1 - a_i occ_ij)
+        output_alpha = self._occ_product(a, occ).unsqueeze(3)
+        obj_occ, bg_occ = self.layer_from_input(factor, grid)
+        return (obj_occ * (obj_alpha.unsqueeze(1) + 1) - 1, bg_occ * (bg_alpha.unsqueeze(1) + 1) - 1,
+                output_alpha)
+
+    # ------------------------------------------------------------------ flow helpers (WIF.inpaint)
+    def grid_to_bg_flow_from_ref_to_pred(self, grid, ctx_len, ref):
+        _, _, tgt_grid_bg, src_grid_bg = grid
+        bg_flow = (tgt_grid_bg[:, [ref]] - tgt_grid_bg[:, ctx_len:]).permute(0, 1, 4, 2, 3)
+        bg_flow = self.bg_to_output(bg_flow, [None, None, None, src_grid_bg[:, ctx_len:]], delta_bg=0).squeeze(2)
+        return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
+
+    def grid_to_obj_flow_from_ref_to_pred(self, grid, ctx_len, ref, obj_id):
+        tgt_grid_obj, src_grid_obj, _, _ = grid
+        obj_flow = tgt_grid_obj[:, [ref], [obj_id]] - tgt_grid_obj[:, ctx_len:, [obj_id]]
+        obj_flow = obj_flow.permute(0, 1, 2, 5, 3, 4)  # B T 1 2 Ho Wo
+        b, t = obj_flow.shape[:2]
+        h, w = self.src_shape
+        g = src_grid_obj[:, ctx_len:, [obj_id]].reshape(b * t, h, w, 2)
+        out = WF.grid_sample(obj_flow.reshape(b * t, 2, *self.tgt_shape), g).view(b, t, 2, h, w)
+        return scale(out, self.scale_hd).permute(0, 1, 3, 4, 2)
+
+    def grid_to_bg_flow_from_ctx_to_ref(self, grid, ctx_len, ref):
+        _, _, tgt_grid_bg, src_grid_bg = grid
+        bg_flow = (tgt_grid_bg[:, :ctx_len] - tgt_grid_bg[:, [ref]]).permute(0, 1, 4, 2, 3)
+        g = src_grid_bg[:, [ref]].expand(-1, ctx_len, -1, -1, -1)
+        bg_flow = self.bg_to_output(bg_flow, [None, None, None, g], delta_bg=0).squeeze(2)
+        return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
+
+    # ------------------------------------------------------------------ flow / alpha synthesis
+    def _lyt_alpha(self, alpha_obj, lyt, hd_lyt, cls):
+        """Layout filter (lvd.py:624-639 / 731-751).  alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W),
+        hd_lyt (B,Tw,Nl,Hd,Wd), cls (B,No,Nl) or None -> (B,Tw,No,1,Hd,Wd).  The reference builds a
+        (B,Tw,No,Nl,Hd,Wd) tensor; this loops over the objects instead."""
+        no = alpha_obj.shape[2]
+        hd_prob = hd_lyt.softmax(dim=2)
+        if cls is None or self.weight_cls:
+            win = alpha_obj.squeeze(3) + 1e-6                                   # B Tw No H W
+            if self.weight_cls:
+                win = win * torch.einsum("bon,btnhw->btohw", cls + self.min_cls, lyt.softmax(dim=2))
+            total = win.sum(dim=(1, 3, 4))                                      # B No
+            mean = torch.einsum("btohw,btnhw->bon", win, lyt) / total.unsqueeze(2)
+            dist = mean.softmax(dim=2)                                          # B No Nl
+        else:
+            dist = cls
+        out = [1 - (dist[:, None, o, :, None, None] - hd_prob).abs().sum(dim=2, keepdim=True) / 2
+               for o in range(no)]
+        return torch.stack(out, dim=2)
+
+    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
+        tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
+        b, _, no = src_grid_obj.shape[:3]
+        tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
+        nl = no + 1
+        h, w = self.src_shape
+        hd, wd = self.src_shape_hd
+        ho, wo = self.tgt_shape
+        hd_input = input
+        input = scale(hd_input, 1 / self.scale_hd)
+        win = slice(0, tc) if ctx_only else slice(0, t)
+
+        # rough alpha of every layer in image space (objects / background shared over time)
+        alpha = self.layer_to_output((obj_alpha + 1) / 2, (bg_alpha + 1) / 2, grid, delta_bg=0, delta_obj=0)
+        alpha = alpha[:, win]                                                   # B Tw L 1 H W
+        filt = ctx_only or not self.no_filter
+        if filt:
+            lyt_alpha = self._lyt_alpha(alpha[:, :, 1:], input[:, win, 3:], hd_input[:, win, 3:], cls)
+        alpha = scale(alpha, self.scale_hd)
+        if filt:
+            alpha = torch.cat([alpha[:, :, :1], alpha[:, :, 1:] * lyt_alpha], dim=2)
+        occ = occ.reshape(b, t, nl, nl)
+        alpha = self._occ_product(alpha.squeeze(3), occ[:, win]).unsqueeze(3)    # B Tw L 1 Hd Wd
+        alpha_unflt = alpha
+
+        # per-layer flow in layer space between context and predicted frames, warped to the image
+        obj_flow = gather_time(tgt_grid_obj, ctx_ts) - tgt_grid_obj[:, pred_ts].unsqueeze(1)
+        obj_flow = obj_flow.permute(0, 1, 2, 3, 6, 4, 5).reshape(b * tc, tp, no, 2, ho, wo)
+        bg_flow = gather_time(tgt_grid_bg, ctx_ts) - tgt_grid_bg[:, pred_ts].unsqueeze(1)
+        bg_flow = bg_flow.permute(0, 1, 2, 5, 3, 4).reshape(b * tc, tp, 2, h, w)
+        sgo = src_grid_obj[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1, -1).reshape(b * tc, tp, no, h, w, 2)
+        sgb = src_grid_bg[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1).reshape(b * tc, tp, h, w, 2)
+        gridp = [None, sgo, None, sgb]
+        is_obj = 1
+        if ctx_only and not self.allow_ghost:
+            ones = torch.ones(b * tc, tp, no, 1, ho, wo, device=input.device, dtype=input.dtype)
+            is_obj = self.obj_to_output(ones, gridp, delta_obj=0)
+            is_obj = (scale(is_obj, self.scale_hd) > 0.9).to(input.dtype).view(b, tc, tp, no, 1, hd, wd)
+            is_obj = torch.cat([torch.ones_like(is_obj[:, :, :, :1]), is_obj], dim=3)
+        flow = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
+        flow = scale(flow.view(b, tc, tp, nl, 2, h, w), self.scale_hd)           # B Tc Tp L 2 Hd Wd
+        samp = self.src_grid_hd + flow.permute(0, 1, 2, 3, 5, 6, 4).reshape(b * tc * tp * nl, hd, wd, 2)
+
+        # context alpha warped by the flow, second occlusion product, flow compositing
+        alpha_ctx = gather_time(alpha, ctx_ts).reshape(b * tc * tp * nl, 1, hd, wd)
+        alpha_ctx = WF.grid_sample(alpha_ctx, samp).reshape(b, tc, tp, nl, 1, hd, wd) * is_obj
+        disocc = alpha_ctx.max(dim=3)[0]
+        occ_p = occ[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1)
+        alpha_ctx = self._occ_product(alpha_ctx.squeeze(4), occ_p).unsqueeze(4)
+        flow = (alpha_ctx * flow).sum(dim=3)
+
+        alpha_unflt = alpha_unflt.squeeze(-3) * 2 - 1
+        alpha = alpha.squeeze(-3) * 2 - 1
+        alpha_ctx = alpha_ctx.squeeze(-3) * 2 - 1
+        return flow, (alpha_unflt if self.fast else None), alpha, alpha_ctx, disocc
+
+    def grid_to_flow(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts):
+        """Reference lvd.py:602-705 (training path: alpha composited on all T frames)."""
+        return self._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, False)
+
+    def grid_to_flow_ctx(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts):
+        """Reference lvd.py:707-828 (restrict_to_ctx inference path)."""
+        return self._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, True)
+
+    def input_to_output(self, input, alpha, flow, ctx_ts, eps=1e-6):
+        """Reference lvd.py:830-853."""
+        b, tc, tp = flow.shape[:3]
+        hd, wd = self.src_shape_hd
+        c = input.size(-3)
+        samp = self.src_grid_hd + flow.permute(0, 1, 2, 4, 5, 3).reshape(b * tc * tp, hd, wd, 2)
+        output = WF.grid_sample(gather_time(input, ctx_ts).reshape(b * tc * tp, c, hd, wd), samp)
+        output = output.reshape(b, tc, tp, c, hd, wd)
+        score = ((alpha + 1) / 2).sum(dim=3, keepdim=True)
+        if self.include_self and tp == input.size(1):
+            score = torch.cat([score, torch.ones_like(score[:, :1])], dim=1)
+            alpha = torch.cat([alpha, torch.ones_like(alpha[:, :1])], dim=1)
+            output = torch.cat([output, input.unsqueeze(1)], dim=1)
+        raw_output = torch.cat([output, alpha], dim=3)
+        output = torch.cat([output, score * 2 - 1], dim=3)
+        score = F.normalize(score + eps, p=1, dim=1)
+        return (output * score).sum(dim=1), raw_output
+
+    # ------------------------------------------------------------------ the four grids
+    def forward(self, obj_pose, bg_pose, invert=True):
+        """Reference lvd.py:855-870: (obj_pose (B,T,No,Lo,2), bg_pose (B,T,1,Lb,2)) ->
+        (tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg)."""
+        b, t, no = obj_pose.shape[:3]
+        lo, lb = self.latent_obj_size, self.latent_size
+        tgt_grid_obj = self.tps_obj(obj_pose.reshape(b * t * no, lo, 2))
+        src_grid_obj = self.invert_obj(tgt_grid_obj) if invert else None
+        tgt_grid_obj = tgt_grid_obj.view(b, t, no, *tgt_grid_obj.shape[1:])
+        src_grid_obj = src_grid_obj.view(b, t, no, *src_grid_obj.shape[1:]) if invert else None
+        tgt_grid_bg = self.tps_bg(bg_pose.reshape(b * t, lb, 2))
+        src_grid_bg = self.invert_bg(tgt_grid_bg, erode=False) if invert else None
+        tgt_grid_bg = tgt_grid_bg.view(b, t, *tgt_grid_bg.shape[1:])
+        src_grid_bg = src_grid_bg.view(b, t, *src_grid_bg.shape[1:]) if invert else None
+        return tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg
