@@ -83,6 +83,21 @@ def cpu_baseline(nl, h, w, frames, reps):
                       f"{cores} threads (fastest of {sorted(probe)} probed on {ncpu} logical CPUs)"}
 
 
+def measured_traffic(entry_point, frames, nl, h, w):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written
+    by tools_dev/traffic.py from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of
+    MI355X_MICROARCH.md), if one matches this workload; else null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("frames") == frames and t.get("layers") == nl and t.get("height") == h and t.get("width") == w:
+            return t["bytes_per_launch"].get(entry_point)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +108,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--frames-per-clip", type=int, default=14)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: fwd+bwd (the headline metric); infer: fwd only + RCCL all-gather "
+                         "of the composited frames (not the headline; vs_baseline/roofline differ)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -115,8 +133,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        from waldo_amd.dist import init_distributed
+        init_distributed(backend="nccl")
 
     import waldo_amd
     from waldo_amd import _lib, functional as WF
@@ -129,7 +147,14 @@ def main():
     layers.requires_grad_()
     pts.requires_grad_()
 
+    from waldo_amd.dist import all_gather_frames
+
     def step():
+        if args.mode == "infer":
+            with torch.no_grad():
+                rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
+                all_gather_frames(rgb, frames * world)
+            return
         layers.grad = None
         pts.grad = None
         rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
@@ -162,6 +187,8 @@ def main():
         hw = h * w
         alg = {"waldo_warp_composite_fwd": (16 * nl + 12) * hw * frames,
                "waldo_warp_composite_bwd": (32 * nl + 12) * hw * frames}
+        if args.mode == "infer":
+            alg.pop("waldo_warp_composite_bwd")
         dom = max(alg, key=lambda k: ks[k][1])
         kern = {}
         for k in alg:
@@ -169,11 +196,12 @@ def main():
             kern[k] = {"launches": ks[k][0], "ms": round(ks[k][1], 4), "alg_bytes": alg[k],
                        "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None,
+                "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": measured_traffic(dom, frames, nl, h, w),
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": alg[dom],
                 "kernels": kern}
         out = {
-            "metric": "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd",
+            "metric": "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd" if args.mode == "train"
+            else "warped+composited frames/sec, fwd only + all-gather (not the headline metric)",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",

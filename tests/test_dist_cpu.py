@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the sharding / all-gather logic of the multi-GPU path
+(waldo_amd/dist.py).  The per-frame compute is a stand-in here (no GPU in this container); the
+GPU kernels themselves are covered by the -m gpu suites."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from waldo_amd.dist import all_gather_frames, init_distributed, shard_frames, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 5, 8, 14, 112, 113):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            flat = [i for s, e in blocks for i in range(s, e)]
+            assert flat == list(range(n)), (n, world, blocks)
+            per = (n + world - 1) // world
+            assert all(e - s <= per for s, e in blocks)
+
+
+def test_shard_frames_slices_per_frame_and_per_layer_tensors():
+    f, nl = 5, 3
+    layers = torch.arange(f * nl * 2).view(f, nl, 2).float()
+    pts = torch.arange(f * nl * 4).view(f * nl, 2, 2).float()
+    occ = torch.arange(f * nl * nl).view(f, nl, nl).float()
+    a, b, c = shard_frames([layers, pts, occ], f, 1, 2, layers=nl)
+    assert torch.equal(a, layers[3:5]) and torch.equal(b, pts[9:15]) and torch.equal(c, occ[3:5])
+    with pytest.raises(ValueError):
+        shard_frames([torch.zeros(7, 1)], f, 0, 2, layers=nl)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, frames, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    # stand-in for the composite: frame f -> constant image of value f (+ channel index)
+    full = torch.arange(frames).float().view(frames, 1, 1, 1) + torch.arange(3).float().view(1, 3, 1, 1)
+    full = full.expand(frames, 3, 4, 6).contiguous()
+    (mine,) = shard_frames([full], frames, rank, world)
+    out = all_gather_frames(mine.clone(), frames)
+    ok = torch.equal(out, full)
+    # the barrier + max-over-ranks timing reduction bench.py uses
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, ok, mine.shape[0], t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames", [4, 5, 1])
+def test_all_gather_frames_world2_gloo(frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert sum(n for _, _, n, _ in res) == frames
+    assert all(tmax == 2.0 for *_, tmax in res)

@@ -18,6 +18,29 @@ constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
 constexpr int kTileW = 64;  // pixel tiles are 64 columns wide: one wavefront = one row segment
 
 // ---------------------------------------------------------------------------------------
+// XCD-aware work mapping.  MI355X deals consecutive workgroup ids round-robin over its 8 XCDs,
+// each with a private 4 MiB L2 (observed behaviour; used for SPEED only, never for correctness).
+// Work = nA outer units (frames / frame chunks / layer planes) x nB inner tiles.  Outer unit a is
+// pinned to XCD a % 8, so every tile of a frame -- and the halo texels neighbouring tiles share --
+// goes through ONE L2 instead of being re-fetched from HBM by several.  Launch 8*ceil(nA/8)*nB
+// workgroups; those decoding to a >= nA exit at once.
+// ---------------------------------------------------------------------------------------
+constexpr int kXcds = 8;
+
+__host__ __device__ inline int64_t xcd_grid(int64_t nA, int64_t nB) {
+  return kXcds * ((nA + kXcds - 1) / kXcds) * nB;
+}
+
+__device__ __forceinline__ bool xcd_decode(unsigned bid, int nA, int nB, int& a, int& b) {
+  const int xcd = (int)(bid & (kXcds - 1));
+  const int j = (int)(bid >> 3);
+  const int al = j / nB;
+  b = j - al * nB;
+  a = al * kXcds + xcd;
+  return a < nA;
+}
+
+// ---------------------------------------------------------------------------------------
 // Bilinear taps of grid_sample(mode=bilinear, padding_mode=zeros, align_corners=False).
 //   ix = ((x + 1) * W - 1) / 2 ; corners (x0,y0) .. (x0+1,y0+1); a corner outside the image
 //   contributes nothing: its weight is zeroed and its address clamped into the image, so every

@@ -98,17 +98,19 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 17 ? 2 : 1))) void wa
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int K3rt, int frames_per_block,
-    int ntx) {
+    int ntx, int ntiles, int nchunks) {
   const int L = EXL ? LP : Lrt;
   const int K3 = EXK ? K3P : K3rt;
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const PixelMap pm = pixel_of(blockIdx.x, wave, lane, H, W, 4, ntx);
+  int chunk, tile;  // frame chunk pinned to an XCD: the tiles of a frame share one L2
+  if (!xcd_decode(blockIdx.x, nchunks, ntiles, chunk, tile)) return;
+  const PixelMap pm = pixel_of(tile, wave, lane, H, W, 4, ntx);
   const int64_t p = pm.p;
   float bas[K3P];
   load_basis<K3P, EXK>(bas, basis_t, HW, p, K3);
 
-  const int f0 = blockIdx.y * frames_per_block;
+  const int f0 = chunk * frames_per_block;
   const int f1 = min(F, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
     float s[LP][4];
@@ -331,6 +333,9 @@ constexpr int kPxRows = kPxWaves;              // tile = kPxWaves rows x 64 colu
 #ifndef WALDO_PX_GROUP
 #define WALDO_PX_GROUP 4
 #endif
+#ifndef WALDO_PX_WPE
+#define WALDO_PX_WPE 3  // waves per SIMD the pixel kernel is compiled for (168 VGPRs: no scratch)
+#endif
 constexpr int kPxGroup = WALDO_PX_GROUP;       // layers whose tap loads are in flight together
 constexpr int kPxPix = kPxRows * kTileW;
 constexpr int kCellRows = 8, kCellCols = 16;   // cell of the footprint table (see warp_composite_splat.hip)
@@ -365,7 +370,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 template <int LP, bool EXL, bool GOCC>
-__global__ __launch_bounds__(kPxThreads, GOCC ? 2 : 4) void warp_composite_bwd_px_kernel(
+__global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_composite_bwd_px_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
@@ -380,7 +385,8 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : 4) void warp_composite_bwd_p
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x, f = blockIdx.y;
+  int f, tile;  // frame pinned to an XCD
+  if (!xcd_decode(blockIdx.x, F, ntiles, f, tile)) return;
 
   // LDS, one array, column-major per pixel with pitch kPxPix + 1 (bank = (row + pixel) mod 32:
   // conflict-free both for a wave writing its 64 pixels of one row and for the MFMA operand reads):
@@ -649,15 +655,26 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
                        const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,
                        int K3, hipStream_t st) {
   const TileGeom g = tile_geom(H, W, 4);
-  int fpb = 4;
-  while (fpb > 1 && (int64_t)g.ntiles * ((F + fpb - 1) / fpb) < 2048) fpb >>= 1;
-  dim3 grid(g.ntiles, (F + fpb - 1) / fpb);
+  // frames per workgroup: amortises the basis loads; prefer a chunk count divisible by the 8 XCDs
+  // (each chunk is pinned to one) while keeping >= 2048 workgroups
+  int fpb = 1;
+  for (int c = 8; c >= 2; --c) {
+    const int chunks = (F + c - 1) / c;
+    if (chunks % kXcds == 0 && (int64_t)chunks * g.ntiles >= 2048) {
+      fpb = c;
+      break;
+    }
+  }
+  const int nchunks = (F + fpb - 1) / fpb;
+  dim3 grid((unsigned)xcd_grid(nchunks, g.ntiles));
   if (L == LP)
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, true, EXK>), grid, dim3(kBlock), 0, st,
-                       layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx);
+                       layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
+                       nchunks);
   else
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, false, EXK>), grid, dim3(kBlock), 0, st,
-                       layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx);
+                       layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
+                       nchunks);
 }
 
 template <int LP, int K3P>
@@ -710,7 +727,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   // bounds start at +0.0f
   (void)hipMemsetAsync(boxes, 0x7f, (size_t)lo.box_bytes, st);
   (void)hipMemsetAsync(bounds, 0, (size_t)lo.bound_bytes, st);
-  dim3 grid(lo.g1.ntiles, F);
+  dim3 grid((unsigned)xcd_grid(F, lo.g1.ntiles));
   auto go = [&](auto exl, auto gocc) {
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
     hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,

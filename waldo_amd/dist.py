@@ -1,0 +1,88 @@
+"""Multi-GPU use of the path: frames are independent units, so ranks SHARD them.
+
+The reference's only parallelism is data parallel over clips (DDP, tools/engine.py:46-49, batch
+split by DistributedSampler tools/engine.py:63-64).  For the warp/composite path that means: every
+output frame (b, t) depends only on its own L layers, control points and occ matrix (SURVEY.md
+section 8e), so each rank composites a contiguous block of frames with no data-path collective;
+only inference that needs all frames everywhere ends with ONE all-gather of the composited frames
+(RCCL over xGMI through torch.distributed's "nccl" backend on ROCm; "gloo" on CPU for the tests).
+One process per GPU, launched by torchrun; rendezvous on 127.0.0.1 unless told otherwise.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """env:// initialisation mirroring the reference's Engine (tools/engine.py:17-35) without its
+    SLURM branch.  Returns (rank, local_rank, world_size).  A single process needs no group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", **kw)
+    return rank, local_rank, world
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous block [start, stop) of `n_units` frames for `rank`: blocks of ceil(n/world),
+    the last ranks may get fewer (or none)."""
+    per = (n_units + world - 1) // world
+    start = min(rank * per, n_units)
+    return start, min(start + per, n_units)
+
+
+def shard_frames(tensors, frames, rank, world, layers=None):
+    """Slice per-frame inputs for this rank.  Each tensor's leading dim is `frames` (e.g. layers
+    (F, L, 4, H, W), occ (F, L, L)) or `frames * layers` (control points (F*L, K, 2))."""
+    s, e = shard_range(frames, rank, world)
+    out = []
+    for t in tensors:
+        if t.shape[0] == frames:
+            out.append(t[s:e])
+        elif layers is not None and t.shape[0] == frames * layers:
+            out.append(t[s * layers:e * layers])
+        else:
+            raise ValueError(f"leading dim {t.shape[0]} is neither F={frames} nor F*L")
+    return out
+
+
+def all_gather_frames(local, frames, group=None):
+    """Gather every rank's block of composited frames (n_local, C, H, W) into (frames, C, H, W) on
+    every rank.  Blocks may be ragged (shard_range): the payload is padded to the common block size,
+    gathered with one all_gather_into_tensor and trimmed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        assert local.shape[0] == frames
+        return local
+    world = dist.get_world_size(group)
+    per = (frames + world - 1) // world
+    if local.shape[0] > per:
+        raise ValueError("local block larger than ceil(frames / world)")
+    if local.shape[0] < per:
+        pad = local.new_zeros(per - local.shape[0], *local.shape[1:])
+        local = torch.cat([local, pad], dim=0)
+    out = local.new_empty(world * per, *local.shape[1:])
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out[:frames]
+
+
+def sharded_warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, gather=True):
+    """Inference over all ranks: composite this rank's frames on its GPU (HIP kernels), then
+    all-gather the RGB frames.  Inputs are the FULL (F, ...) tensors present on every rank (or
+    already this rank's shard with gather=False)."""
+    from . import functional as WF
+    frames, nl = layers.shape[:2]
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    l, p, o = shard_frames([layers, src_pts, occ], frames, rank, world, layers=nl)
+    rgb = WF.warp_composite(l, p, o, inverse_kernel, basis_t)
+    return all_gather_frames(rgb, frames) if gather else rgb
