@@ -80,16 +80,18 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     const float2* __restrict__ rec_g, const float2* __restrict__ rec_a,
     const float* __restrict__ grad_rgb,
     const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
-    float* __restrict__ grad_layers, int FL, int L, int H, int W, int nsx, int nstiles, int ncx,
+    float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int ncx,
     int ncells) {
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  // a layer plane (f * L + l) is pinned to one XCD: its records (2 MB at 256x512) are read by the
-  // 64 source tiles of the plane ~1.8 times in total -- from that XCD's L2, once from HBM
-  int pl, stile;
-  if (!xcd_decode(blockIdx.x, FL, nstiles, pl, stile)) return;
-  const int64_t fl = pl;
-  const int64_t f = fl / L;
+  // a FRAME is pinned to one XCD and its L layer planes run back to back there: a plane's records
+  // (2 MB at 256x512) are read ~1.8 times by its source tiles and the frame's grad_rgb by all L
+  // planes -- from that XCD's L2, once from HBM
+  int fi, rest;
+  if (!xcd_decode(blockIdx.x, F, L * nstiles, fi, rest)) return;
+  const int64_t f = fi;
+  const int64_t fl = f * L + rest / nstiles;
+  const int stile = rest % nstiles;
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
@@ -205,10 +207,10 @@ void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
   const int ncx = (W + kCellCols - 1) / kCellCols, ncy = (H + kCellRows - 1) / kCellRows;
-  dim3 grid((unsigned)xcd_grid((int64_t)F * L, (int64_t)nsx * nsy));
+  dim3 grid((unsigned)xcd_grid(F, (int64_t)L * nsx * nsy));
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
                      reinterpret_cast<const float2*>(rec_g), reinterpret_cast<const float2*>(rec_a),
-                     grad_rgb, cellbox, cellbound, grad_layers, F * L, L, H, W, nsx, nsx * nsy, ncx,
+                     grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
                      ncx * ncy);
 }
 
