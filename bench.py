@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="train: fwd+bwd (the headline metric); infer: fwd only + RCCL all-gather "
                          "of the composited frames (not the headline; vs_baseline/roofline differ)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL on ROCm) is the real thing; gloo only to smoke-test the "
+                         "multi-rank code path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -128,13 +131,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(1)
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU in the smoke test
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         from waldo_amd.dist import init_distributed
-        init_distributed(backend="nccl")
+        init_distributed(backend=args.dist_backend)
 
     import waldo_amd
     from waldo_amd import _lib, functional as WF
@@ -175,7 +180,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 

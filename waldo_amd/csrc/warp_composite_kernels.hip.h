@@ -356,16 +356,27 @@ __device__ __forceinline__ int pk_min(int a, int b) {
   return o;
 }
 
-// component-wise minimum of two packed int16 values over each group of 16 consecutive lanes
+// Reductions over each group of 16 consecutive lanes with DPP row rotations (row_ror:8/4/2/1):
+// plain VALU moves, no LDS crossbar (ds_bpermute) and no lgkmcnt waits.  A rotation is not an
+// xor exchange, but min / + over all 16 lanes only needs every lane to meet every other once.
+template <int ROR>
+__device__ __forceinline__ int row_ror_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x120 + ROR, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ int group16_pk_min(int v) {
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v = pk_min(v, __shfl_xor(v, d, kWave));
+  v = pk_min(v, row_ror_i<8>(v));
+  v = pk_min(v, row_ror_i<4>(v));
+  v = pk_min(v, row_ror_i<2>(v));
+  v = pk_min(v, row_ror_i<1>(v));
   return v;
 }
 
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  v += __int_as_float(row_ror_i<8>(__float_as_int(v)));
+  v += __int_as_float(row_ror_i<4>(__float_as_int(v)));
+  v += __int_as_float(row_ror_i<2>(__float_as_int(v)));
+  v += __int_as_float(row_ror_i<1>(__float_as_int(v)));
   return v;
 }
 
@@ -398,7 +409,9 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
   constexpr int PP1 = kPxPix + 1;
   constexpr int kParkRows = 4 * LP > GGC ? 4 * LP : GGC;
   constexpr int kAccFloats = kPxWaves * 2 * NT * 256;
-  constexpr int kLdsFloats = kParkRows * PP1 > kAccFloats ? kParkRows * PP1 : kAccFloats;
+  constexpr int kTFloats = kPxWaves * kWave * (GGC + 1);  // per-wave transposition slices (TPS)
+  constexpr int kLds0 = kParkRows * PP1 > kAccFloats ? kParkRows * PP1 : kAccFloats;
+  constexpr int kLdsFloats = kLds0 > kTFloats ? kLds0 : kTFloats;
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* gg = lds;
   const int pix = threadIdx.x;
@@ -409,15 +422,58 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
   const float* oc = occ + (int64_t)f * L * L;
   float gxs[LP], gys[LP], ap[LP];
   {
-    float bas[K3];
-    load_basis<K3, true>(bas, basis_t, HW, p, K3);
-    // (A) grid of every layer first: the basis registers die before the tap loads start
+    // (A) TPS grid of every layer on the matrix pipe: for each group of 16 pixels of this wave's
+    // row, D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)] with
+    // v_mfma_f32_16x16x4_f32 (exact f32 fma chain in k order -- the same numbers as the scalar
+    // chain of tps_eval).  Nothing goes through SGPRs (the scalar version kept 38*L mapping values
+    // there and spilled hundreds of them to VGPR lanes) and 38*L VALU fmas per pixel disappear.
+    // The accumulators are transposed through this wave's slice of LDS.
+    constexpr int KS = (K3 + 3) / 4;  // k steps of 4
+    const int arow = lane & 15, kk = lane >> 4;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[g][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      float bv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 16 + arow, l = col >> 1;
+        const float m = (mapping + (int64_t)f * L * K3 * 2)[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
+        bv[nt] = (k < K3 && l < L) ? m : 0.0f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const PixelMap pq = pixel_of(tile, wave, 16 * g + arow, H, W, kPxRows, ntx);
+        // 32-bit byte offset from the uniform base: K3 * HW * 4 < 2^32 is checked by the launcher
+        const float bs = ldb(basis_t, ((uint32_t)min(k, K3 - 1) * (uint32_t)HW + (uint32_t)pq.p) * 4u);
+        const float av = (k < K3) ? bs : 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[g][nt], 0, 0, 0);
+      }
+    }
+    // D[row = (lane>>4)*4 + r][col = lane&15] of group g  ->  T[pixel][col], pitch GGC + 1
+    constexpr int TP = GGC + 1;
+    float* T = lds + wave * (kWave * TP);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * g + kk * 4 + r) * TP + nt * 16 + arow] = acc[g][nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
-      const int lc = EXL ? l : min(l, L - 1);
-      tps_eval<K3, true>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, gxs[l], gys[l]);
+      gxs[l] = T[lane * TP + 2 * l];
+      gys[l] = T[lane * TP + 2 * l + 1];
     }
   }
+  __syncthreads();  // the transposition slices are inside the park region written below
   const float g0 = grad_rgb[(int64_t)f * 3 * HW + p] * livef;
   const float g1 = grad_rgb[(int64_t)f * 3 * HW + HW + p] * livef;
   const float g2 = grad_rgb[(int64_t)f * 3 * HW + 2 * HW + p] * livef;
@@ -572,7 +628,7 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int k = mt * 16 + arow;
-        const float v = basis_t[(int64_t)min(k, K3 - 1) * HW + pq.p];
+        const float v = ldb(basis_t, ((uint32_t)min(k, K3 - 1) * (uint32_t)HW + (uint32_t)pq.p) * 4u);
         av[mt] = (k < K3) ? v : 0.0f;  // dead pixels carry gg == 0
       }
 #pragma unroll
