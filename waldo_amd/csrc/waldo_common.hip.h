@@ -157,6 +157,13 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[N], int lane) 
   return TransposeReduce<N, 32>::run(v, lane);
 }
 
+// LDS-only workgroup barrier: waits for this wave's LDS traffic but NOT for its outstanding global
+// loads / stores (__syncthreads() also emits s_waitcnt vmcnt(0), which would serialise a prefetch
+// that is meant to stay in flight across the barrier)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);

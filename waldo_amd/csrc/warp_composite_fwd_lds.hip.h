@@ -1,0 +1,332 @@
+// Forward of the fused path with LDS-staged sampling (K3 == 19, 4 | W).
+//
+// Same sampling / compositing arithmetic as warp_composite_fwd_kernel, different data movement
+// and a different pipe for the TPS grid:
+//  * the plain kernel fetches every texel four times through the vector-memory path (each lane
+//    loads its own 2x2 taps, 4 bytes per lane).  Here a workgroup (16 x 16 pixels, four rows per
+//    wavefront -- square tiles: the warp's skew over a 64-pixel-wide tile makes its footprint box
+//    ~4x the tile, over 16 pixels ~1.9x) finds, per layer, the bounding box of the 2x2 blocks its
+//    pixels read, streams that box ONCE from global memory with 16-byte-per-lane loads (wave w
+//    stages channel plane w) and takes the bilinear taps out of LDS (ds_read2_b32 pairs);
+//  * with sampling off the vector-memory path the kernel is VALU-issue bound (rocprofv3:
+//    SQ_INSTS_VALU * 4 cycles ~ 80 % of its duration), so the TPS grid of all layers is one
+//    v_mfma_f32_16x16x4_f32 chain per 16 pixels (N = (layer, xy) columns), and the boxes come from
+//    the min / max of the grid coordinates in the accumulator layout (a lane holds 16 pixels of
+//    one column) instead of per-layer cross-lane reductions of tap indices.
+// Layers are staged in groups (all loads of a group in flight together) and double-buffered in LDS
+// (one barrier per layer).  A box that does not fit the LDS image (violent warp) falls back to
+// gathering that layer straight from memory.
+//
+// Tap pairs: instead of clamping the four corners separately, a pixel reads the 2x2 block at
+// (xb, yb) = clamp((x0, y0), 0, (W-2, H-2)), which lies inside the layer; the block's cells are
+// re-assigned to the corners when x0 / y0 was clamped (only within one texel of the border), and
+// corners outside the layer carry zero weight exactly as in make_taps().
+#pragma once
+// included at the end of warp_composite_kernels.hip.h (uses its tps_eval / pixel_of / opaque)
+
+namespace waldo {
+
+#ifndef WALDO_STAGE_CAP
+#define WALDO_STAGE_CAP 512
+#endif
+#ifndef WALDO_STAGE_GROUP
+#define WALDO_STAGE_GROUP 4
+#endif
+constexpr int kStageCap = WALDO_STAGE_CAP;  // texels per channel plane per buffer; box rows x cols <= cap
+constexpr int kLdsTile = 16;     // the staged forward works on 16 x 16-pixel tiles
+
+struct PairTaps {
+  float w00, w01, w10, w11;  // corner weights, identical to Taps
+  int xb, yb;                // origin of the 2x2 block that is read (inside the layer)
+  int cs, rs;                // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
+};
+
+__device__ __forceinline__ PairTaps make_pair_taps(float gx, float gy, int Hi, int Wi) {
+  const Taps t = make_taps(gx, gy, Hi, Wi);
+  PairTaps p;
+  p.w00 = t.w00;
+  p.w01 = t.w01;
+  p.w10 = t.w10;
+  p.w11 = t.w11;
+  p.xb = min(max(t.x0, 0), Wi - 2);
+  p.yb = min(max(t.y0, 0), Hi - 2);
+  p.cs = t.x0 - p.xb;
+  p.rs = t.y0 - p.yb;
+  return p;
+}
+
+// first texel column / row of the 2x2 block a coordinate reads: the xb / yb of make_pair_taps
+// (same instruction chain; monotonic in c, so the block origins of a set of pixels lie between
+// the origins of the set's smallest and largest coordinate)
+__device__ __forceinline__ int block_origin(float c, int size) {
+  float i = unnormalize(c, size);
+  i = fminf(fmaxf(i, -2.0f), (float)size + 1.0f);
+  return min(max((int)floorf(i), 0), size - 2);
+}
+
+// At least 2 waves per SIMD (<= 256 VGPRs) for every LP: with 1 (LP >= 24 wants ~310 registers)
+// hipcc 7.2 parks MFMA accumulator components in AGPRs and reads some of them back wrong
+// (tools_dev/dbg_fwd.py: columns 4k of tile rows 0 and 3, layers 8..15); spilling is correct.
+template <int LP, bool EXL>
+__global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_lds_kernel(
+    const float* __restrict__ layers, const float* __restrict__ basis_t,
+    const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
+    float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int frames_per_block, int ntx,
+    int ntiles, int nchunks) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
+  constexpr int K3 = 19, KS = (K3 + 3) / 4;
+  constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
+  constexpr int kImgFloats = 2 * 4 * kStageCap;  // two buffers of four channel planes
+  constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
+  constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
+  const int L = EXL ? LP : Lrt;
+  const int64_t HW = (int64_t)H * W;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int arow = lane & 15, kk = lane >> 4;
+  int chunk, tile;
+  if (!xcd_decode(blockIdx.x, nchunks, ntiles, chunk, tile)) return;
+  const int col0 = (tile % ntx) * kLdsTile, row0 = (tile / ntx) * kLdsTile + wave * 4;
+  // 16 x 16 tile: wave w covers rows 4w .. 4w+3, lane -> (row 4w + lane / 16, column lane % 16)
+  PixelMap pm;
+  pm.live = col0 + arow < W && row0 + kk < H;
+  pm.p = (int64_t)min(row0 + kk, H - 1) * W + min(col0 + arow, W - 1);
+  const int64_t p = pm.p;
+
+  __shared__ __attribute__((aligned(16))) float lds[kMain + 4 * GGC * 2];
+  float* img = lds;
+  float* boxred = lds + kMain;  // [wave][column][min, max]
+  // zero-weight taps of wild (NaN) coordinates may read any word of the image: keep it finite
+  for (int i = threadIdx.x; i < kMain; i += kBlock) lds[i] = 0.0f;
+
+  // MFMA A operand, v_mfma_f32_16x16x4_f32: A[row = lane & 15][k = lane >> 4]; row = pixel column
+  // arow of tile row g of this wave, k = 4 * ks + kk.  Kept across the frames of the chunk.
+  float av[4][KS];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t pa = (uint32_t)(min(row0 + g, H - 1) * W + min(col0 + arow, W - 1));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      // 32-bit byte offset from the uniform base: K3 * HW * 4 < 2^32 is checked by the launcher
+      const float bs = ldb(basis_t, ((uint32_t)min(k, K3 - 1) * (uint32_t)HW + pa) * 4u);
+      av[g][ks] = (k < K3) ? bs : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  const int f0 = chunk * frames_per_block;
+  const int f1 = min(F, f0 + frames_per_block);
+  for (int f = f0; f < f1; ++f) {
+    // ---- (A) TPS grid of every layer on the matrix pipe:
+    // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[g][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const float* mp = mapping + (int64_t)f * L * K3 * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      float bv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 16 + arow, l = col >> 1;
+        const float m = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
+        bv[nt] = (k < K3 && l < L) ? m : 0.0f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][ks], bv[nt], acc[g][nt], 0, 0, 0);
+    }
+    // ---- (B) range of every grid coordinate over the workgroup's pixels.  In the accumulator
+    // layout a lane holds 16 pixels of ONE column (layer, xy): 30 min/max + two cross-row steps
+    // per 16 columns, instead of a cross-lane reduction per layer and coordinate.
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float mn = acc[0][nt][0], mx = mn;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          mn = fminf(mn, acc[g][nt][r]);
+          mx = fmaxf(mx, acc[g][nt][r]);
+        }
+      mn = fminf(mn, __shfl_xor(mn, 16, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+      mn = fminf(mn, __shfl_xor(mn, 32, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      if (kk == 0) {
+        boxred[(wave * GGC + nt * 16 + arow) * 2 + 0] = mn;
+        boxred[(wave * GGC + nt * 16 + arow) * 2 + 1] = mx;
+      }
+    }
+    // ---- (C) accumulators -> one pixel per lane, through this wave's slice of LDS:
+    // D[row = (lane >> 4) * 4 + r][col = lane & 15] of tile row g -> T[16 g + row][col]
+    float gx[LP], gy[LP];
+    {
+      float* T = lds + wave * (kWave * TP);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(16 * g + kk * 4 + r) * TP + nt * 16 + arow] = acc[g][nt][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < LP; ++l) {
+        gx[l] = T[lane * TP + 2 * l];
+        gy[l] = T[lane * TP + 2 * l + 1];
+      }
+    }
+    __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
+    // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 of every wave turn the range of
+    // "their" column into block origins, then the corners go to SGPRs
+    int lo_t[NT], hi_t[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float mn = boxred[(nt * 16 + arow) * 2 + 0], mx = boxred[(nt * 16 + arow) * 2 + 1];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        mn = fminf(mn, boxred[(w * GGC + nt * 16 + arow) * 2 + 0]);
+        mx = fmaxf(mx, boxred[(w * GGC + nt * 16 + arow) * 2 + 1]);
+      }
+      const int size = (arow & 1) ? H : W;
+      lo_t[nt] = block_origin(mn, size);
+      hi_t[nt] = block_origin(mx, size) + 1;
+    }
+    int bx0[LP], by0[LP], bw[LP], bh[LP];
+#pragma unroll
+    for (int l = 0; l < LP; ++l) {
+      const int nt = (2 * l) / 16, ln = (2 * l) % 16;
+      const int xmin = __builtin_amdgcn_readlane(lo_t[nt], ln), xmax = __builtin_amdgcn_readlane(hi_t[nt], ln);
+      const int ymin = __builtin_amdgcn_readlane(lo_t[nt], ln + 1), ymax = __builtin_amdgcn_readlane(hi_t[nt], ln + 1);
+      bx0[l] = xmin & ~3;
+      by0[l] = ymin;
+      bw[l] = ((xmax - bx0[l] + 1) + 3) & ~3;
+      bh[l] = ymax - ymin + 1;
+    }
+
+    // ---- (E) staging: wave w moves channel plane w of a layer's box, 16 bytes per lane.  The
+    // loads of a whole group of layers are issued back to back (memory latency is paid once per
+    // group, with kGroup boxes in flight per workgroup), then each layer goes registers -> LDS ->
+    // taps; the image is double-buffered, one barrier per layer.
+    constexpr int kGroup = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
+    constexpr int kItems = kStageCap / 4 / kWave;
+    float s[LP][4];
+#pragma unroll
+    for (int g0 = 0; g0 < LP; g0 += kGroup) {
+      f32x4 stg[kGroup][kItems];
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int l = g0 + q;
+        if (l >= LP) continue;
+        const int lc = EXL ? l : min(l, L - 1);
+        const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
+        // unconditional loads (items past the box re-read its last item; a box that does not fit
+        // reads texel 0): no exec-mask branches, so the whole group's loads are issued back to back
+        const bool fits = bh[l] * bw[l] <= kStageCap;
+        const int bw4 = bw[l] >> 2, n = fits ? bh[l] * bw4 : 1;
+        const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
+        const float rcp = 1.0f / (float)bw4;
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+          const int item = min(lane + j * kWave, n - 1);
+          const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
+          const int xg = item - r * bw4;
+          const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
+          stg[q][j] = *reinterpret_cast<const f32x4*>(src + off);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int l = g0 + q;
+        if (l >= LP) continue;
+        if (!EXL && l >= L) {  // padding layer: inert
+          s[l][0] = s[l][1] = s[l][2] = 0.0f;
+          s[l][3] = -1.0f;
+          continue;
+        }
+        const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
+        if (fits) {
+          const int n = bh[l] * (bw[l] >> 2);
+          f32x4* dst = reinterpret_cast<f32x4*>(img + ((l & 1) * 4 + wave) * kStageCap);
+#pragma unroll
+          for (int j = 0; j < kItems; ++j) {
+            const int item = lane + j * kWave;
+            if (item < n) dst[item] = stg[q][j];  // row-major with pitch bw: item = r * bw4 + xg
+          }
+        }
+        __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
+        if (fits) {
+          const PairTaps t = make_pair_taps(gx[l], gy[l], H, W);
+          const float* b0 = img + (l & 1) * 4 * kStageCap;
+          // inside the box by construction; the clamp only matters for NaN coordinates
+          const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+          const bool border = (t.cs | t.rs) != 0;
+          if (__ballot(border) == 0ull) {  // wave-uniform: interior
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float* pc = b0 + c * kStageCap + idx;
+              const float v00 = pc[0], v01 = pc[1], v10 = pc[bw[l]], v11 = pc[bw[l] + 1];
+              s[l][c] = fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float* pc = b0 + c * kStageCap + idx;
+              const float a0 = pc[0], b0v = pc[1], a1 = pc[bw[l]], b1v = pc[bw[l] + 1];
+              // rows: block row 0/1 -> corner rows y0 / y0+1 (rs = y0 - yb)
+              const float ta = t.rs > 0 ? a1 : a0, tb = t.rs > 0 ? b1v : b0v;  // corner row y0
+              const float ua = t.rs < 0 ? a0 : a1, ub = t.rs < 0 ? b0v : b1v;  // corner row y0 + 1
+              const float v00 = t.cs > 0 ? tb : ta, v01 = t.cs < 0 ? ta : tb;
+              const float v10 = t.cs > 0 ? ub : ua, v11 = t.cs < 0 ? ua : ub;
+              s[l][c] = fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
+            }
+          }
+        } else {  // box larger than the LDS image (violent warp): gather straight from memory
+          const Taps t = make_taps(gx[l], gy[l], H, W);
+          const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t);
+        }
+      }
+    }
+
+    // ---- composite: a_0 = 1 (lvd.py:105), a_l = (s_l3 + 1) / 2
+    float a[LP];
+#pragma unroll
+    for (int l = 0; l < LP; ++l) a[l] = (s[l][3] + 1.0f) * 0.5f;
+    a[0] = 1.0f;
+    const float* oc = occ + (int64_t)f * L * L;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int jc = EXL ? j : min(j, L - 1);
+      float pr = 1.0f;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const int ic = EXL ? i : min(i, L - 1);
+        pr *= (1.0f - a[i] * oc[ic * L + jc]);
+      }
+      const float ap = a[j] * pr;
+      r = fmaf(ap, (s[j][0] + 1.0f) * 0.5f, r);
+      g = fmaf(ap, (s[j][1] + 1.0f) * 0.5f, g);
+      b = fmaf(ap, (s[j][2] + 1.0f) * 0.5f, b);
+      if (alpha_out != nullptr && pm.live && (EXL || j < L))
+        alpha_out[((int64_t)f * L + j) * HW + p] = 2.0f * ap - 1.0f;
+    }
+    if (pm.live) {
+      float* o = rgb + (int64_t)f * 3 * HW + p;
+      o[0] = 2.0f * r - 1.0f;
+      o[HW] = 2.0f * g - 1.0f;
+      o[2 * HW] = 2.0f * b - 1.0f;
+    }
+    __syncthreads();  // boxred and the image buffers are re-used by the next frame
+  }
+}
+
+}  // namespace waldo

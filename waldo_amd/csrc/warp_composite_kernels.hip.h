@@ -23,6 +23,8 @@
 //                               atomics only on the shared rims.
 //   warp_composite_bwd_kernel   generic backward (any L <= 32, K3 <= 32): per-tap global atomics.
 #pragma once
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "waldo_common.hip.h"
@@ -691,6 +693,12 @@ void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st);
 
+}  // namespace waldo
+
+#include "warp_composite_fwd_lds.hip.h"
+
+namespace waldo {
+
 // ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
@@ -723,6 +731,21 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
   }
   const int nchunks = (F + fpb - 1) / fpb;
   dim3 grid((unsigned)xcd_grid(nchunks, g.ntiles));
+  if constexpr (EXK) {
+    // LDS-staged sampling needs 16-byte-aligned rows and a 2x2 block inside the layer
+    static const bool plain = getenv("WALDO_FWD_PLAIN") != nullptr;  // A/B switch for testing
+    if (!plain && (W % 4) == 0 && H >= 2 && W >= 2) {
+      const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
+      dim3 grid16((unsigned)xcd_grid(nchunks, nt16));
+      if (L == LP)
+        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, true>), grid16, dim3(kBlock), 0, st, layers,
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks);
+      else
+        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, false>), grid16, dim3(kBlock), 0, st, layers,
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks);
+      return;
+    }
+  }
   if (L == LP)
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, true, EXK>), grid, dim3(kBlock), 0, st,
                        layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
