@@ -36,24 +36,38 @@ __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
 // LDS image of S: [channel][row][kPitch] int32.  kPitch = 80 = 16 (mod 32): the LDS serves a
 // wave-instruction as two 32-lane halves over 32 banks; a wave covers 4 pixel rows x 16 columns,
 // so with this pitch the two rows of a half land on disjoint bank ranges (pitch 64 is a 4-way
-// conflict).  Behind the image, one dump word per lane takes the taps that fall outside S.
+// conflict).  Behind every channel plane, one dump word per lane takes the taps that fall outside
+// S (the same word offset in every plane, so a tap's four channel adds differ only in the
+// instruction's immediate offset).
 constexpr int kPitch = 80;
-constexpr int kImgWords = kSrcRows * kPitch;           // per channel
-constexpr int kDump = 4 * kImgWords;                   // + lane
+constexpr int kImgWords = kSrcRows * kPitch;           // image words per channel
+constexpr int kPlane = kImgWords + kWave;              // + the dump words
+constexpr int kDump = kImgWords;                       // + lane
 
-// taps of one candidate pixel into the S image.  Branch-free: a tap outside S (or outside the
-// layer, or with zero weight) adds 0 to the lane's own dump word -- never to a shared address,
-// where same-address adds would serialise.
+// round(x) to int32 in one instruction (floor(x + 0.5); __float2int_rn is v_rndne + v_cvt)
+__device__ __forceinline__ int cvt_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// taps of one candidate pixel into the S image.  Branch-free: a tap outside S adds to the lane's
+// own dump word -- never to a shared address, where same-address adds would serialise.  (A corner
+// outside the LAYER has weight 0 and adds 0 wherever it lands.)  This loop is VALU-issue bound
+// (rocprofv3: SQ_INSTS_VALU * 4 cycles ~ 3/4 of the kernel), hence two VALU instructions per add:
+// the four corner addresses are selected once, the channel planes are immediate offsets.
 __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const Taps& t,
                                             const float4 rec, float g0, float g1, float g2,
                                             float scale, int sx0, int sy0) {
   const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
-  const bool cx0 = lx0 >= 0 && lx0 < kSrcCols, cx1 = lx0 + 1 >= 0 && lx0 + 1 < kSrcCols;
-  const bool cy0 = ly0 >= 0 && ly0 < kSrcRows, cy1 = ly0 + 1 >= 0 && ly0 + 1 < kSrcRows;
-  const bool in00 = on && cx0 && cy0 && t.w00 != 0.0f, in01 = on && cx1 && cy0 && t.w01 != 0.0f;
-  const bool in10 = on && cx0 && cy1 && t.w10 != 0.0f, in11 = on && cx1 && cy1 && t.w11 != 0.0f;
+  const bool cx0 = (unsigned)lx0 < (unsigned)kSrcCols, cx1 = (unsigned)(lx0 + 1) < (unsigned)kSrcCols;
+  const bool cy0 = on && (unsigned)ly0 < (unsigned)kSrcRows, cy1 = on && (unsigned)(ly0 + 1) < (unsigned)kSrcRows;
   const int base = ly0 * kPitch + lx0;
   const int dump = kDump + lane;
+  int* a00 = img + ((cx0 && cy0) ? base : dump);
+  int* a01 = img + ((cx1 && cy0) ? base + 1 : dump);
+  int* a10 = img + ((cx0 && cy1) ? base + kPitch : dump);
+  int* a11 = img + ((cx1 && cy1) ? base + kPitch + 1 : dump);
   float gv[4];
   gv[0] = rec.x * g0;
   gv[1] = rec.x * g1;
@@ -61,12 +75,11 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
   gv[3] = rec.y;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const int cb = base + c * kImgWords;
     const float gs = gv[c] * scale;
-    atomicAdd(img + (in00 ? cb : dump), in00 ? __float2int_rn(gs * t.w00) : 0);
-    atomicAdd(img + (in01 ? cb + 1 : dump), in01 ? __float2int_rn(gs * t.w01) : 0);
-    atomicAdd(img + (in10 ? cb + kPitch : dump), in10 ? __float2int_rn(gs * t.w10) : 0);
-    atomicAdd(img + (in11 ? cb + kPitch + 1 : dump), in11 ? __float2int_rn(gs * t.w11) : 0);
+    atomicAdd(a00 + c * kPlane, cvt_round(gs * t.w00));
+    atomicAdd(a01 + c * kPlane, cvt_round(gs * t.w01));
+    atomicAdd(a10 + c * kPlane, cvt_round(gs * t.w10));
+    atomicAdd(a11 + c * kPlane, cvt_round(gs * t.w11));
   }
 }
 
@@ -95,13 +108,13 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
-  __shared__ __attribute__((aligned(16))) int lds[4 * kImgWords + kWave + kMaxHit + 2 * kG2Waves + 4];
+  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + 2 * kG2Waves + 4];
   int* img = lds;
-  int* hitlist = lds + 4 * kImgWords + kWave;
+  int* hitlist = lds + 4 * kPlane;
   int* wcount = hitlist + kMaxHit;                      // hits per wave (current chunk)
   float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);
 
-  for (int e = threadIdx.x; e < 4 * kImgWords + kWave; e += kG2Threads) img[e] = 0;
+  for (int e = threadIdx.x; e < 4 * kPlane; e += kG2Threads) img[e] = 0;
 
   // ---- cells whose box reaches S, listed in cell order (deterministic), and the sum of their
   // contribution bounds.  Chunks of kG2Threads cells; ballot-based compaction inside a wave.
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const unsigned doff = (unsigned)(__mul24(y, W) + x);
       const int li = (e >> 6) * kPitch + (e & 63);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) (gbase + c * HW)[doff] = (float)img[c * kImgWords + li] * inv_scale;
+      for (int c = 0; c < 4; ++c) (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * inv_scale;
     }
   }
 }
