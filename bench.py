@@ -39,7 +39,8 @@ def synth(frames, nl, h, w, device, seed):
     g = torch.Generator(device=device).manual_seed(seed)
     layers = torch.rand(frames, nl, 4, h, w, generator=g, device=device) * 2 - 1
     ctrl = get_grid(4, 4).view(1, 16, 2).to(device)
-    pts = ctrl + 0.05 * torch.randn(frames * nl, 16, 2, generator=g, device=device)
+    sigma = float(os.environ.get("WALDO_BENCH_SIGMA", "0.05"))  # dev knob; the benchmark is 0.05
+    pts = ctrl + sigma * torch.randn(frames * nl, 16, 2, generator=g, device=device)
     score = torch.randn(frames, nl - 1, generator=g, device=device)
     s = torch.exp(-score ** 2) + 1e-6
     occ = torch.zeros(frames, nl, nl, device=device)

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/waldo_hip.h"
+#include "warp_composite_layout.hip.h"
 
 namespace waldo {
 
@@ -15,7 +16,6 @@ int launch_status(const char* what);
 
 constexpr int kWave = 64;   // gfx950 wavefront
 constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
-constexpr int kTileW = 64;  // pixel tiles are 64 columns wide: one wavefront = one row segment
 
 // ---------------------------------------------------------------------------------------
 // XCD-aware work mapping.  MI355X deals consecutive workgroup ids round-robin over its 8 XCDs,
@@ -93,6 +93,13 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   t.w10 = wx0 * wy1;
   t.w11 = wx1 * wy1;
   return t;
+}
+
+// round(x) to int32 in one instruction (floor(x + 0.5); __float2int_rn is v_rndne + v_cvt)
+__device__ __forceinline__ int cvt_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 __device__ __forceinline__ float ldb(const float* __restrict__ base, uint32_t byte_off) {

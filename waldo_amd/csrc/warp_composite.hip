@@ -54,19 +54,6 @@ using namespace waldo;
 
 extern "C" int waldo_max_layers(void) { return kMaxLayers; }
 
-// two-kernel backward (K3 == 19, L <= 8): footprint table of the 8x16-pixel cells (box + bound),
-// two 8-byte records per (frame, layer, pixel), control-point partials of the 4x64 pixel tiles
-// (same layout as bwd2_layout in warp_composite_kernels.hip.h)
-static int64_t bwd_workspace_bytes(int64_t F, int L, int H, int W, int K3) {
-  if (K3 != 19 || L > 8 || (int64_t)H * W * K3 * 4 >= 4294967296ll) return 0;
-  const int64_t nt1 = (int64_t)((W + 63) / 64) * ((H + 3) / 4);
-  const int64_t ncells = (int64_t)((W + 15) / 16) * ((H + 7) / 8);
-  const int64_t box = ((F * L * ncells * 16 + 255) / 256) * 256;
-  const int64_t bnd = ((F * L * ncells * 4 + 255) / 256) * 256;
-  const int64_t rec = 2 * (((F * L * (int64_t)H * W * 8 + 255) / 256) * 256);
-  return box + bnd + rec + F * nt1 * L * 19 * 2 * 4;
-}
-
 extern "C" int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, int H, int W,
                                                             int K3) {
   if (F < 0 || L < 1 || H < 1 || W < 1) return 0;

@@ -26,14 +26,9 @@
 
 namespace waldo {
 
-#ifndef WALDO_STAGE_CAP
-#define WALDO_STAGE_CAP 512
-#endif
 #ifndef WALDO_STAGE_GROUP
-#define WALDO_STAGE_GROUP 4
+#define WALDO_STAGE_GROUP 4  // layers whose box loads are in flight together
 #endif
-constexpr int kStageCap = WALDO_STAGE_CAP;  // texels per channel plane per buffer; box rows x cols <= cap
-constexpr int kLdsTile = 16;     // the staged forward works on 16 x 16-pixel tiles
 
 struct PairTaps {
   float w00, w01, w10, w11;  // corner weights, identical to Taps
@@ -303,16 +298,28 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_
     a[0] = 1.0f;
     const float* oc = occ + (int64_t)f * L * L;
     float r = 0.0f, g = 0.0f, b = 0.0f;
+    // two layers j per step: the occlusion products run on the packed-fp32 pipe (v_pk_mul_f32 /
+    // v_pk_add_f32, two lanes' worth of work per VALU issue slot -- this kernel is issue bound)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float apv[LP];
 #pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int jc = EXL ? j : min(j, L - 1);
-      float pr = 1.0f;
+    for (int j = 0; j < LP; j += 2) {
+      const int j1 = j + 1 < LP ? j + 1 : j;
+      const int jc0 = EXL ? j : min(j, L - 1), jc1 = EXL ? j1 : min(j1, L - 1);
+      f32x2 pr = {1.0f, 1.0f};
 #pragma unroll
       for (int i = 0; i < LP; ++i) {
         const int ic = EXL ? i : min(i, L - 1);
-        pr *= (1.0f - a[i] * oc[ic * L + jc]);
+        const f32x2 o = {oc[ic * L + jc0], oc[ic * L + jc1]};
+        const f32x2 av = {a[i], a[i]};
+        pr = pr * ((f32x2){1.0f, 1.0f} - av * o);
       }
-      const float ap = a[j] * pr;
+      apv[j] = a[j] * pr[0];
+      if (j + 1 < LP) apv[j + 1] = a[j + 1] * pr[1];
+    }
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const float ap = apv[j];
       r = fmaf(ap, (s[j][0] + 1.0f) * 0.5f, r);
       g = fmaf(ap, (s[j][1] + 1.0f) * 0.5f, g);
       b = fmaf(ap, (s[j][2] + 1.0f) * 0.5f, b);

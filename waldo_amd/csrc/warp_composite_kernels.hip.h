@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 constexpr int kPxWaves = WALDO_PX_WAVES;       // wavefronts per workgroup of K1 (4: two workgroups
                                                // per CU at 256 VGPRs overlap each other's phases)
 constexpr int kPxThreads = kPxWaves * kWave;
-constexpr int kPxRows = kPxWaves;              // tile = kPxWaves rows x 64 columns, one pixel per thread
+static_assert(kPxRows == kPxWaves, "tile = kPxWaves rows x 64 columns, one pixel per thread");
 #ifndef WALDO_PX_GROUP
 #define WALDO_PX_GROUP 4
 #endif
@@ -340,13 +340,9 @@ constexpr int kPxRows = kPxWaves;              // tile = kPxWaves rows x 64 colu
 #endif
 constexpr int kPxGroup = WALDO_PX_GROUP;       // layers whose tap loads are in flight together
 constexpr int kPxPix = kPxRows * kTileW;
-constexpr int kCellRows = 8, kCellCols = 16;   // cell of the footprint table (see warp_composite_splat.hip)
-constexpr int kGmapK3 = 19;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using short2_ = __attribute__((ext_vector_type(2))) short;
-
-__host__ __device__ constexpr int64_t gmap_partial_floats(int L) { return (int64_t)L * kGmapK3 * 2; }
 
 __device__ __forceinline__ int pk_min(int a, int b) {
   short2_ x, y;
@@ -696,6 +692,7 @@ void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb,
 }  // namespace waldo
 
 #include "warp_composite_fwd_lds.hip.h"
+#include "warp_composite_bwd_px16.hip.h"
 
 namespace waldo {
 
@@ -734,7 +731,7 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
   if constexpr (EXK) {
     // LDS-staged sampling needs 16-byte-aligned rows and a 2x2 block inside the layer
     static const bool plain = getenv("WALDO_FWD_PLAIN") != nullptr;  // A/B switch for testing
-    if (!plain && (W % 4) == 0 && H >= 2 && W >= 2) {
+    if (!plain && staged_eligible(H, W)) {
       const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
       dim3 grid16((unsigned)xcd_grid(nchunks, nt16));
       if (L == LP)
@@ -769,25 +766,7 @@ static void launch_bwd(const float* layers, const float* basis_t, const float* m
                      grad_occ, F, L, H, W, K3);
 }
 
-// two-kernel backward; workspace = [cell boxes | cell bounds | records | control-point partials]
-struct Bwd2Layout {
-  int64_t box_bytes, bound_bytes, rec_bytes, part_bytes;
-  TileGeom g1;
-  int ncx, ncells;
-};
-
-static inline Bwd2Layout bwd2_layout(int64_t F, int L, int H, int W) {
-  Bwd2Layout o;
-  o.g1 = tile_geom(H, W, kPxRows);
-  o.ncx = (W + kCellCols - 1) / kCellCols;
-  o.ncells = o.ncx * ((H + kCellRows - 1) / kCellRows);
-  o.box_bytes = ((F * L * o.ncells * 16 + 255) / 256) * 256;
-  o.bound_bytes = ((F * L * o.ncells * 4 + 255) / 256) * 256;
-  o.rec_bytes = 2 * (((F * L * (int64_t)H * W * 8 + 255) / 256) * 256);
-  o.part_bytes = F * o.g1.ntiles * gmap_partial_floats(L) * 4;
-  return o;
-}
-
+// two-kernel backward; workspace = Bwd2Layout
 template <int LP>
 static void launch_bwd2(const float* layers, const float* basis_t, const float* mapping,
                         const float* occ, const float* grad_rgb, const float* grad_alpha,
@@ -802,28 +781,49 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   float* part = grad_mapping == nullptr
                     ? nullptr
                     : reinterpret_cast<float*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes);
-  // boxes are (min x, -max x, min y, -max y): every component starts at a large positive value;
-  // bounds start at +0.0f
-  (void)hipMemsetAsync(boxes, 0x7f, (size_t)lo.box_bytes, st);
-  (void)hipMemsetAsync(bounds, 0, (size_t)lo.bound_bytes, st);
-  dim3 grid((unsigned)xcd_grid(F, lo.g1.ntiles));
-  auto go = [&](auto exl, auto gocc) {
-    constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
-    hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,
-                       layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
-                       grad_occ, F, L, H, W, lo.g1.ntx, lo.g1.ntiles, lo.ncx, lo.ncells);
-  };
   using T = std::true_type;
   using N = std::false_type;
-  if (L == LP) {
-    if (grad_occ != nullptr) go(T{}, T{}); else go(T{}, N{});
+  static const bool gather = getenv("WALDO_BWD_GATHER") != nullptr;  // A/B switch for testing
+  const bool staged = staged_eligible(H, W) && !gather;
+  int ntiles;
+  if (staged) {
+    // LDS-staged pixel kernel: owns its cells, writes their table entries itself
+    ntiles = lo.ntiles16;
+    dim3 grid((unsigned)xcd_grid(F, ntiles));
+    auto go = [&](auto exl, auto gocc) {
+      constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
+      hipLaunchKernelGGL((warp_composite_bwd_px16_kernel<LP, EXL, GOCC>), grid, dim3(kBlock), 0, st, layers,
+                         basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
+                         grad_occ, F, L, H, W, lo.ntx16, ntiles, lo.ncx, lo.ncells);
+    };
+    if (L == LP) {
+      if (grad_occ != nullptr) go(T{}, T{}); else go(T{}, N{});
+    } else {
+      if (grad_occ != nullptr) go(N{}, T{}); else go(N{}, N{});
+    }
   } else {
-    if (grad_occ != nullptr) go(N{}, T{}); else go(N{}, N{});
+    // boxes are (min x, -max x, min y, -max y): every component starts at a large positive value;
+    // bounds start at +0.0f
+    ntiles = lo.ntiles;
+    (void)hipMemsetAsync(boxes, 0x7f, (size_t)lo.box_bytes, st);
+    (void)hipMemsetAsync(bounds, 0, (size_t)lo.bound_bytes, st);
+    dim3 grid((unsigned)xcd_grid(F, ntiles));
+    auto go = [&](auto exl, auto gocc) {
+      constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
+      hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,
+                         layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
+                         grad_occ, F, L, H, W, lo.ntx, ntiles, lo.ncx, lo.ncells);
+    };
+    if (L == LP) {
+      if (grad_occ != nullptr) go(T{}, T{}); else go(T{}, N{});
+    } else {
+      if (grad_occ != nullptr) go(N{}, T{}); else go(N{}, N{});
+    }
   }
   if (part != nullptr) {
     const int64_t n = (int64_t)F * gmap_partial_floats(L);
     hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, part, grad_mapping, F, L, lo.g1.ntiles);
+                       dim3(kBlock), 0, st, part, grad_mapping, F, L, ntiles);
   }
   launch_splat(reinterpret_cast<const float*>(rec_g), reinterpret_cast<const float*>(rec_a), grad_rgb,
                boxes, bounds, grad_layers, F, L, H, W, st);

@@ -1,0 +1,55 @@
+// Tile geometry and workspace layout of the tiled backward (host side; shared by the C-ABI dispatcher, which
+// answers waldo_warp_composite_bwd_workspace_bytes, and by the launchers in
+// warp_composite_kernels.hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace waldo {
+
+constexpr int kGmapK3 = 19;
+constexpr int kTileW = 64;                     // pixel tiles of the plain / record kernels: rows x 64
+constexpr int kPxRows = 4;                     // K1 (record path): 4 x 64 pixels per workgroup
+constexpr int kCellRows = 8, kCellCols = 16;   // cell of the footprint table (record path)
+constexpr int kLdsTile = 16;                   // LDS-staged kernels: 16 x 16 pixels per workgroup
+constexpr int kStageCap = 512;                 // texels per channel plane of a staged image (forward)
+
+inline int64_t round256(int64_t b) { return ((b + 255) / 256) * 256; }
+__host__ __device__ constexpr int64_t gmap_partial_floats(int L) { return (int64_t)L * kGmapK3 * 2; }
+
+// ---- two-kernel backward: [cell boxes | cell bounds | records (grid) | records (alpha) | partials]
+// The pixel kernel runs on 4 x 64 tiles (gather variant) or 16 x 16 tiles (LDS-staged variant,
+// 4 | W); the control-point partials are sized for whichever has more tiles.
+struct Bwd2Layout {
+  int64_t box_bytes, bound_bytes, rec_bytes, part_bytes, total;
+  int ntx, ntiles;        // 4 x 64 tiles
+  int ntx16, ntiles16;    // 16 x 16 tiles
+  int ncx, ncells;
+};
+
+inline bool staged_eligible(int H, int W) { return (W % 4) == 0 && H >= 2 && W >= 2; }
+
+inline Bwd2Layout bwd2_layout(int64_t F, int L, int H, int W) {
+  Bwd2Layout o;
+  o.ntx = (W + kTileW - 1) / kTileW;
+  o.ntiles = o.ntx * ((H + kPxRows - 1) / kPxRows);
+  o.ntx16 = (W + kLdsTile - 1) / kLdsTile;
+  o.ntiles16 = o.ntx16 * ((H + kLdsTile - 1) / kLdsTile);
+  o.ncx = (W + kCellCols - 1) / kCellCols;
+  o.ncells = o.ncx * ((H + kCellRows - 1) / kCellRows);
+  o.box_bytes = round256(F * L * o.ncells * 16);
+  o.bound_bytes = round256(F * L * o.ncells * 4);
+  o.rec_bytes = 2 * round256(F * L * (int64_t)H * W * 8);
+  const int64_t nt = o.ntiles > o.ntiles16 ? o.ntiles : o.ntiles16;
+  o.part_bytes = round256(F * nt * gmap_partial_floats(L) * 4);
+  o.total = o.box_bytes + o.bound_bytes + o.rec_bytes + o.part_bytes;
+  return o;
+}
+
+// 0: the shape is served by the generic backward, which needs no workspace
+inline int64_t bwd_workspace_bytes(int64_t F, int L, int H, int W, int K3) {
+  if (K3 != kGmapK3 || L > 8 || (int64_t)H * W * K3 * 4 >= 4294967296ll) return 0;
+  return bwd2_layout(F, L, H, W).total;
+}
+
+}  // namespace waldo

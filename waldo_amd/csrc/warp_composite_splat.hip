@@ -22,7 +22,6 @@ namespace waldo {
 
 constexpr int kSrcRows = 32, kSrcCols = 64;          // S tile
 constexpr int kSrcTex = kSrcRows * kSrcCols;          // 2048 texels (x4 channels)
-constexpr int kCellRows = 8, kCellCols = 16;          // K1's cell (must match the pixel kernel)
 constexpr int kCellPix = kCellRows * kCellCols;       // 128
 constexpr int kG2Waves = 8;
 constexpr int kG2Threads = kG2Waves * kWave;          // 512
@@ -43,13 +42,6 @@ constexpr int kPitch = 80;
 constexpr int kImgWords = kSrcRows * kPitch;           // image words per channel
 constexpr int kPlane = kImgWords + kWave;              // + the dump words
 constexpr int kDump = kImgWords;                       // + lane
-
-// round(x) to int32 in one instruction (floor(x + 0.5); __float2int_rn is v_rndne + v_cvt)
-__device__ __forceinline__ int cvt_round(float x) {
-  int r;
-  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
 
 // taps of one candidate pixel into the S image.  Branch-free: a tap outside S adds to the lane's
 // own dump word -- never to a shared address, where same-address adds would serialise.  (A corner
