@@ -155,24 +155,50 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
 
   if (bsum > 0.0f) {
     if (nhit <= kMaxHit) {
-      // candidates: 128 pixels per listed cell; a wave takes 4 rows x 16 columns of one cell
+      // candidates: 128 pixels per listed cell; a wave takes 4 rows x 16 columns of one cell.
+      // Two candidates per thread are in flight (ping-pong A / B; deeper rings measured slower):
+      // the loop is a chain
+      // record -> taps -> LDS adds, and with one candidate per trip the kernel mostly waits for
+      // the record loads (rocprofv3: SQ_WAIT_ANY ~ 60 % of the wave cycles).
       const int total = nhit * kCellPix;
-      for (int i = threadIdx.x; i < total; i += kG2Threads) {
-        const int c = hitlist[i >> 7];
-        const int within = i & (kCellPix - 1);
+      struct Cand {
+        unsigned p;
+        bool livep;
+        float2 rg, ra;
+        float g0, g1, g2;
+      };
+      auto fetch = [&](int i, Cand& k) {
+        const int ic = min(i, total - 1);  // past the end: a valid candidate, masked by livep
+        const int c = hitlist[ic >> 7];
+        const int within = ic & (kCellPix - 1);
         const int py = (c / ncx) * kCellRows + (within >> 4);
         const int px = (c % ncx) * kCellCols + (within & 15);
+        k.livep = i < total && py < H && px < W;
+        k.p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
+        k.rg = rgp[k.p];
+        k.ra = rap[k.p];
+        k.g0 = gplane[k.p];
+        k.g1 = (gplane + HW)[k.p];
+        k.g2 = (gplane + 2 * HW)[k.p];
+      };
+      auto splat = [&](const Cand& k) {
+        const Taps t = make_taps(k.rg.x, k.rg.y, H, W);
+        const bool any = k.livep && touches(t, sx0, sy0);
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
-        const bool livep = py < H && px < W;
-        const unsigned p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
-        const float2 rg = rgp[p];
-        const Taps t = make_taps(rg.x, rg.y, H, W);
-        const bool any = livep && touches(t, sx0, sy0);
-        if (__ballot(any) == 0ull) continue;  // wave-uniform: (a', g_alpha) not even loaded
-        const float2 ra = rap[p];
-        const float4 rec = make_float4(ra.x, ra.y, rg.x, rg.y);
-        splat_pixel(img, lane, any, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p], scale,
-                    sx0, sy0);
+        if (__ballot(any) != 0ull)
+          splat_pixel(img, lane, any, t, make_float4(k.ra.x, k.ra.y, k.rg.x, k.rg.y), k.g0, k.g1, k.g2,
+                      scale, sx0, sy0);
+      };
+      Cand ka, kb;
+      int i = threadIdx.x;
+      if (i < total) fetch(i, ka);
+      while (i < total) {  // uniform per wave: total is a multiple of 128, the stride of 512
+        fetch(i + kG2Threads, kb);
+        splat(ka);
+        if (i + kG2Threads >= total) break;
+        fetch(i + 2 * kG2Threads, ka);
+        splat(kb);
+        i += 2 * kG2Threads;
       }
     } else {
       // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
