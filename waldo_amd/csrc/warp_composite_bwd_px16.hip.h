@@ -291,45 +291,67 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
     }
   }
 
-  // ---- (F) composite backward (lvd.py:100-114): a'_j = a_j prod_i (1 - a_i occ[i][j])
+  // ---- (F) composite backward (lvd.py:100-114): a'_j = a_j prod_i (1 - a_i occ[i][j]).
+  // Two layers j per step on the packed-fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of
+  // work per VALU issue slot -- this kernel is issue bound); the contributions of even and odd j
+  // to d loss / d a_m accumulate separately and are added at the end.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   a[0] = 1.0f;
   float ap[LP], ga[LP];
+  {
+    f32x2 ga2[LP];
 #pragma unroll
-  for (int l = 0; l < LP; ++l) ga[l] = 0.0f;
+    for (int l = 0; l < LP; ++l) ga2[l] = (f32x2){0.0f, 0.0f};
 #pragma unroll
-  for (int j = 0; j < LP; ++j) {
-    const int jc = EXL ? j : min(j, L - 1);
-    float tfac[LP], ex[LP];
-    float pre = 1.0f;
+    for (int j = 0; j < LP; j += 2) {
+      const int jc0 = EXL ? j : min(j, L - 1), jc1 = EXL ? j + 1 : min(j + 1, L - 1);
+      f32x2 tfac[LP], ex[LP];
+      f32x2 pre = {1.0f, 1.0f};
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
-      const int ic = EXL ? i : min(i, L - 1);
-      tfac[i] = 1.0f - a[i] * oc[ic * L + jc];
-      ex[i] = pre;
-      pre *= tfac[i];
+      for (int i = 0; i < LP; ++i) {
+        const int ic = EXL ? i : min(i, L - 1);
+        const f32x2 o = {oc[ic * L + jc0], oc[ic * L + jc1]};
+        tfac[i] = (f32x2){1.0f, 1.0f} - (f32x2){a[i], a[i]} * o;
+        ex[i] = pre;
+        pre = pre * tfac[i];
+      }
+      f32x2 suf = {1.0f, 1.0f};
+#pragma unroll
+      for (int i = LP - 1; i >= 0; --i) {
+        ex[i] = ex[i] * suf;
+        suf = suf * tfac[i];
+      }
+      ap[j] = a[j] * pre[0];  // 0 for padding layers
+      ap[j + 1] = a[j + 1] * pre[1];
+      ga[j] = G[j] * pre[0];  // G[j] = d loss / d a'_j
+      ga[j + 1] = G[j + 1] * pre[1];
+      const f32x2 gaj = (f32x2){G[j], G[j + 1]} * (f32x2){a[j], a[j + 1]};
+      float gocc0[LP], gocc1[LP];
+#pragma unroll
+      for (int m = 0; m < LP; ++m) {
+        const int mc = EXL ? m : min(m, L - 1);
+        const f32x2 o = {oc[mc * L + jc0], oc[mc * L + jc1]};
+        ga2[m] = __builtin_elementwise_fma(-gaj * o, ex[m], ga2[m]);
+        if (GOCC) {
+          const f32x2 go = -gaj * (f32x2){a[m], a[m]} * ex[m];
+          gocc0[m] = go[0];
+          gocc1[m] = go[1];
+        }
+      }
+      if (GOCC) {  // compile-time: the reduction costs ~60 registers
+        const int m = bitrev6(lane);
+        if (EXL || j < L) {
+          const float redv = wave_transpose_reduce<LP>(gocc0, lane);
+          if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j, redv);
+        }
+        if (EXL || j + 1 < L) {
+          const float redv = wave_transpose_reduce<LP>(gocc1, lane);
+          if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j + 1, redv);
+        }
+      }
     }
-    float suf = 1.0f;
 #pragma unroll
-    for (int i = LP - 1; i >= 0; --i) {
-      ex[i] *= suf;
-      suf *= tfac[i];
-    }
-    ap[j] = a[j] * pre;      // 0 for padding layers
-    const float gap = G[j];  // d loss / d a'_j
-    ga[j] = fmaf(gap, pre, ga[j]);
-    const float gaj = gap * a[j];
-    float gocc[LP];
-#pragma unroll
-    for (int m = 0; m < LP; ++m) {
-      const int mc = EXL ? m : min(m, L - 1);
-      ga[m] = fmaf(-gaj * oc[mc * L + jc], ex[m], ga[m]);
-      gocc[m] = -gaj * a[m] * ex[m];
-    }
-    if (GOCC && (EXL || j < L)) {  // compile-time: the reduction costs ~60 registers
-      const float redv = wave_transpose_reduce<LP>(gocc, lane);
-      const int m = bitrev6(lane);
-      if (m < L) atomicAdd(grad_occ + (int64_t)f * L * L + m * L + j, redv);
-    }
+    for (int l = 0; l < LP; ++l) ga[l] += ga2[l][0] + ga2[l][1];
   }
   // ---- (G) a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Second half of the records,
   // contribution bounds, and the grid gradient of every layer (read this thread's parked

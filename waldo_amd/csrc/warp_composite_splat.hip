@@ -140,7 +140,9 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       nhit += wcount[w];
       bsum += wbound[w];
     }
-    if (hit && base + before < kMaxHit) hitlist[base + before] = c;
+    // listed as the cell's pixel origin (row << 16 | column): the division happens once per cell
+    if (hit && base + before < kMaxHit)
+      hitlist[base + before] = (((c / ncx) * kCellRows) << 16) | ((c % ncx) * kCellCols);
     __syncthreads();
   }
   // fixed-point scale: bsum bounds the magnitude of ANY texel sum (bilinear weights are <= 1);
@@ -169,17 +171,18 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       };
       auto fetch = [&](int i, Cand& k) {
         const int ic = min(i, total - 1);  // past the end: a valid candidate, masked by livep
-        const int c = hitlist[ic >> 7];
+        const int org = hitlist[ic >> 7];
         const int within = ic & (kCellPix - 1);
-        const int py = (c / ncx) * kCellRows + (within >> 4);
-        const int px = (c % ncx) * kCellCols + (within & 15);
+        const int py = (org >> 16) + (within >> 4);
+        const int px = (org & 0xffff) + (within & 15);
         k.livep = i < total && py < H && px < W;
         k.p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
-        k.rg = rgp[k.p];
-        k.ra = rap[k.p];
-        k.g0 = gplane[k.p];
-        k.g1 = (gplane + HW)[k.p];
-        k.g2 = (gplane + 2 * HW)[k.p];
+        // 32-bit byte offsets from uniform bases (HW * 8 < 2^32 is implied by the launcher's check)
+        k.rg = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rgp) + k.p * 8u);
+        k.ra = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rap) + k.p * 8u);
+        k.g0 = ldb(gplane, k.p * 4u);
+        k.g1 = ldb(gplane + HW, k.p * 4u);
+        k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
       };
       auto splat = [&](const Cand& k) {
         const Taps t = make_taps(k.rg.x, k.rg.y, H, W);
