@@ -59,18 +59,38 @@ __device__ __forceinline__ float unnormalize(float c, int size) {
   return ((c + 1.0f) * (float)size - 1.0f) * 0.5f;
 }
 
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
+// integer corner and fractional parts; everything else about a tap set derives from these
+struct TapCore {
+  float fx, fy;
+  int x0, y0;  // may be -2 .. W + 1 / H + 1: unclamped
+};
+
+__device__ __forceinline__ TapCore tap_core(float gx, float gy, int Hi, int Wi) {
   float ix = unnormalize(gx, Wi);
   float iy = unnormalize(gy, Hi);
   // keep the float->int conversion defined for wild / NaN coordinates; anything clamped here has
   // all four corners outside the image anyway
   ix = fminf(fmaxf(ix, -2.0f), (float)Wi + 1.0f);
   iy = fminf(fmaxf(iy, -2.0f), (float)Hi + 1.0f);
-  float x0f = floorf(ix), y0f = floorf(iy);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  TapCore c;
+  c.fx = ix - x0f;
+  c.fy = iy - y0f;
+  c.x0 = (int)x0f;
+  c.y0 = (int)y0f;
+  return c;
+}
+
+// all four corners inside the layer: every validity factor is exactly 1
+__device__ __forceinline__ bool tap_interior(const TapCore& c, int Hi, int Wi) {
+  return (unsigned)c.x0 < (unsigned)(Wi - 1) && (unsigned)c.y0 < (unsigned)(Hi - 1);
+}
+
+__device__ __forceinline__ Taps finish_taps(const TapCore& c, int Hi, int Wi) {
   Taps t;
-  t.fx = ix - x0f;
-  t.fy = iy - y0f;
-  int x0 = (int)x0f, y0 = (int)y0f;
+  t.fx = c.fx;
+  t.fy = c.fy;
+  const int x0 = c.x0, y0 = c.y0;
   int x1 = x0 + 1, y1 = y0 + 1;
   t.x0 = x0;
   t.y0 = y0;
@@ -93,6 +113,10 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   t.w10 = wx0 * wy1;
   t.w11 = wx1 * wy1;
   return t;
+}
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
+  return finish_taps(tap_core(gx, gy, Hi, Wi), Hi, Wi);
 }
 
 // round(x) to int32 in one instruction (floor(x + 0.5); __float2int_rn is v_rndne + v_cvt)

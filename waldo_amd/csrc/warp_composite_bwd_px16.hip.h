@@ -25,8 +25,8 @@ struct BoxTaps {
   int cs, rs;                    // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
 };
 
-__device__ __forceinline__ BoxTaps make_box_taps(float gx, float gy, int Hi, int Wi) {
-  const Taps t = make_taps(gx, gy, Hi, Wi);
+__device__ __forceinline__ BoxTaps make_box_taps(const TapCore& tc, int Hi, int Wi) {
+  const Taps t = finish_taps(tc, Hi, Wi);
   BoxTaps p;
   p.w00 = t.w00;
   p.w01 = t.w01;
@@ -238,29 +238,33 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
         }
       }
       __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
-      const BoxTaps t = make_box_taps(gxs[l], gys[l], H, W);
+      const TapCore tc = tap_core(gxs[l], gys[l], H, W);
       const float* b0 = img + (l & 1) * 4 * kStageCap;
-      // inside the box by construction; the clamp only matters for NaN coordinates
-      const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
-      const bool border = (t.cs | t.rs) != 0;
       float sv[4], sx[4], sy[4];
       if (!fits[l]) {  // box larger than the LDS image (violent warp): gather straight from memory
-        const Taps tg = make_taps(gxs[l], gys[l], H, W);
+        const Taps tg = finish_taps(tc, H, W);
         const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
         for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, tg, sx[c], sy[c]);
-      } else if (__ballot(border) == 0ull) {  // wave-uniform: interior, all four corners valid
+      } else if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
+        // wave-uniform: all corners inside the layer, every validity factor is exactly 1
+        const float wx0 = 1.0f - tc.fx, wy0 = 1.0f - tc.fy;
+        const float w00 = wx0 * wy0, w01 = tc.fx * wy0, w10 = wx0 * tc.fy, w11 = tc.fx * tc.fy;
+        const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float* pc = b0 + c * kStageCap + idx;
           const float p00 = pc[0], p01 = pc[1], p10 = pc[bw[l]], p11 = pc[bw[l] + 1];
-          const float top = fmaf(t.fx, p01 - p00, p00);
-          const float bot = fmaf(t.fx, p11 - p10, p10);
-          sx[c] = fmaf(t.fy, (p11 - p10) - (p01 - p00), p01 - p00);
+          const float top = fmaf(tc.fx, p01 - p00, p00);
+          const float bot = fmaf(tc.fx, p11 - p10, p10);
+          sx[c] = fmaf(tc.fy, (p11 - p10) - (p01 - p00), p01 - p00);
           sy[c] = bot - top;
-          sv[c] = fmaf(p11, t.w11, fmaf(p10, t.w10, fmaf(p01, t.w01, p00 * t.w00)));
+          sv[c] = fmaf(p11, w11, fmaf(p10, w10, fmaf(p01, w01, p00 * w00)));
         }
       } else {
+        const BoxTaps t = make_box_taps(tc, H, W);
+        // inside the box by construction; the clamp only matters for NaN coordinates
+        const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float* pc = b0 + c * kStageCap + idx;

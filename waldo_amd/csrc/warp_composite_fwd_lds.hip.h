@@ -36,8 +36,8 @@ struct PairTaps {
   int cs, rs;                // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
 };
 
-__device__ __forceinline__ PairTaps make_pair_taps(float gx, float gy, int Hi, int Wi) {
-  const Taps t = make_taps(gx, gy, Hi, Wi);
+__device__ __forceinline__ PairTaps make_pair_taps(const TapCore& tc, int Hi, int Wi) {
+  const Taps t = finish_taps(tc, Hi, Wi);
   PairTaps p;
   p.w00 = t.w00;
   p.w01 = t.w01;
@@ -257,19 +257,24 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_
         }
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
-          const PairTaps t = make_pair_taps(gx[l], gy[l], H, W);
+          const TapCore tc = tap_core(gx[l], gy[l], H, W);
           const float* b0 = img + (l & 1) * 4 * kStageCap;
-          // inside the box by construction; the clamp only matters for NaN coordinates
-          const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
-          const bool border = (t.cs | t.rs) != 0;
-          if (__ballot(border) == 0ull) {  // wave-uniform: interior
+          if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
+            // wave-uniform: all corners inside the layer, every validity factor is exactly 1 --
+            // the weights are those of make_taps() without the (v_cmp, v_cndmask, v_mul) per corner
+            const float wx0 = 1.0f - tc.fx, wy0 = 1.0f - tc.fy;
+            const float w00 = wx0 * wy0, w01 = tc.fx * wy0, w10 = wx0 * tc.fy, w11 = tc.fx * tc.fy;
+            const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const float* pc = b0 + c * kStageCap + idx;
               const float v00 = pc[0], v01 = pc[1], v10 = pc[bw[l]], v11 = pc[bw[l] + 1];
-              s[l][c] = fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
+              s[l][c] = fmaf(v11, w11, fmaf(v10, w10, fmaf(v01, w01, v00 * w00)));
             }
           } else {
+            const PairTaps t = make_pair_taps(tc, H, W);
+            // inside the box by construction; the clamp only matters for NaN coordinates
+            const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const float* pc = b0 + c * kStageCap + idx;

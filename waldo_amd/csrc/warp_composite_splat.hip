@@ -76,7 +76,7 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
 }
 
 // does any tap of this pixel fall into S?
-__device__ __forceinline__ bool touches(const Taps& t, int sx0, int sy0) {
+__device__ __forceinline__ bool touches(const TapCore& t, int sx0, int sy0) {
   const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
   return lx0 >= -1 && lx0 < kSrcCols && ly0 >= -1 && ly0 < kSrcRows;
 }
@@ -185,12 +185,26 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
       };
       auto splat = [&](const Cand& k) {
-        const Taps t = make_taps(k.rg.x, k.rg.y, H, W);
-        const bool any = k.livep && touches(t, sx0, sy0);
+        const TapCore tc = tap_core(k.rg.x, k.rg.y, H, W);
+        const bool any = k.livep && touches(tc, sx0, sy0);
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
-        if (__ballot(any) != 0ull)
+        if (__ballot(any) != 0ull) {
+          Taps t;
+          if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
+            // wave-uniform: all corners inside the layer, every validity factor is exactly 1
+            const float wx0 = 1.0f - tc.fx, wy0 = 1.0f - tc.fy;
+            t.x0 = tc.x0;
+            t.y0 = tc.y0;
+            t.w00 = wx0 * wy0;
+            t.w01 = tc.fx * wy0;
+            t.w10 = wx0 * tc.fy;
+            t.w11 = tc.fx * tc.fy;
+          } else {
+            t = finish_taps(tc, H, W);
+          }
           splat_pixel(img, lane, any, t, make_float4(k.ra.x, k.ra.y, k.rg.x, k.rg.y), k.g0, k.g1, k.g2,
                       scale, sx0, sy0);
+        }
       };
       Cand ka, kb;
       int i = threadIdx.x;
