@@ -45,12 +45,13 @@ def corrected(kernel_sub, width):
                 tot += v * 1024.0 * calib.get(width, {}).get(c, 1.0)
     return tot
 per = {
-    "waldo_warp_composite_fwd": corrected("warp_composite_fwd_kernel", "4B"),
-    "waldo_warp_composite_bwd": corrected("warp_composite_bwd_px_kernel", "4B") + corrected("warp_composite_splat_kernel", "8B")
-                                + corrected("gmap_reduce", "4B"),
+    "waldo_warp_composite_fwd": corrected("warp_composite_fwd_lds_kernel", "16B") + corrected("warp_composite_fwd_kernel", "4B"),
+    "waldo_warp_composite_bwd": corrected("warp_composite_bwd_px16_kernel", "16B") + corrected("warp_composite_bwd_px_kernel", "4B")
+                                + corrected("warp_composite_splat_kernel", "8B") + corrected("gmap_reduce", "4B"),
 }
 res.update(frames=112, layers=8, height=256, width=512, bytes_per_launch=per,
-           note="bwd = pixel kernel (4-byte taps) + gather splat (8-byte records) + partial reduce; "
-                "workspace records written by K1 and re-read by K2 are real HBM traffic of this design")
+           note="fwd = LDS-staged kernel (16-byte box loads); bwd = staged pixel kernel (16-byte box loads, "
+                "8-byte record stores) + gather splat (8-byte records) + partial reduce; workspace records "
+                "written by K1 and re-read by K2 are real HBM traffic of this design")
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
