@@ -115,6 +115,35 @@ int waldo_occ_composite_bwd(const float* alpha, const float* occ, const float* g
                             int64_t occ_div, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A9: the two full-resolution passes of Warper.grid_to_flow_ctx / grid_to_flow
+ * (models/nets/lvd.py:707-828, 602-705), forward only (the inference path).  The low-resolution
+ * inputs come from waldo_grid_sample2d_fwd (lvd.py:723-728, 784-796); Hd = H*scale, Wd = W*scale.
+ *
+ * waldo_flow_ctx_alpha_fwd (lvd.py:731-766): bilinear x`scale` upsampling (F.interpolate,
+ * align_corners=False) of the rough alphas, layout filter, occlusion product.
+ *   alpha_lr (B*Tw,L,H,W) in [0,1]   rough alpha of every layer in image space, frames 0..Tw-1
+ *   input    (B,T,C,Hd,Wd)           layout logits in channels [chan_off, chan_off+Nl) (lvd.py:731)
+ *   dist     (B,L-1,Nl) or NULL      class distribution of every object (NULL: no filter)
+ *   occ      (B,T,L,L)               occlusion order (LVD.compute_occ)
+ *   a01      (B*Tw,L,Hd,Wd)          out: a'_j = a_j prod_i (1 - a_i occ[i][j]) in [0,1]
+ *   alpha_out same shape or NULL     out: 2a' - 1 (the method's `alpha` / `alpha_unflt`)
+ * waldo_flow_ctx_warp_fwd (lvd.py:784-818), M = B*Tc*Tp:
+ *   flow_lr  (M,L,2,H,W)             per-layer flow warped to image space (low resolution)
+ *   isobj_lr (M,L-1,H,W) or NULL     warped ones of the objects (ghost mask, `allow_ghost` = NULL)
+ *   a01      (B*Tw,L,Hd,Wd)          from waldo_flow_ctx_alpha_fwd
+ *   ctx_ts   (B,Tc,Tp) int64, pred_ts (Tp) int64, occ (B,T,L,L)
+ *   flow (M,2,Hd,Wd), alpha_ctx (M,L,Hd,Wd) in [-1,1], disocc (M,Hd,Wd)      outputs
+ * ------------------------------------------------------------------------------------- */
+int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const float* dist,
+                             const float* occ, float* a01, float* alpha_out, int B, int T, int Tw,
+                             int L, int Nl, int C, int chan_off, int H, int W, int scale,
+                             waldo_stream_t stream);
+int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                            const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
+                            float* flow, float* alpha_ctx, float* disocc, int B, int T, int Tw,
+                            int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused hot path (BASELINE.json metric): TPS grid (A2) -> bilinear warp of every 4-channel
  * layer (A4) -> LVD.reduce_comp (A6, lvd.py:100-114) in ONE launch.
  *   layers   (F,L,4,H,W) in [-1,1]   channel 3 = alpha; the alpha of layer 0 is taken as +1

@@ -205,6 +205,38 @@ def test_warper_against_oracle(dev, over):
         close(x, y, what="alpha_to_alpha")
 
 
+@pytest.mark.parametrize("over", [dict(num_obj=16, obj_shape=[2, 2], dim=8, load_dim=32),
+                                  dict(num_obj=11, dim=16, load_dim=48, allow_ghost=True),
+                                  dict(num_obj=3, dim=16, load_dim=16, weight_cls=True, min_cls=0.05)])
+@pytest.mark.parametrize("ctx_only", [True, False])
+def test_flow_ctx_fused_passes(dev, over, ctx_only):
+    """The fused full-resolution passes of grid_to_flow[_ctx] (csrc/flow_ctx.hip)
+    against the CPU oracle and against the unfused per-op path: the recipe's L = 17 layers and
+    Nl = 20 classes at x4, a non-power-of-two x3, and x1 (load_dim == dim)."""
+    from waldo_amd.nets import Warper
+    opt = opt_ns(**over)
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    b, t, nl = 2, 3, 20
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=11)
+    ctx_ts = torch.tensor([[[0], [1]], [[1], [1]]])
+    pred_ts = torch.tensor([2])
+    with torch.no_grad():
+        grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
+        fn_o = WO.grid_to_flow_ctx if ctx_only else WO.grid_to_flow
+        ro = fn_o(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+        args = (inp.to(dev), [x.to(dev) for x in grid_o], occ.to(dev), obj_alpha.to(dev), bg_alpha.to(dev),
+                cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
+        fn_h = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
+        assert wp.fuse_hd and wp._fused_ok(list(args[:1]), cfg.num_obj + 1, nl)
+        rf = fn_h(*args)
+        wp.fuse_hd = False
+        ru = fn_h(*args)
+    for x, y, z, name in zip(rf, ro, ru, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
+        close(x, y, what="fused vs oracle:" + name)
+        close(x, z, what="fused vs unfused:" + name)
+
+
 def test_warper_state_dict_names(dev):
     """Buffer names / shapes survive, so a reference checkpoint's warper.* entries load."""
     from waldo_amd.nets import Warper

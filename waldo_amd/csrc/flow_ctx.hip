@@ -1,0 +1,310 @@
+// A9: the two full-resolution passes of Warper.grid_to_flow_ctx
+// (models/nets/lvd.py:707-828; the unrestricted twin grid_to_flow, :602-705, shares them), fused.
+//
+// The reference runs the HD part of the method as ~25 elementwise / interpolate / grid_sample /
+// softmax / prod launches over (B, Tc, [Tp,] L, [Nl | L,] Hd, Wd) temporaries (2.7 GB for the layout
+// filter and 2.4 GB for the L x L occlusion broadcast at B = 1, Tc = 4, Tp = 1, L = 17, 512 x 1024).
+// Everything that lives at the LOW resolution (layers warped to the image: alpha, flow, object
+// mask; the objects' class distributions) is 1/16 of the pixels and stays with the per-op kernels;
+// the two passes over the HD raster are one kernel each, one thread per HD pixel, the L values of
+// a pixel in registers:
+//
+//   flow_ctx_alpha_kernel  (lvd.py:731-766)   x4 bilinear upsampling of the L rough alphas
+//       (F.interpolate, align_corners=False) -> layout filter: object o keeps
+//       1 - 1/2 sum_n |dist[o][n] - softmax_n(layout logits at the pixel)| of its alpha -> occlusion
+//       product a'_j = a_j prod_i (1 - a_i occ[i][j]) -> a' (kept in [0,1] for the second pass) and
+//       2a' - 1 (the method's `alpha` output).
+//   flow_ctx_warp_kernel   (lvd.py:784-818)   per (b, tc, tp): upsampled per-layer flow ->
+//       alpha of context frame ctx_ts[b,tc,tp] sampled at (pixel + flow_l) (bilinear, zeros) ->
+//       ghost mask (upsampled warped ones > 0.9) -> disocclusion = max_l -> occlusion product with
+//       the predicted frame's order -> flow = sum_l a'_l flow_l; writes flow, 2a' - 1, disocc.
+//
+// Both are HBM streaming passes: A reads Nl + (L taps from the 16x smaller LR planes) and writes
+// 2L floats per HD pixel; B reads ~L gathered alphas and writes L + 3.
+#include "waldo_common.hip.h"
+
+namespace waldo {
+
+// source taps of F.interpolate(mode="bilinear", align_corners=False, scale_factor=s):
+// src = max((dst + 0.5) / s - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, size - 1)
+struct UpTap {
+  int i0, i1;
+  float l0, l1;
+};
+
+__device__ __forceinline__ UpTap up_tap(int dst, float rscale, int size) {
+  const float src = fmaxf(((float)dst + 0.5f) * rscale - 0.5f, 0.0f);
+  UpTap t;
+  t.i0 = min((int)src, size - 1);
+  t.i1 = min(t.i0 + 1, size - 1);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+
+// the four taps of one HD pixel inside ANY low-resolution plane: byte offsets + weights, computed
+// once per thread and shared by all the planes it upsamples (uniform plane base + 32-bit offset)
+struct UpTaps {
+  uint32_t o00, o01, o10, o11;
+  float lx0, lx1, ly0, ly1;
+};
+
+__device__ __forceinline__ UpTaps up_taps(int y, int x, float rscale, int H, int W) {
+  const UpTap ty = up_tap(y, rscale, H), tx = up_tap(x, rscale, W);
+  UpTaps t;
+  t.o00 = (uint32_t)(__mul24(ty.i0, W) + tx.i0) * 4u;
+  t.o01 = (uint32_t)(__mul24(ty.i0, W) + tx.i1) * 4u;
+  t.o10 = (uint32_t)(__mul24(ty.i1, W) + tx.i0) * 4u;
+  t.o11 = (uint32_t)(__mul24(ty.i1, W) + tx.i1) * 4u;
+  t.lx0 = tx.l0;
+  t.lx1 = tx.l1;
+  t.ly0 = ty.l0;
+  t.ly1 = ty.l1;
+  return t;
+}
+
+__device__ __forceinline__ float up_sample(const float* __restrict__ plane, const UpTaps& t) {
+  const float top = t.lx0 * ldb(plane, t.o00) + t.lx1 * ldb(plane, t.o01);
+  const float bot = t.lx0 * ldb(plane, t.o10) + t.lx1 * ldb(plane, t.o11);
+  return t.ly0 * top + t.ly1 * bot;
+}
+
+constexpr int kMaxCls = 32;
+
+template <int LP>
+__global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
+    const float* __restrict__ alpha_lr, const float* __restrict__ input,
+    const float* __restrict__ dist, const float* __restrict__ occ, float* __restrict__ a01,
+    float* __restrict__ alpha_out, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W,
+    int scale, int tiles) {
+  const int Hd = H * scale, Wd = W * scale;
+  const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
+  const int n = blockIdx.x / tiles;  // (b, t) with t < Tw
+  const int b = n / Tw, t = n % Tw;
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  // the objects' class distributions of this batch entry: broadcast reads from LDS
+  __shared__ float sdist[(32 - 1) * kMaxCls];
+  const int No = L - 1;
+  if (dist != nullptr)
+    for (int i = threadIdx.x; i < No * Nl; i += kBlock) sdist[i] = dist[(int64_t)b * No * Nl + i];
+  __syncthreads();
+  if (p >= HWd) return;
+  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
+
+  float a[LP];
+#pragma unroll
+  for (int l = 0; l < LP; ++l)
+    a[l] = (l < L) ? up_sample(alpha_lr + ((int64_t)n * L + min(l, L - 1)) * HW, ut) : 0.0f;
+
+  if (dist != nullptr) {
+    // softmax over the Nl layout logits of this pixel (held in registers)
+    const float* lg = input + (((int64_t)b * T + t) * C + chan_off) * HWd + p;
+    float pr[kMaxCls];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) {
+      pr[c] = (c < Nl) ? lg[(int64_t)min(c, Nl - 1) * HWd] : -INFINITY;
+      m = fmaxf(m, pr[c]);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) {
+      pr[c] = (c < Nl) ? expf(pr[c] - m) : 0.0f;
+      den += pr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
+#pragma unroll
+    for (int l = 1; l < LP; ++l) {
+      const int lc = min(l, L - 1) - 1;
+      float d = 0.0f;
+#pragma unroll
+      for (int c = 0; c < kMaxCls; ++c)
+        if (c < Nl) d += fabsf(sdist[lc * Nl + c] - pr[c]);
+      a[l] *= 1.0f - d / 2.0f;  // padding layers: a == 0 stays 0
+    }
+  }
+
+  // padding layers carry alpha 0 (factor exactly 1); branch-free so that the arrays stay in registers
+  const float* oc = occ + ((int64_t)b * T + t) * L * L;
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    const int jc = min(j, L - 1);
+    float prd = 1.0f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) prd *= (1.0f - a[i] * oc[min(i, L - 1) * L + jc]);
+    const float v = a[j] * prd;
+    if (j < L) {
+      a01[((int64_t)n * L + j) * HWd + p] = v;
+      if (alpha_out != nullptr) alpha_out[((int64_t)n * L + j) * HWd + p] = v * 2.0f - 1.0f;
+    }
+    // one column of occ (scalar loads) at a time: hoisting all L*L of them spills SGPRs
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int LP>
+__global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
+    const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
+    const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
+    const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
+    float* __restrict__ alpha_ctx, float* __restrict__ disocc, int T, int Tw, int Tc, int Tp, int L,
+    int H, int W, int scale, int tiles) {
+  const int Hd = H * scale, Wd = W * scale;
+  const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
+  const int m = blockIdx.x / tiles;  // (b, tc, tp)
+  const int tp = m % Tp, b = m / (Tc * Tp);
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= HWd) return;
+  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
+  // frame of the context alpha (clamped: the index comes from device memory) and of the order
+  const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1));
+  const int tpred = (int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1));
+  // texel centre of the HD identity grid exactly as get_grid() builds it: torch.linspace(start, end,
+  // n) with start / end rounded from double, step = (end - start) / (n - 1) in float, and the
+  // upper half counted down from the end
+  const float sx = (float)(-1.0 + 1.0 / (double)Wd), ex = (float)(1.0 - 1.0 / (double)Wd);
+  const float sy = (float)(-1.0 + 1.0 / (double)Hd), ey = (float)(1.0 - 1.0 / (double)Hd);
+  const float stepx = (Wd > 1) ? (ex - sx) / (float)(Wd - 1) : 0.0f;
+  const float stepy = (Hd > 1) ? (ey - sy) / (float)(Hd - 1) : 0.0f;
+  const float gx0 = (x < Wd / 2) ? sx + stepx * (float)x : ex - stepx * (float)(Wd - 1 - x);
+  const float gy0 = (y < Hd / 2) ? sy + stepy * (float)y : ey - stepy * (float)(Hd - 1 - y);
+
+  // branch-free over the padded layer count (a padding layer re-reads layer L-1 and is zeroed):
+  // conditional writes to the per-layer arrays would keep them out of registers
+  float a[LP], fx[LP], fy[LP];
+  float dis = -INFINITY;
+#pragma unroll
+  for (int l = 0; l < LP; ++l) {
+    const int lc = min(l, L - 1);
+    const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW;
+    const float fxl = up_sample(fl, ut), fyl = up_sample(fl + HW, ut);
+    const Taps t = make_taps(gx0 + fxl, gy0 + fyl, Hd, Wd);
+    float v = tap_sample(a01 + (((int64_t)b * Tw + ts) * L + lc) * HWd, t);
+    if (isobj_lr != nullptr && l >= 1)
+      v *= (up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(lc - 1, 0)) * HW, ut) > 0.9f) ? 1.0f : 0.0f;
+    const bool real = l < L;
+    a[l] = real ? v : 0.0f;
+    fx[l] = real ? fxl : 0.0f;
+    fy[l] = real ? fyl : 0.0f;
+    dis = real ? fmaxf(dis, v) : dis;
+    // two layers' loads in flight at a time: left alone, the scheduler hoists the 16 loads of all
+    // L layers to the top
+    if ((l & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+  }
+  disocc[(int64_t)m * HWd + p] = dis;
+  const float* oc = occ + ((int64_t)b * T + tpred) * L * L;
+  float ox = 0.0f, oy = 0.0f;
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    const int jc = min(j, L - 1);
+    float prd = 1.0f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) prd *= (1.0f - a[i] * oc[min(i, L - 1) * L + jc]);
+    const float v = a[j] * prd;  // 0 for padding layers
+    ox += v * fx[j];
+    oy += v * fy[j];
+    if (j < L) alpha_ctx[((int64_t)m * L + j) * HWd + p] = v * 2.0f - 1.0f;
+    // one column of occ (scalar loads) at a time: hoisting all L*L of them spills SGPRs
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  flow[((int64_t)m * 2) * HWd + p] = ox;
+  flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
+}
+
+static int pad_l(int L) {
+  if (L <= 4) return 4;
+  if (L <= 8) return 8;
+  if (L <= 12) return 12;
+  if (L <= 17) return 17;
+  if (L <= 24) return 24;
+  return 32;
+}
+
+static int check_flow_ctx(const char* fn, int64_t N, int L, int H, int W, int scale) {
+  if (N < 0 || L < 1 || L > 32 || H < 1 || W < 1 || scale < 1 || scale > 64 ||
+      (int64_t)H * scale > 32767 || (int64_t)W * scale > 32767) {
+    set_error("%s: bad shape N=%lld L=%d H=%d W=%d scale=%d (need 1<=L<=32, integer scale, HD side < 32768)",
+              fn, (long long)N, L, H, W, scale);
+    return WALDO_EINVAL;
+  }
+  const int64_t tiles = ((int64_t)H * scale * W * scale + kBlock - 1) / kBlock;
+  if (N * tiles > 2147483647) {
+    set_error("%s: problem too large for one launch", fn);
+    return WALDO_EINVAL;
+  }
+  return WALDO_OK;
+}
+
+}  // namespace waldo
+
+using namespace waldo;
+
+#define WALDO_FC_CASE(LPV, KERNEL, ...)                                                      \
+  case LPV:                                                                                  \
+    hipLaunchKernelGGL((KERNEL<LPV>), dim3((unsigned)(N * tiles)), dim3(kBlock), 0, st,      \
+                       __VA_ARGS__);                                                         \
+    break;
+
+extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const float* dist,
+                                        const float* occ, float* a01, float* alpha_out, int B, int T,
+                                        int Tw, int L, int Nl, int C, int chan_off, int H, int W,
+                                        int scale, waldo_stream_t stream) {
+  const int64_t N = (int64_t)B * Tw;
+  int rc = check_flow_ctx("waldo_flow_ctx_alpha_fwd", N, L, H, W, scale);
+  if (rc) return rc;
+  if (B < 0 || T < 1 || Tw < 1 || Tw > T ||
+      (dist != nullptr && (Nl < 1 || Nl > kMaxCls || chan_off < 0 || chan_off + Nl > C))) {
+    set_error("waldo_flow_ctx_alpha_fwd: bad frame window Tw=%d of T=%d or class channels [%d, %d) of %d "
+              "(at most %d classes)", Tw, T, chan_off, chan_off + Nl, C, kMaxCls);
+    return WALDO_EINVAL;
+  }
+  if (N == 0) return WALDO_OK;
+  if (!alpha_lr || !occ || !a01 || (dist != nullptr && !input)) {
+    set_error("waldo_flow_ctx_alpha_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
+  switch (pad_l(L)) {
+    WALDO_FC_CASE(4, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(8, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(12, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(17, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(24, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(32, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+  }
+  return launch_status("waldo_flow_ctx_alpha_fwd");
+}
+
+extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                                       const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
+                                       float* flow, float* alpha_ctx, float* disocc, int B, int T,
+                                       int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                       waldo_stream_t stream) {
+  const int64_t N = (int64_t)B * Tc * Tp;
+  int rc = check_flow_ctx("waldo_flow_ctx_warp_fwd", N, L, H, W, scale);
+  if (rc) return rc;
+  if (B < 0 || T < 1 || Tw < 1 || Tw > T || Tc < 0 || Tp < 0) {
+    set_error("waldo_flow_ctx_warp_fwd: bad frame counts T=%d Tw=%d Tc=%d Tp=%d", T, Tw, Tc, Tp);
+    return WALDO_EINVAL;
+  }
+  if (N == 0) return WALDO_OK;
+  if (!flow_lr || !a01 || !ctx_ts || !pred_ts || !occ || !flow || !alpha_ctx || !disocc) {
+    set_error("waldo_flow_ctx_warp_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
+  switch (pad_l(L)) {
+    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+  }
+  return launch_status("waldo_flow_ctx_warp_fwd");
+}

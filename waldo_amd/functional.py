@@ -277,6 +277,73 @@ def wif_fuse(vid, net_out, ab=True):
 
 
 # --------------------------------------------------------------------------------------
+# A9: the two HD passes of Warper.grid_to_flow_ctx / grid_to_flow (forward only)
+# --------------------------------------------------------------------------------------
+def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale):
+    """Upsampling + layout filter + first occlusion product (models/nets/lvd.py:731-766).
+    alpha_lr (B*Tw, L, H, W) in [0, 1]; input (B, T, C, Hd, Wd) with the layout logits in channels
+    [chan_off, chan_off + Nl); dist (B, L-1, Nl) or None (no filter); occ (B, T, L, L).
+    Returns (a01, alpha) of shape (B*Tw, L, Hd, Wd): the composited alpha in [0, 1] and 2a - 1.
+    Inference path: no autograd graph is recorded."""
+    _lib.check_cuda(alpha_lr, input, occ)
+    alpha_lr, input, occ = _c(alpha_lr.detach()), _c(input.detach()), _c(occ.detach())
+    n, nl, h, w = alpha_lr.shape
+    b, t, c, hd, wd = input.shape
+    if n != b * tw or tuple(occ.shape) != (b, t, nl, nl) or hd != h * scale or wd != w * scale:
+        raise _lib.WaldoHipError(
+            f"flow_ctx_alpha: inconsistent shapes alpha_lr={tuple(alpha_lr.shape)} input={tuple(input.shape)} "
+            f"occ={tuple(occ.shape)} tw={tw} scale={scale}")
+    ncls = 0
+    if dist is not None:
+        dist = _c(dist.detach())
+        ncls = dist.shape[2]
+        if tuple(dist.shape[:2]) != (b, nl - 1):
+            raise _lib.WaldoHipError(f"flow_ctx_alpha: dist {tuple(dist.shape)} is not (B, L-1, Nl)")
+    a01 = alpha_lr.new_empty(n, nl, hd, wd)
+    out = alpha_lr.new_empty(n, nl, hd, wd)
+    with torch.cuda.device(alpha_lr.device):
+        _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
+                  _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), b, t, tw, nl, ncls, c, chan_off, h, w,
+                  scale, _lib.current_stream(alpha_lr.device))
+    return a01, out
+
+
+def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
+    """Context-alpha warp + ghost mask + disocclusion + second occlusion product + flow compositing
+    (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
+    a01 (B*Tw, L, Hd, Wd) from flow_ctx_alpha; ctx_ts (B, Tc, Tp) long; pred_ts (Tp) long;
+    occ (B, T, L, L).  Returns flow (M, 2, Hd, Wd), alpha_ctx (M, L, Hd, Wd) in [-1, 1],
+    disocc (M, Hd, Wd)."""
+    _lib.check_cuda(flow_lr, a01, occ)
+    if not (ctx_ts.is_cuda and pred_ts.is_cuda):
+        raise _lib.WaldoHipError("flow_ctx_warp: ctx_ts / pred_ts must be on the GPU")
+    flow_lr, a01, occ = _c(flow_lr.detach()), _c(a01), _c(occ.detach())
+    ctx_ts, pred_ts = _c(ctx_ts.long()), _c(pred_ts.long())
+    m, nl, _, h, w = flow_lr.shape
+    b, tc, tp = ctx_ts.shape
+    t = occ.shape[1]
+    hd, wd = a01.shape[-2:]
+    if m != b * tc * tp or pred_ts.numel() != tp or tuple(a01.shape) != (b * tw, nl, h * scale, w * scale) \
+            or tuple(occ.shape) != (b, t, nl, nl):
+        raise _lib.WaldoHipError(
+            f"flow_ctx_warp: inconsistent shapes flow_lr={tuple(flow_lr.shape)} a01={tuple(a01.shape)} "
+            f"ctx_ts={tuple(ctx_ts.shape)} pred_ts={tuple(pred_ts.shape)} occ={tuple(occ.shape)}")
+    if isobj_lr is not None:
+        _lib.check_cuda(isobj_lr)
+        isobj_lr = _c(isobj_lr.detach())
+        if tuple(isobj_lr.shape) != (m, nl - 1, h, w):
+            raise _lib.WaldoHipError(f"flow_ctx_warp: isobj_lr {tuple(isobj_lr.shape)} is not (M, L-1, H, W)")
+    flow = flow_lr.new_empty(m, 2, hd, wd)
+    alpha_ctx = flow_lr.new_empty(m, nl, hd, wd)
+    disocc = flow_lr.new_empty(m, hd, wd)
+    with torch.cuda.device(flow_lr.device):
+        _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
+                  _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
+                  _lib.ptr(disocc), b, t, tw, tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
+    return flow, alpha_ctx, disocc
+
+
+# --------------------------------------------------------------------------------------
 # fused hot path
 # --------------------------------------------------------------------------------------
 class _WarpComposite(torch.autograd.Function):

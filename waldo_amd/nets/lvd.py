@@ -106,6 +106,7 @@ class Warper(nn.Module):
         self.invert_bg = InverseWarp(*self.src_shape, *self.src_shape, num_perm=opt.num_perm_grid)
         self.no_filter = opt.no_filter
         self.allow_ghost = opt.allow_ghost
+        self.fuse_hd = True  # inference: run the two full-resolution passes of grid_to_flow[_ctx] fused
 
     # ------------------------------------------------------------------ image -> layer space
     def layer_from_input(self, input, grid):
@@ -209,26 +210,80 @@ class Warper(nn.Module):
         return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
 
     # ------------------------------------------------------------------ flow / alpha synthesis
-    def _lyt_alpha(self, alpha_obj, lyt, hd_lyt, cls):
-        """Layout filter (lvd.py:624-639 / 731-751).  alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W),
-        hd_lyt (B,Tw,Nl,Hd,Wd), cls (B,No,Nl) or None -> (B,Tw,No,1,Hd,Wd).  The reference builds a
-        (B,Tw,No,Nl,Hd,Wd) tensor; this loops over the objects instead."""
-        no = alpha_obj.shape[2]
-        hd_prob = hd_lyt.softmax(dim=2)
+    def _lyt_dist(self, alpha_obj, lyt, cls):
+        """Class distribution of every object for the layout filter (lvd.py:624-634 / 731-746).
+        alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W), cls (B,No,Nl) or None -> (B,No,Nl)."""
         if cls is None or self.weight_cls:
             win = alpha_obj.squeeze(3) + 1e-6                                   # B Tw No H W
             if self.weight_cls:
                 win = win * torch.einsum("bon,btnhw->btohw", cls + self.min_cls, lyt.softmax(dim=2))
             total = win.sum(dim=(1, 3, 4))                                      # B No
             mean = torch.einsum("btohw,btnhw->bon", win, lyt) / total.unsqueeze(2)
-            dist = mean.softmax(dim=2)                                          # B No Nl
-        else:
-            dist = cls
+            return mean.softmax(dim=2)                                          # B No Nl
+        return cls
+
+    def _lyt_alpha(self, alpha_obj, lyt, hd_lyt, cls):
+        """Layout filter (lvd.py:624-639 / 731-751).  alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W),
+        hd_lyt (B,Tw,Nl,Hd,Wd), cls (B,No,Nl) or None -> (B,Tw,No,1,Hd,Wd).  The reference builds a
+        (B,Tw,No,Nl,Hd,Wd) tensor; this loops over the objects instead."""
+        no = alpha_obj.shape[2]
+        hd_prob = hd_lyt.softmax(dim=2)
+        dist = self._lyt_dist(alpha_obj, lyt, cls)
         out = [1 - (dist[:, None, o, :, None, None] - hd_prob).abs().sum(dim=2, keepdim=True) / 2
                for o in range(no)]
         return torch.stack(out, dim=2)
 
+    def _fused_ok(self, tensors, nl, ncls):
+        """The fused HD passes are forward-only kernels with an integer upsampling factor."""
+        s = self.scale_hd
+        return (not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+                and float(s) == int(s) and int(s) >= 1 and nl <= 32 and 1 <= ncls <= 32
+                and self.src_shape_hd[0] == self.src_shape[0] * int(s)
+                and self.src_shape_hd[1] == self.src_shape[1] * int(s))
+
+    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
+        """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
+        the low resolution goes through the same per-op kernels as the unfused path."""
+        tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
+        b, _, no = src_grid_obj.shape[:3]
+        tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
+        nl = no + 1
+        h, w = self.src_shape
+        hd, wd = self.src_shape_hd
+        ho, wo = self.tgt_shape
+        s = int(self.scale_hd)
+        tw = tc if ctx_only else t
+        alpha = self.layer_to_output((obj_alpha + 1) / 2, (bg_alpha + 1) / 2, grid, delta_bg=0, delta_obj=0)
+        alpha = alpha[:, :tw]                                                   # B Tw L 1 H W
+        dist = None
+        if ctx_only or not self.no_filter:
+            lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
+            dist = self._lyt_dist(alpha[:, :, 1:], lyt, cls)
+        occ = occ.reshape(b, t, nl, nl)
+        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ, tw, 3, s)
+
+        obj_flow = gather_time(tgt_grid_obj, ctx_ts) - tgt_grid_obj[:, pred_ts].unsqueeze(1)
+        obj_flow = obj_flow.permute(0, 1, 2, 3, 6, 4, 5).reshape(b * tc, tp, no, 2, ho, wo)
+        bg_flow = gather_time(tgt_grid_bg, ctx_ts) - tgt_grid_bg[:, pred_ts].unsqueeze(1)
+        bg_flow = bg_flow.permute(0, 1, 2, 5, 3, 4).reshape(b * tc, tp, 2, h, w)
+        sgo = src_grid_obj[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1, -1).reshape(b * tc, tp, no, h, w, 2)
+        sgb = src_grid_bg[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1).reshape(b * tc, tp, h, w, 2)
+        gridp = [None, sgo, None, sgb]
+        is_obj = None
+        if ctx_only and not self.allow_ghost:
+            ones = torch.ones(b * tc, tp, no, 1, ho, wo, device=input.device, dtype=input.dtype)
+            is_obj = self.obj_to_output(ones, gridp, delta_obj=0).reshape(b * tc * tp, no, h, w)
+        flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
+        flow, alpha_ctx, disocc = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01,
+                                                   ctx_ts, pred_ts, occ, tw, s)
+        alpha_out = alpha_out.view(b, tw, nl, hd, wd)
+        return (flow.view(b, tc, tp, 2, hd, wd), (alpha_out if self.fast else None), alpha_out,
+                alpha_ctx.view(b, tc, tp, nl, hd, wd), disocc.view(b, tc, tp, 1, hd, wd))
+
     def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
+        if self.fuse_hd and self._fused_ok([input, occ, obj_alpha, bg_alpha, cls, *grid],
+                                           grid[1].shape[2] + 1, input.size(2) - 3):
+            return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
         tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
