@@ -144,6 +144,19 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
                             int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward only: warp of the context frames
+ * by the composited flow and temporal fusion, incl. the include_self branch (lvd.py:842-845).
+ *   input (B,T,C,Hd,Wd); flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1];
+ *   ctx_ts (B,Tc,Tp) int64; Tc' = Tc + (include_self ? 1 : 0) <= 8; include_self needs Tp == T
+ *   out (B,Tp,C+1,Hd,Wd)  fused frames, last channel = fused (2 score - 1)
+ *   raw (B,Tc',Tp,C+L,Hd,Wd)  per-context warped frames and alphas (the WIF input, wif.py:21)
+ * ------------------------------------------------------------------------------------- */
+int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
+                              const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
+                              int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+                              waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused hot path (BASELINE.json metric): TPS grid (A2) -> bilinear warp of every 4-channel
  * layer (A4) -> LVD.reduce_comp (A6, lvd.py:100-114) in ONE launch.
  *   layers   (F,L,4,H,W) in [-1,1]   channel 3 = alpha; the alpha of layer 0 is taken as +1

@@ -237,6 +237,36 @@ def test_flow_ctx_fused_passes(dev, over, ctx_only):
         close(x, z, what="fused vs unfused:" + name)
 
 
+@pytest.mark.parametrize("include_self", [False, True])
+@pytest.mark.parametrize("shape", [(2, 3, 2, 3, 7, 5, 16, 32), (1, 2, 4, 2, 23, 17, 24, 48), (1, 3, 6, 1, 4, 3, 8, 16)])
+def test_frame_warp_fuse(dev, include_self, shape):
+    """Fused Warper.input_to_output (A10, csrc/flow_ctx.hip) vs the oracle and the per-op path,
+    with and without the include_self branch (lvd.py:842-845: Tp == T appends the unwarped frame)."""
+    from waldo_amd.nets import Warper
+    b, t, tc, tp, c, nl, hd, wd = shape
+    if include_self:
+        tp = t
+    opt = opt_ns(num_obj=nl - 1, dim=hd, load_dim=hd, include_self=include_self)
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    g = torch.Generator().manual_seed(5)
+    lo = torch.randn(b * t, c, hd // 4, wd // 4, generator=g)
+    inp = torch.nn.functional.interpolate(lo, size=(hd, wd), mode="bilinear").view(b, t, c, hd, wd)
+    flow = 0.2 * torch.randn(b, tc, tp, 2, hd, wd, generator=g)
+    alpha = torch.rand(b, tc, tp, nl, hd, wd, generator=g) * 2 - 1
+    ctx_ts = torch.randint(0, t, (b, tc, tp), generator=g)
+    out_o, raw_o = WO.input_to_output(cfg, inp, alpha, flow, ctx_ts)
+    with torch.no_grad():
+        args = (inp.to(dev), alpha.to(dev), flow.to(dev), ctx_ts.to(dev))
+        out_f, raw_f = wp.input_to_output(*args)
+        wp.fuse_hd = False
+        out_u, raw_u = wp.input_to_output(*args)
+    close(out_f, out_o, what="out vs oracle")
+    close(raw_f, raw_o, what="raw vs oracle")
+    close(out_f, out_u, what="out vs per-op")
+    close(raw_f, raw_u, what="raw vs per-op")
+
+
 def test_warper_state_dict_names(dev):
     """Buffer names / shapes survive, so a reference checkpoint's warper.* entries load."""
     from waldo_amd.nets import Warper

@@ -47,6 +47,20 @@ with torch.no_grad():
         torch.cuda.synchronize()
         res[name + "_ms"] = round(e0.elapsed_time(e1) / n, 3)
         res[name + "_peak_extra_MB"] = round((torch.cuda.max_memory_allocated() - base) / 2**20, 1)
+    wp.fuse_hd = True
+    flow, _, alpha, alpha_ctx, disocc = wp.grid_to_flow_ctx(*args)
+    for name, fused in (("i2o_fused", True), ("i2o_per_op", False)):
+        wp.fuse_hd = fused
+        for _ in range(3):
+            out = wp.input_to_output(inp, alpha_ctx, flow, ctx_ts)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            out = wp.input_to_output(inp, alpha_ctx, flow, ctx_ts)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = round(e0.elapsed_time(e1) / 10, 3)
 hwd = 512 * 1024
 alg = b * tc * ((nl + 2 * 17) * hwd * 4) + b * tc * tp * ((17 + 17 + 3) * hwd * 4)
 res["hd_alg_bytes"] = alg

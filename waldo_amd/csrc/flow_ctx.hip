@@ -214,6 +214,109 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
 }
 
+// A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward: warp of the context frames by
+// the composited flow + temporal fusion, one thread per HD pixel of one (b, tp).
+//   warped[tc][c] = grid_sample(input[b, ctx_ts[b,tc,tp], c], id_hd + flow[b,tc,tp])
+//   score[tc]     = sum_l (alpha[b,tc,tp,l] + 1) / 2;  w[tc] = (score + eps) / max(sum_tc |score + eps|, 1e-12)
+//   raw[b,tc,tp]  = cat(warped, alpha);  out[b,tp] = sum_tc cat(warped, 2 score - 1)[tc] * w[tc]
+// `include_self` (lvd.py:842-845, only when Tp == T) appends the unwarped frame tp as one more context
+// with score 1 and alpha 1.  The reference materialises warped, score, the two concatenations and
+// the normalised weights as (B,Tc,Tp,.,Hd,Wd) tensors; here the taps and scores of the Tc contexts
+// of a pixel stay in registers and every input channel is sampled, written to `raw` and fused
+// into `out` in one pass.
+constexpr int kFwMaxCtx = 8;
+
+template <int TCP>
+__global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
+    const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
+    const int64_t* __restrict__ ctx_ts, float* __restrict__ out, float* __restrict__ raw, int T, int Tc,
+    int Tp, int C, int L, int Hd, int Wd, int include_self, float eps, int tiles) {
+  const int64_t HWd = (int64_t)Hd * Wd;
+  const int n = blockIdx.x / tiles;  // (b, tp)
+  const int b = n / Tp, tp = n % Tp;
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= HWd) return;
+  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  const float sx = (float)(-1.0 + 1.0 / (double)Wd), ex = (float)(1.0 - 1.0 / (double)Wd);
+  const float sy = (float)(-1.0 + 1.0 / (double)Hd), ey = (float)(1.0 - 1.0 / (double)Hd);
+  const float stepx = (Wd > 1) ? (ex - sx) / (float)(Wd - 1) : 0.0f;
+  const float stepy = (Hd > 1) ? (ey - sy) / (float)(Hd - 1) : 0.0f;
+  const float gx0 = (x < Wd / 2) ? sx + stepx * (float)x : ex - stepx * (float)(Wd - 1 - x);
+  const float gy0 = (y < Hd / 2) ? sy + stepy * (float)y : ey - stepy * (float)(Hd - 1 - y);
+
+  // taps, score and source frame of every context of this pixel, in registers (branch-free over the
+  // padded context count: a padding context repeats context Tc-1 and is never stored or summed)
+  const int Tcx = Tc + (include_self ? 1 : 0);
+  uint32_t o00[TCP], o01[TCP], o10[TCP], o11[TCP];
+  float w00[TCP], w01[TCP], w10[TCP], w11[TCP], sc[TCP];
+  const float* frame[TCP];
+  float ssum = 0.0f;
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) {
+    const int tcc = min(tc, Tc - 1);
+    const bool real = tc < Tc;
+    const int64_t m = ((int64_t)b * Tc + tcc) * Tp + tp;
+    const float* fl = flow + m * 2 * HWd + p;
+    const Taps t = make_taps(gx0 + fl[0], gy0 + fl[HWd], Hd, Wd);
+    o00[tc] = t.o00;
+    o01[tc] = t.o01;
+    o10[tc] = t.o10;
+    o11[tc] = t.o11;
+    w00[tc] = t.w00;
+    w01[tc] = t.w01;
+    w10[tc] = t.w10;
+    w11[tc] = t.w11;
+    const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1));
+    frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
+    const float* al = alpha + m * L * HWd + p;
+    float* rw = raw + ((((int64_t)b * Tcx + tcc) * Tp + tp) * (C + L) + C) * HWd + p;
+    float s = 0.0f;
+    for (int l = 0; l < L; ++l) {
+      const float av = al[(int64_t)l * HWd];
+      s += (av + 1.0f) / 2.0f;
+      if (real) rw[(int64_t)l * HWd] = av;
+    }
+    sc[tc] = s;
+    ssum += real ? fabsf(s + eps) : 0.0f;
+  }
+  if (include_self) {
+    float* rw = raw + ((((int64_t)b * Tcx + Tc) * Tp + tp) * (C + L) + C) * HWd + p;
+    for (int l = 0; l < L; ++l) rw[(int64_t)l * HWd] = 1.0f;
+    ssum += fabsf(1.0f + eps);
+  }
+  const float den = fmaxf(ssum, 1e-12f);
+  const float wself = (1.0f + eps) / den;
+  float wt[TCP];
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) wt[tc] = (tc < Tc) ? (sc[tc] + eps) / den : 0.0f;
+  const float* self = input + ((int64_t)b * T + min(tp, T - 1)) * C * HWd + p;
+  float* rbase = raw + ((int64_t)b * Tcx * Tp + tp) * (C + L) * HWd + p;  // context tc: + tc * Tp * (C+L) * HWd
+  float* obase = out + ((int64_t)b * Tp + tp) * (C + 1) * HWd + p;
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int tc = 0; tc < TCP; ++tc) {
+      const float* plane = frame[tc] + (int64_t)c * HWd;
+      const float v00 = ldb(plane, o00[tc]), v01 = ldb(plane, o01[tc]);
+      const float v10 = ldb(plane, o10[tc]), v11 = ldb(plane, o11[tc]);
+      const float v = fmaf(v11, w11[tc], fmaf(v10, w10[tc], fmaf(v01, w01[tc], v00 * w00[tc])));
+      if (tc < Tc) rbase[((int64_t)tc * Tp * (C + L) + c) * HWd] = v;
+      acc += v * wt[tc];
+    }
+    if (include_self) {
+      const float v = self[(int64_t)c * HWd];
+      rbase[((int64_t)Tc * Tp * (C + L) + c) * HWd] = v;
+      acc += v * wself;
+    }
+    obase[(int64_t)c * HWd] = acc;
+  }
+  float acc = 0.0f;  // the score channel
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) acc += (sc[tc] * 2.0f - 1.0f) * wt[tc];
+  if (include_self) acc += wself;  // (1 * 2 - 1) * w
+  obase[(int64_t)C * HWd] = acc;
+}
+
 static int pad_l(int L) {
   if (L <= 4) return 4;
   if (L <= 8) return 8;
@@ -307,4 +410,35 @@ extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_
     WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
   }
   return launch_status("waldo_flow_ctx_warp_fwd");
+}
+
+extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
+                                         const int64_t* ctx_ts, float* out, float* raw, int B, int T,
+                                         int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self,
+                                         float eps, waldo_stream_t stream) {
+  if (B < 0 || T < 1 || Tc < 1 || Tc + (include_self ? 1 : 0) > kFwMaxCtx || Tp < 1 || C < 1 || L < 1 ||
+      Hd < 1 || Wd < 1 || Hd > 32767 || Wd > 32767 || (include_self && Tp != T)) {
+    set_error("waldo_frame_warp_fuse_fwd: bad shape B=%d T=%d Tc=%d Tp=%d C=%d L=%d Hd=%d Wd=%d include_self=%d "
+              "(at most %d contexts incl. self; include_self needs Tp == T)", B, T, Tc, Tp, C, L, Hd, Wd,
+              include_self, kFwMaxCtx);
+    return WALDO_EINVAL;
+  }
+  const int64_t tiles = ((int64_t)Hd * Wd + kBlock - 1) / kBlock;
+  if ((int64_t)B * Tp * tiles > 2147483647) {
+    set_error("waldo_frame_warp_fuse_fwd: problem too large for one launch");
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!input || !flow || !alpha || !ctx_ts || !out || !raw) {
+    set_error("waldo_frame_warp_fuse_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  const dim3 grid((unsigned)((int64_t)B * Tp * tiles));
+  if (Tc <= 4)
+    hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)tiles);
+  else
+    hipLaunchKernelGGL(frame_warp_fuse_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)tiles);
+  return launch_status("waldo_frame_warp_fuse_fwd");
 }

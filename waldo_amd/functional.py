@@ -343,6 +343,35 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
     return flow, alpha_ctx, disocc
 
 
+MAX_FUSE_CTX = 8
+
+
+def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
+    """Warper.input_to_output (models/nets/lvd.py:830-853), forward only.  input (B,T,C,Hd,Wd);
+    flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1]; ctx_ts (B,Tc,Tp) long.
+    Returns (out (B,Tp,C+1,Hd,Wd), raw (B,Tc',Tp,C+L,Hd,Wd))."""
+    _lib.check_cuda(input, flow, alpha)
+    if not ctx_ts.is_cuda:
+        raise _lib.WaldoHipError("frame_warp_fuse: ctx_ts must be on the GPU")
+    input, flow, alpha = _c(input.detach()), _c(flow.detach()), _c(alpha.detach())
+    ctx_ts = _c(ctx_ts.long())
+    b, t, c, hd, wd = input.shape
+    _, tc, tp, nl = alpha.shape[:4]
+    if tuple(flow.shape) != (b, tc, tp, 2, hd, wd) or tuple(alpha.shape) != (b, tc, tp, nl, hd, wd) \
+            or tuple(ctx_ts.shape) != (b, tc, tp):
+        raise _lib.WaldoHipError(
+            f"frame_warp_fuse: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
+            f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
+    tcx = tc + (1 if include_self else 0)
+    out = input.new_empty(b, tp, c + 1, hd, wd)
+    raw = input.new_empty(b, tcx, tp, c + nl, hd, wd)
+    with torch.cuda.device(input.device):
+        _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
+                  _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
+                  1 if include_self else 0, float(eps), _lib.current_stream(input.device))
+    return out, raw
+
+
 # --------------------------------------------------------------------------------------
 # fused hot path
 # --------------------------------------------------------------------------------------

@@ -350,6 +350,10 @@ class Warper(nn.Module):
     def input_to_output(self, input, alpha, flow, ctx_ts, eps=1e-6):
         """Reference lvd.py:830-853."""
         b, tc, tp = flow.shape[:3]
+        self_slot = self.include_self and tp == input.size(1)
+        if self.fuse_hd and tc + int(self_slot) <= WF.MAX_FUSE_CTX and \
+                not (torch.is_grad_enabled() and any(x.requires_grad for x in (input, alpha, flow))):
+            return WF.frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=self_slot, eps=eps)
         hd, wd = self.src_shape_hd
         c = input.size(-3)
         samp = self.src_grid_hd + flow.permute(0, 1, 2, 4, 5, 3).reshape(b * tc * tp, hd, wd, 2)
