@@ -267,6 +267,38 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
+@pytest.mark.parametrize("restrict,use_disocc,include_self", [(True, False, False), (True, True, False),
+                                                              (False, True, False), (True, True, True)])
+def test_decode_output_glue(dev, restrict, use_disocc, include_self):
+    """LVD.forward(mode="decode_output") / "estimate_alpha_grid_occ" glue (A11, lvd.py:126-153) vs the
+    oracle's restatement, incl. the use_disocc / include_self branches; the downstream chain runs on
+    the oracle's grids (grid inversion is compared on identical inputs elsewhere)."""
+    from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
+    opt = opt_ns(include_self=include_self)
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    b, t, nl = 2, 3, 5
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=8)
+    tp = t if include_self else 1
+    ctx_ts = torch.randint(0, 2, (b, 2, tp), generator=torch.Generator().manual_seed(2))
+    pred_ts = torch.arange(t) if include_self else torch.tensor([2])
+    occ_score = torch.randn(b, t, cfg.num_obj, generator=torch.Generator().manual_seed(4))
+    mask = (torch.rand(1, 1, 1, *cfg.tgt_shape, generator=torch.Generator().manual_seed(6)) > 0.2).float()
+    with torch.no_grad():
+        grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
+        ref = WO.decode_output(cfg, inp, grid_o, O.compute_occ(occ_score), mask * obj_alpha + (1 - mask) * -1.0,
+                               bg_alpha, cls, ctx_ts, pred_ts, restrict, use_disocc)
+        occ_h, oa_h, ba_h, grid_h = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev),
+                                                            obj_pose.to(dev), bg_pose.to(dev), occ_score.to(dev),
+                                                            obj_alpha_mask=mask.to(dev))
+        close(occ_h, O.compute_occ(occ_score), what="occ")
+        close(grid_h[0], grid_o[0], what="tgo")
+        got = decode_output(wp, inp.to(dev), [x.to(dev) for x in grid_o], occ_h, oa_h, ba_h, cls.to(dev),
+                            ctx_ts.to(dev), pred_ts.to(dev), restrict, use_disocc)
+    for x, y, name in zip(got, ref, ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")):
+        close(x, y, 3e-4 if name in ("output", "raw_output", "raw_alpha") else TOL, what=name)
+
+
 def test_warper_state_dict_names(dev):
     """Buffer names / shapes survive, so a reference checkpoint's warper.* entries load."""
     from waldo_amd.nets import Warper

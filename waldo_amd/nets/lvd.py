@@ -7,8 +7,10 @@ construct and call it unchanged and a reference checkpoint's ``warper.*`` entrie
 are.  Every resampling (``F.grid_sample`` in the reference), every occlusion product
 (``(1 - alpha * occ).prod(dim)``), the TPS grids and the grid inversion run in the hand-written
 gfx950 kernels of ``waldo_amd.functional``; what is left in PyTorch is indexing, concatenation,
-the small softmax / mean of the layout filter and the bilinear ``F.interpolate`` rescale (the
-"next" row f1 of SURVEY.md section 8 fuses those too).  No CPU path: tensors must live on the GPU.
+the small low-resolution softmax / mean of the layout filter and the bilinear ``F.interpolate``
+rescale.  When no autograd graph is needed (inference), the full-resolution passes of
+``grid_to_flow[_ctx]`` and ``input_to_output`` run fused (csrc/flow_ctx.hip; row f1 of SURVEY.md
+section 8).  No CPU path: tensors must live on the GPU.
 
 The occlusion products never materialise the reference's (L, L, h, w) broadcast, so the
 ``fast`` / ``restrict_to_ctx`` memory switches of the reference only change WHAT is returned
@@ -384,3 +386,37 @@ class Warper(nn.Module):
         tgt_grid_bg = tgt_grid_bg.view(b, t, *tgt_grid_bg.shape[1:])
         src_grid_bg = src_grid_bg.view(b, t, *src_grid_bg.shape[1:]) if invert else None
         return tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg
+
+
+# ---------------------------------------------------------------------- LVD.forward glue (A11)
+def estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose, bg_pose, occ_score, obj_alpha_mask=None,
+                            remove_obj=False, freeze_obj=False):
+    """The warp-path part of ``LVD.forward(mode="estimate_alpha_grid_occ")`` (lvd.py:126-135).
+    ``obj_alpha`` (B, No, 1, Ho, Wo) is the object decoder's output (``self.decoder(x_obj)``, a conv
+    net outside this path), ``bg_alpha`` the model's (1, 1, H, W) parameter; ``obj_alpha_mask`` the
+    padding mask of lvd.py:132.  Returns ``(occ, obj_alpha, bg_alpha, grid)``."""
+    bg_alpha = bg_alpha.expand(obj_alpha.size(0), -1, -1, -1)
+    if remove_obj:
+        obj_alpha = 0 * obj_alpha - 1
+    if freeze_obj:
+        obj_alpha = 0 * obj_alpha + 1
+    if obj_alpha_mask is not None:
+        obj_alpha = obj_alpha_mask * obj_alpha + (1 - obj_alpha_mask) * (-1.0)
+    grid = warper(obj_pose, bg_pose)
+    return compute_occ(occ_score), obj_alpha, bg_alpha, grid
+
+
+def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, restrict_to_ctx=True,
+                  use_disocc=False):
+    """``LVD.forward(mode="decode_output")`` (lvd.py:141-153): flow / alpha synthesis, frame warp and
+    temporal fusion, the ``use_disocc`` concatenation (lvd.py:148-151) and the split of the score
+    channel.  Returns ``(output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx)``."""
+    fn = warper.grid_to_flow_ctx if restrict_to_ctx else warper.grid_to_flow
+    flow, alpha_unflt, alpha, alpha_ctx, disocc = fn(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+    output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
+    raw_alpha = output[:, :, -1:]
+    if use_disocc:
+        if warper.include_self:
+            disocc = torch.cat([disocc, torch.ones_like(disocc[:, :1])], dim=1)
+        raw_output = torch.cat([raw_output, disocc], dim=3)
+    return output[:, :, :-1], flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx
