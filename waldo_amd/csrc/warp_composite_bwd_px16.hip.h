@@ -190,37 +190,34 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   float a[LP], G[LP];
 
   // ---- (E) staged sampling with derivatives.  Wave w moves channel plane w of a layer's box,
-  // 16 bytes per lane; the loads of a group of layers are issued back to back; the image is
-  // double-buffered, one barrier per layer.
-  constexpr int kGroup = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
+  // 16 bytes per lane; a rolling window of kAhead layers is in flight (the load of layer l + kAhead
+  // is issued when layer l leaves its registers for LDS); the image is double-buffered, one
+  // barrier per layer.
+  constexpr int kAhead = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
   constexpr int kItems = kStageCap / 4 / kWave;
+  f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
+  auto issue = [&](int l) {
+    const int lc = EXL ? l : min(l, L - 1);
+    const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
+    // unconditional loads (items past the box re-read its last item; a box that does not fit
+    // reads texel 0): no exec-mask branches, so the loads are issued back to back
+    const int bw4 = bw[l] >> 2, n = fits[l] ? bh[l] * bw4 : 1;
+    const int ox = fits[l] ? __mul24(by0[l], W) + bx0[l] : 0;
+    const float rcp = 1.0f / (float)bw4;
 #pragma unroll
-  for (int q0 = 0; q0 < LP; q0 += kGroup) {
-    f32x4 stg[kGroup][kItems];
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const int l = q0 + q;
-      if (l >= LP) continue;
-      const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
-      // unconditional loads (items past the box re-read its last item; a box that does not fit
-      // reads texel 0): no exec-mask branches, so the whole group's loads are issued back to back
-      const int bw4 = bw[l] >> 2, n = fits[l] ? bh[l] * bw4 : 1;
-      const int ox = fits[l] ? __mul24(by0[l], W) + bx0[l] : 0;
-      const float rcp = 1.0f / (float)bw4;
-#pragma unroll
-      for (int j = 0; j < kItems; ++j) {
-        const int item = min(lane + j * kWave, n - 1);
-        const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
-        const int xg = item - r * bw4;
-        const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-        stg[q][j] = *reinterpret_cast<const f32x4*>(src + off);
-      }
+    for (int j = 0; j < kItems; ++j) {
+      const int item = min(lane + j * kWave, n - 1);
+      const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
+      const int xg = item - r * bw4;
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
+      stg[l][j] = *reinterpret_cast<const f32x4*>(src + off);
     }
+  };
 #pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const int l = q0 + q;
-      if (l >= LP) continue;
+  for (int l = 0; l < kAhead; ++l) issue(l);
+  {
+#pragma unroll
+    for (int l = 0; l < LP; ++l) {
       if (!EXL && l >= L) {  // padding layer: inert
         a[l] = 0.0f;
         G[l] = 0.0f;
@@ -234,9 +231,10 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
 #pragma unroll
         for (int j = 0; j < kItems; ++j) {
           const int item = lane + j * kWave;
-          if (item < n) dst[item] = stg[q][j];  // row-major with pitch bw: item = r * bw4 + xg
+          if (item < n) dst[item] = stg[l][j];  // row-major with pitch bw: item = r * bw4 + xg
         }
       }
+      if (l + kAhead < LP) issue(l + kAhead);
       __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
       const TapCore tc = tap_core(gxs[l], gys[l], H, W);
       const float* b0 = img + (l & 1) * 4 * kStageCap;

@@ -205,41 +205,37 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_
       bh[l] = ymax - ymin + 1;
     }
 
-    // ---- (E) staging: wave w moves channel plane w of a layer's box, 16 bytes per lane.  The
-    // loads of a whole group of layers are issued back to back (memory latency is paid once per
-    // group, with kGroup boxes in flight per workgroup), then each layer goes registers -> LDS ->
-    // taps; the image is double-buffered, one barrier per layer.
-    constexpr int kGroup = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
+    // ---- (E) staging: wave w moves channel plane w of a layer's box, 16 bytes per lane.  A
+    // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
+    // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
+    // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
+    constexpr int kAhead = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
     constexpr int kItems = kStageCap / 4 / kWave;
     float s[LP][4];
+    f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
+    auto issue = [&](int l) {
+      const int lc = EXL ? l : min(l, L - 1);
+      const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
+      // unconditional loads (items past the box re-read its last item; a box that does not fit
+      // reads texel 0): no exec-mask branches, so the loads are issued back to back
+      const bool fits = bh[l] * bw[l] <= kStageCap;
+      const int bw4 = bw[l] >> 2, n = fits ? bh[l] * bw4 : 1;
+      const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
+      const float rcp = 1.0f / (float)bw4;
 #pragma unroll
-    for (int g0 = 0; g0 < LP; g0 += kGroup) {
-      f32x4 stg[kGroup][kItems];
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        const int l = g0 + q;
-        if (l >= LP) continue;
-        const int lc = EXL ? l : min(l, L - 1);
-        const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
-        // unconditional loads (items past the box re-read its last item; a box that does not fit
-        // reads texel 0): no exec-mask branches, so the whole group's loads are issued back to back
-        const bool fits = bh[l] * bw[l] <= kStageCap;
-        const int bw4 = bw[l] >> 2, n = fits ? bh[l] * bw4 : 1;
-        const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
-        const float rcp = 1.0f / (float)bw4;
-#pragma unroll
-        for (int j = 0; j < kItems; ++j) {
-          const int item = min(lane + j * kWave, n - 1);
-          const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
-          const int xg = item - r * bw4;
-          const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-          stg[q][j] = *reinterpret_cast<const f32x4*>(src + off);
-        }
+      for (int j = 0; j < kItems; ++j) {
+        const int item = min(lane + j * kWave, n - 1);
+        const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
+        const int xg = item - r * bw4;
+        const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
+        stg[l][j] = *reinterpret_cast<const f32x4*>(src + off);
       }
+    };
 #pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        const int l = g0 + q;
-        if (l >= LP) continue;
+    for (int l = 0; l < kAhead; ++l) issue(l);
+    {
+#pragma unroll
+      for (int l = 0; l < LP; ++l) {
         if (!EXL && l >= L) {  // padding layer: inert
           s[l][0] = s[l][1] = s[l][2] = 0.0f;
           s[l][3] = -1.0f;
@@ -252,9 +248,10 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_
 #pragma unroll
           for (int j = 0; j < kItems; ++j) {
             const int item = lane + j * kWave;
-            if (item < n) dst[item] = stg[q][j];  // row-major with pitch bw: item = r * bw4 + xg
+            if (item < n) dst[item] = stg[l][j];  // row-major with pitch bw: item = r * bw4 + xg
           }
         }
+        if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
           const TapCore tc = tap_core(gx[l], gy[l], H, W);
