@@ -49,6 +49,22 @@ def synth(frames, nl, h, w, device, seed):
     return layers, pts, occ
 
 
+def copy_bandwidth(device, nbytes=1 << 30, reps=10):
+    """Measured device-to-device copy rate of this box (read + write bytes per second, GB/s): the
+    second denominator SURVEY 8(d) asks for next to the 8 TB/s spec figure."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(nl, h, w, frames, reps):
     """Oracle (kind "port") on the host cores: fwd+bwd frames/s on `frames` frames."""
     from oracle import wif_oracle as O
@@ -205,6 +221,9 @@ def main():
                 "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": measured_traffic(dom, frames, nl, h, w),
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": alg[dom],
                 "kernels": kern}
+        copy_gbs = copy_bandwidth(device)
+        roof["copy_GBps"] = round(copy_gbs, 1)  # measured D2D copy rate of this box (read + write)
+        roof["frac_of_copy"] = round(kern[dom]["GBps"] / copy_gbs, 4)
         out = {
             "metric": "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd" if args.mode == "train"
             else "warped+composited frames/sec, fwd only + all-gather (not the headline metric)",
