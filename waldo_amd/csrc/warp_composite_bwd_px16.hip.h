@@ -45,6 +45,17 @@ __device__ __forceinline__ BoxTaps make_box_taps(const TapCore& tc, int Hi, int 
   return p;
 }
 
+__device__ __forceinline__ int pk_max_u16(int a, int b) {
+  typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+  u2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  u2 r = __builtin_elementwise_max(x, y);
+  int o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+
 template <int LP, bool EXL, bool GOCC>
 __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   float* gg = lds;
   float* img = lds + kParkFloats;
   float* boxred = img + kStageFloats;
-  float* wbound = boxred + 4 * GGC * 2;  // [wave][layer]
+  int* wbound = reinterpret_cast<int*>(boxred + 4 * GGC * 2);  // [wave][layer pair]: packed exponents
   const int pix = threadIdx.x;
 
   const int col0 = (tile % ntx) * kLdsTile, row0 = (tile / ntx) * kLdsTile + wave * 4;
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   // derivatives, then overwrite the same LDS column with gg -- no other thread touches it).
   {
     float ggx[LP], ggy[LP];
+    int eb[LP];
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
       const bool pad = !EXL && l >= L;
@@ -368,15 +380,26 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
       const float dyr = lds[(4 * l + 2) * PP1 + pix], dya = lds[(4 * l + 3) * PP1 + pix];
       ggx[l] = fmaf(gsa, dxa, ap[l] * dxr) * (0.5f * (float)W);
       ggy[l] = fmaf(gsa, dya, ap[l] * dyr) * (0.5f * (float)H);
-      if (!pad) {
-        // |tap contribution| <= max(|a'_l| max_c |g_c|, |g_alpha|): bilinear weights are <= 1.  The
-        // table keeps the largest 16-pixel row sum of the cell
-        float bnd = group16_sum(live ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f);
-        bnd = fmaxf(bnd, __shfl_xor(bnd, 16, kWave));
-        bnd = fmaxf(bnd, __shfl_xor(bnd, 32, kWave));
-        if (lane == 0) wbound[wave * LP + l] = bnd;
-        if (live) rec_a[((int64_t)f * L + l) * HW + p] = make_float2(ap[l], gsa);
-      }
+      // |tap contribution| <= max(|a'_l| max_c |g_c|, |g_alpha|) < 2^(e - 126), e its biased
+      // exponent: bilinear weights are <= 1.  Only e goes into the bound (see below).
+      const float cb = (live && !pad) ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f;
+      eb[l] = (int)(__float_as_uint(cb) >> 23);  // cb >= 0: sign bit clear
+      if (live && !pad) rec_a[((int64_t)f * L + l) * HW + p] = make_float2(ap[l], gsa);
+    }
+    // the table's bound (an upper bound of any 16-pixel row sum of the cell): 16 * 2^(e_max - 126)
+    // with e_max the largest exponent in the cell -- one packed 16-bit max-reduction per two
+    // layers instead of a float row-sum reduction per layer; at most 2x looser (one bit of the
+    // splat's 29-bit fixed point)
+#pragma unroll
+    for (int j = 0; j < LP / 2; ++j) {
+      int v = eb[2 * j] | (eb[2 * j + 1] << 16);
+      v = pk_max_u16(v, row_ror_i<8>(v));
+      v = pk_max_u16(v, row_ror_i<4>(v));
+      v = pk_max_u16(v, row_ror_i<2>(v));
+      v = pk_max_u16(v, row_ror_i<1>(v));
+      v = pk_max_u16(v, __shfl_xor(v, 16, kWave));
+      v = pk_max_u16(v, __shfl_xor(v, 32, kWave));
+      if (lane == 0) wbound[wave * (LP / 2) + j] = v;
     }
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
@@ -390,9 +413,13 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   if (threadIdx.x < 2 * LP) {
     const int c = threadIdx.x / LP, l = threadIdx.x % LP;
     const int crow = (tile / ntx) * 2 + c;
-    if (l < L && crow * ncx < ncells)
+    if (l < L && crow * ncx < ncells) {
+      const int v = pk_max_u16(wbound[(2 * c) * (LP / 2) + l / 2], wbound[(2 * c + 1) * (LP / 2) + l / 2]);
+      const int e = (l & 1) ? (v >> 16) & 0xffff : v & 0xffff;
+      // 16 * 2^(e - 126) as float bits; nothing but zeros / denormals in the cell: 0
       cellbound[((int64_t)f * L + l) * ncells + crow * ncx + (tile % ntx)] =
-          __float_as_uint(fmaxf(wbound[(2 * c) * LP + l], wbound[(2 * c + 1) * LP + l]));
+          e == 0 ? 0u : (unsigned)min(e + 5, 254) << 23;
+    }
   }
 
   // ---- (H) control-point gradient: basis^T x gg on the MFMA pipe
