@@ -377,3 +377,25 @@ def test_warp_composite_full_size(dev, h, w, nl, smooth):
         plain, _, _ = O.reduce_comp(layers.unsqueeze(1), occ.unsqueeze(1))
         close(rgb_i, plain[:, 0], tol=2e-2, what="identity warp = plain composite")
         close(rgb_0, layers[:, 0, :3], tol=2e-2, what="transparent objects = layer 0")
+
+
+def test_graphed_forward_replay(dev):
+    """A captured HIP graph of the fused forward replays bit-identically on new input contents
+    (the library launches on the capturing stream and never synchronises)."""
+    from waldo_amd import functional as WF
+    from waldo_amd.graphs import GraphedCall
+    import waldo_amd
+    f, nl, h, w = 4, 8, 32, 64
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+
+    def fwd(layers, pts, occ):
+        return WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
+
+    a = [x.to(dev) for x in O.make_synthetic(f, nl, h, w, seed=1)[:3]]
+    b = [x.to(dev) for x in O.make_synthetic(f, nl, h, w, seed=2, sigma=0.2)[:3]]
+    g = GraphedCall(fwd, *a)
+    with torch.no_grad():
+        for inp in (a, b, a):
+            assert torch.equal(g(*inp), fwd(*inp))
+    with pytest.raises(ValueError):
+        g(a[0][:1], a[1], a[2])

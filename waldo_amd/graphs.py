@@ -1,0 +1,40 @@
+"""HIP-graph replay for launch-bound calls of the path (inference).
+
+At small shapes (BASELINE config C2: 8 frames of 128x128, L = 8) one forward of the fused path is
+two ~10 us kernels behind ~30 us of Python / ctypes / launch overhead.  The C-ABI library launches
+on whatever stream the caller passes and never synchronises, so a call sequence can be captured
+once into a HIP graph (``torch.cuda.CUDAGraph``, which is hipGraph on ROCm) and replayed with a
+single launch: 54.6 us -> 25.9 us per C2 forward on MI355X (tools_dev/bench_graph.py).
+"""
+import torch
+
+
+class GraphedCall:
+    """Captures ``fn(*inputs)`` (forward only, fixed shapes) and replays it.
+
+    ``inputs`` are copied into static buffers on every call; the returned tensors are the graph's
+    static outputs (clone them if they must survive the next call)."""
+
+    def __init__(self, fn, *example_inputs, warmup=3):
+        self._static = [x.clone() if torch.is_tensor(x) else x for x in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):  # allocator / lazy-init work must not happen during capture
+                fn(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph), torch.no_grad():
+            self._out = fn(*self._static)
+
+    def __call__(self, *inputs):
+        if len(inputs) != len(self._static):
+            raise ValueError(f"expected {len(self._static)} inputs, got {len(inputs)}")
+        for dst, src in zip(self._static, inputs):
+            if torch.is_tensor(dst):
+                if dst.shape != src.shape or dst.dtype != src.dtype:
+                    raise ValueError(f"graphed call was captured for {tuple(dst.shape)} {dst.dtype}, "
+                                     f"got {tuple(src.shape)} {src.dtype}")
+                dst.copy_(src)
+        self._graph.replay()
+        return self._out
