@@ -9,6 +9,7 @@ script is the provenance.  InverseWarp vectors are produced with ``Tensor.sort``
 (see ``ref_import.stable_sort``): the reference's own tie-break is implementation-defined.
 """
 import os
+import types
 import sys
 import warnings
 
@@ -183,6 +184,83 @@ def gen_warper(ns):
     save("wif_forward", vid=vid, weight=lin.weight, bias=lin.bias, out=y)
 
 
+def inpaint_opt(**over):
+    d = dict(ii_score=True, ii_ab=True, use_inpainter=True, ii_last_only=False, fix_thresh=True,
+             use_expansion=True, num_expansion=2, loop_ii=True, inpaint_obj=True, propagate_unique=True,
+             use_shadows=True, soft_shadow=False, fix_mask=False, propagate_obj=True)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+INPAINT_CASES = {
+    "a": dict(),
+    "b": dict(fix_mask=True, soft_shadow=True, propagate_obj=False, ii_last_only=True, fix_thresh=False,
+              use_expansion=False),
+    "c": dict(loop_ii=False, inpaint_obj=False),
+    "d": dict(loop_ii=False, inpaint_obj=True, use_expansion=False),
+}
+
+
+def inpaint_inputs(ns_get_grid, seed=9):
+    """Synthetic but structured inputs of WIF.inpaint: smooth frames, blobby alphas (so that the
+    thresholded masks have regions), one object touching the left image border."""
+    g = torch.Generator().manual_seed(seed)
+    b, ctx_len, tp, no, nl = 1, 2, 2, 2, 3
+    t = ctx_len + tp
+    hd, wd = 32, 64
+
+    def smooth(*shape, lo=4):
+        x = torch.randn(*shape[:-2], shape[-2] // lo, shape[-1] // lo, generator=g)
+        lead = x.shape[:-3]
+        y = torch.nn.functional.interpolate(x.reshape(-1, *x.shape[-3:]), size=shape[-2:], mode="bilinear")
+        return y.reshape(*lead, *y.shape[-3:])
+
+    nlay = no + 1
+    c = 3 + nl + nlay
+    obj_pose = ns_get_grid(2, 2).view(1, 1, 1, 4, 2) * 0.5 + 0.1 * torch.randn(b, t, no, 4, 2, generator=g)
+    bg_pose = ns_get_grid(2, 4).view(1, 1, 1, 8, 2) + 0.04 * torch.randn(b, t, 1, 8, 2, generator=g)
+    raw_output = smooth(b, ctx_len, tp, c, hd, wd)
+    real_vid = smooth(b, t, 3, hd, wd).clamp(-1, 1)
+    alpha = (2.5 * smooth(b, ctx_len, nlay, hd, wd)).tanh()
+    alpha[:, :, 0] = alpha[:, :, 0] * 0.3 + 0.7                      # background mostly visible
+    alpha_ctx = (2.5 * smooth(b, ctx_len, tp, nlay, hd, wd)).tanh() * 0.5 - 0.45
+    alpha_ctx[:, :, :, 0] = (2.0 * smooth(b, ctx_len, tp, hd, wd) + 0.5).tanh()
+    alpha_ctx[:, :, -1, 1, 8:20, 0:5] = 0.95                          # an object at the left border
+    pred_flow = 0.05 * smooth(b, ctx_len, tp, 2, hd, wd)
+    pred_flow[:, -1, -1, 0, 8:20, 0:5] = -0.1                         # ... moving out of the frame
+    return dict(obj_pose=obj_pose, bg_pose=bg_pose, raw_output=raw_output, real_vid=real_vid, alpha=alpha,
+                alpha_ctx=alpha_ctx, pred_flow=pred_flow, ctx_len=ctx_len, channels=c)
+
+
+def gen_inpaint(ns):
+    """WIF.inpaint (wif.py:58-226) with a 1x1-conv UNet stand-in and the deterministic stub
+    inpainter of oracle/inpaint_oracle.py, for four option sets."""
+    from oracle.inpaint_oracle import stub_inpainter
+    d = inpaint_inputs(ns.get_grid)
+    wopt = R.warper_opt(num_obj=2)
+    warper = ns.Warper(wopt)
+    with R.stable_sort():
+        grid = warper(d["obj_pose"], d["bg_pose"])
+    g = torch.Generator().manual_seed(10)
+    lin = torch.nn.Conv2d(d["channels"], 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.3)
+        lin.bias.copy_(torch.randn(5, generator=g) * 0.1)
+    save("wif_inpaint_inputs", tgo=grid[0], sgo=grid[1], tgb=grid[2], sgb=grid[3], weight=lin.weight,
+         bias=lin.bias, **{k: v for k, v in d.items() if torch.is_tensor(v)})
+    for tag, over in INPAINT_CASES.items():
+        opt = inpaint_opt(**over)
+        wif = ns.WIF.__new__(ns.WIF)
+        torch.nn.Module.__init__(wif)
+        wif.score, wif.ab, wif.opt, wif.unet = True, True, opt, lin
+        wif.src_grid_hd = ns.get_grid(32, 64)
+        wif.inpainter = stub_inpainter  # the non-loop branch calls an attribute the class never sets
+        with torch.no_grad():
+            out = wif.inpaint(stub_inpainter, d["raw_output"].clone(), d["alpha"], d["alpha_ctx"], d["real_vid"],
+                              d["pred_flow"], d["ctx_len"], warper, grid)
+        save(f"wif_inpaint_{tag}", out=out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
@@ -192,6 +270,7 @@ def main():
     gen_warp_composite(ns)
     gen_inverse_warp(ns)
     gen_warper(ns)
+    gen_inpaint(ns)
 
 
 if __name__ == "__main__":

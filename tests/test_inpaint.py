@@ -1,0 +1,93 @@
+"""Row f3: WIF.inpaint (models/nets/wif.py:58-226) -- the oracle against the reference's own outputs
+(golden, CPU) and the HIP-backed mirror against both (GPU).  The method is a cascade of thresholded
+masks: an fp32 rounding difference can flip a mask pixel and with it the pixel's whole value, so
+besides the 1e-4 bound a small fraction of flipped pixels is tolerated and reported."""
+import types
+
+import pytest
+import torch
+
+from oracle import inpaint_oracle as IO
+from oracle import warper_oracle as WO
+from oracle.make_golden import INPAINT_CASES, inpaint_opt
+
+CTX_LEN = 2
+
+
+def warper_opt(**over):
+    d = dict(latent_shape=[2, 4], obj_shape=[2, 2], time_dropout=False, num_obj=2, patch_size=4,
+             scale_factor=1, dim=16, aspect_ratio=2, load_dim=32, num_perm_grid=1,
+             normalize_alpha=False, use_lyt_filtering=False, use_lyt_opacity=False,
+             weight_cls=False, min_cls=0.0, include_self=False, no_filter=False, allow_ghost=False)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+def flipped_fraction(a, b, tol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape
+    return ((a - b).abs() > tol).double().mean().item()
+
+
+def make_forward(g, dev="cpu"):
+    w, bias = g["weight"].to(dev), g["bias"].to(dev)
+
+    def forward(vid):  # WIF.forward with the 1x1-conv UNet stand-in of the golden (wif.py:37-57)
+        b, tc, t, c, h, ww = vid.shape
+        v = vid.permute(0, 2, 1, 3, 4, 5)
+        net = torch.nn.functional.conv2d(v.reshape(b * t * tc, c, h, ww), w, bias).reshape(b, t, tc, -1, h, ww)
+        return WO.wif_fuse(v, net, ab=True)
+    return forward
+
+
+@pytest.mark.parametrize("tag", sorted(INPAINT_CASES))
+def test_inpaint_oracle_vs_reference(golden, tag):
+    g = golden("wif_inpaint_inputs")
+    ref = golden(f"wif_inpaint_{tag}")["out"]
+    cfg = WO.WarperCfg.from_opt(warper_opt())
+    grid = (g["tgo"], g["sgo"], g["tgb"], g["sgb"])
+    out = IO.wif_inpaint(inpaint_opt(**INPAINT_CASES[tag]), cfg, make_forward(g), IO.stub_inpainter,
+                         g["raw_output"].clone(), g["alpha"], g["alpha_ctx"], g["real_vid"], g["pred_flow"],
+                         CTX_LEN, grid)
+    assert flipped_fraction(out, ref) == 0.0, (tag, (out - ref).abs().max().item())
+
+
+def test_expand_matches_box_dilation():
+    """A hard round of (south, north, east, west) is a 3x3 box dilation; soft rounds decay by alpha."""
+    torch.manual_seed(0)
+    m = (torch.rand(2, 1, 9, 11) > 0.85).float()
+    box = torch.nn.functional.max_pool2d(m, 3, 1, 1)
+    assert torch.equal(IO.expand(m, 1), box)
+    assert torch.equal(IO.expand(m, 2), torch.nn.functional.max_pool2d(box, 3, 1, 1))
+    assert torch.equal(IO.expand(m, 1, dir="east")[:, :, :, 1:], torch.maximum(m[:, :, :, 1:], m[:, :, :, :-1]))
+    s = IO.expand(m, 3, soft=True, alpha=0.5)
+    assert (s >= m).all() and s.max() <= 1 and ((s > 0) == (IO.expand(m, 3) > 0)).all()
+    from waldo_amd.tools.utils import expand
+    for kw in (dict(num=2), dict(num=3, soft=True), dict(num=1, dir="north")):
+        assert torch.equal(expand(m, **kw), IO.expand(m, **kw))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(INPAINT_CASES))
+def test_inpaint_hip_vs_oracle_and_reference(dev, golden, tag):
+    from waldo_amd.nets import WIF, Warper
+    g = golden("wif_inpaint_inputs")
+    ref = golden(f"wif_inpaint_{tag}")["out"]
+    opt = inpaint_opt(**INPAINT_CASES[tag])
+    wopt = warper_opt()
+    for k, v in vars(wopt).items():
+        setattr(opt, k, v)
+    lin = torch.nn.Conv2d(g["weight"].shape[1], 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(g["weight"])
+        lin.bias.copy_(g["bias"])
+    wif = WIF(opt, unet=lin).to(dev)
+    warper = Warper(wopt).to(dev)
+    d = {k: v.to(dev) for k, v in g.items()}
+    grid = [d["tgo"], d["sgo"], d["tgb"], d["sgb"]]
+    with torch.no_grad():
+        out = wif.inpaint(IO.stub_inpainter, d["raw_output"].clone(), d["alpha"], d["alpha_ctx"], d["real_vid"],
+                          d["pred_flow"], CTX_LEN, warper, grid)
+    assert out.shape == ref.shape
+    frac = flipped_fraction(out, ref)
+    assert frac <= 2e-3, f"{tag}: {frac:.2e} of the values differ from the reference by more than 1e-4"
