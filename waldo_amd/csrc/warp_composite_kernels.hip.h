@@ -301,17 +301,19 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 // ---------------------------------------------------------------------------------------
 // two-kernel backward (K3 == 19, L <= 8)
 //
-//   K1  warp_composite_bwd_px_kernel    pixel-major, 4x64-pixel tiles, all layers of a pixel in one
-//       thread: re-sample with derivatives, composite backward, control-point gradient as an f32
-//       MFMA contraction basis^T x grid-grad (per-tile partial, summed by a tiny second kernel),
-//       and per (pixel, layer) a 16-byte RECORD (a'_l, d loss/d s_l3, grid x, grid y) that is all
-//       the splat needs; it also maintains, per (frame, layer, 32x64 splat tile), the bounding box
-//       of the source texels the tile's bilinear footprints touch (packed 16-bit wave min/max,
-//       then integer global atomics).
-//   K2  warp_composite_splat_kernel (warp_composite_splat.hip)   layer-plane-major, 32x64-pixel
-//       tiles: scatter-add of the tile's tap contributions into a FIXED-POINT LDS image of the
-//       bounding box, flushed with PLAIN stores where no other tile's box covers the texel and
-//       float atomics only on the shared rims.
+//   K1  pixel-major, all layers of a pixel in one thread: re-sample with derivatives, composite
+//       backward, control-point gradient as an f32 MFMA contraction basis^T x grid-grad (per-tile
+//       partial, summed by a tiny second kernel), and per (pixel, layer) two 8-byte RECORDS
+//       (grid x, grid y) / (a'_l, d loss / d s_l3) that are all the splat needs, plus a footprint
+//       table per 8x16-pixel CELL: the bounding box of the source texels the cell's bilinear
+//       footprints touch and an upper bound of its contribution magnitudes.  Two variants:
+//       warp_composite_bwd_px16_kernel (warp_composite_bwd_px16.hip.h; 16x16 tiles, samples from an
+//       LDS image of each layer's footprint box, owns its cells) when 4 | W, else
+//       warp_composite_bwd_px_kernel below (4x64 tiles, per-tap gathers, cell table by atomics).
+//   K2  warp_composite_splat_kernel (warp_composite_splat.hip): one workgroup OWNS a 32x64-texel
+//       tile of one layer's gradient plane, visits the cells whose box reaches it, re-derives the
+//       taps from the records and sums them in a FIXED-POINT LDS image; plain stores, no global
+//       atomics, no zero fill, bitwise reproducible.
 //
 // Hardware facts this is built around (measured on MI355X, tools_dev/*.hip):
 //   * ds_add_f32 (LDS float atomic) retires ~3 cycles PER LANE (195 cycles per wave-instruction);
@@ -320,10 +322,9 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 //     so that no texel can overflow; integer sums are order-independent (bitwise reproducible).
 //   * thousands of waves adding floats to the same few hundred addresses run ~14x below the
 //     streaming atomic rate: the control-point gradient uses per-tile partials + a reduce.
-//   * an 8-row tile shares ~70% of its bounding box with its vertical neighbours (skew of the
-//     warp over 64 columns + the 1-texel bilinear overlap), and shared texels need atomics; the
-//     splat therefore runs on taller tiles than the register-heavy pixel kernel can afford,
-//     which is what the records buy.
+//   * a pixel tile shares most of its footprint box with its neighbours (skew of the warp + the
+//     1-texel bilinear overlap), and shared texels would need atomics; the scatter is therefore
+//     organised by SOURCE tile (exclusive ownership), which is what the records buy.
 // ---------------------------------------------------------------------------------------
 #ifndef WALDO_PX_WAVES
 #define WALDO_PX_WAVES 4
@@ -519,12 +520,8 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
       const int ya = t.vy0 > 0.0f ? t.y0 : t.y0 + 1, yb = t.vy1 > 0.0f ? t.y0 + 1 : t.y0;
       int lo = has ? (int)(((unsigned)ya << 16) | ((unsigned)xa & 0xffffu)) : 0x7fff7fff;
       int hi = has ? (int)(((unsigned)(-yb) << 16) | ((unsigned)(-xb) & 0xffffu)) : 0x7fff7fff;
-#ifndef ABL_K1_NOBOX
       lo = group16_pk_min(lo);
       hi = group16_pk_min(hi);
-#else
-      asm volatile("" : "+v"(lo), "+v"(hi));
-#endif
       if (leader && lo != 0x7fff7fff) {
         int* bb = cellbox + (((int64_t)f * L + l) * ncells + cell) * 4;
         atomicMin(bb + 0, (int)(short)(lo & 0xffff));   // x min
@@ -609,7 +606,6 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
   // [kk=lane>>4], B[kk=lane>>4][col=lane&15], D[row=(lane>>4)*4+reg][col=lane&15].  Each wave
   // contracts the pixels it produced; the 8 wave results are summed through LDS in a fixed order
   // and stored as this tile's partial (no atomics, deterministic).
-#ifndef ABL_K1_NOMFMA
   if (gmap_partial != nullptr) {
     f32x4 acc[2][NT];
 #pragma unroll
@@ -659,7 +655,6 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
                      (col & 1)] = sum;
     }
   }
-#endif
 }
 
 // second stage of the control-point gradient: grad_mapping[f,l,k,c] += sum_tile partial
