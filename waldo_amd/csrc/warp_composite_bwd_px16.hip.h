@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
-    float2* __restrict__ rec_g, float2* __restrict__ rec_a, int* __restrict__ cellbox,
+    float4* __restrict__ rec, int* __restrict__ cellbox,
     unsigned* __restrict__ cellbound, float* __restrict__ gmap_partial, float* __restrict__ grad_occ,
     int F, int Lrt, int H, int W, int ntx, int ntiles, int ncx, int ncells) {
   static_assert(LP <= 8 && (LP % 2) == 0, "one 16-column MFMA tile of (layer, xy) columns");
@@ -299,8 +299,6 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
       lds[(4 * l + 3) * PP1 + pix] = sy[3];
       if (grad_alpha != nullptr)
         G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + l) * HW + p], G[l]);
-      // the grid point is final: half of the record goes out now
-      if (live) rec_g[((int64_t)f * L + l) * HW + p] = make_float2(gxs[l], gys[l]);
     }
   }
 
@@ -384,7 +382,7 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
       // exponent: bilinear weights are <= 1.  Only e goes into the bound (see below).
       const float cb = (live && !pad) ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f;
       eb[l] = (int)(__float_as_uint(cb) >> 23);  // cb >= 0: sign bit clear
-      if (live && !pad) rec_a[((int64_t)f * L + l) * HW + p] = make_float2(ap[l], gsa);
+      if (live && !pad) rec[((int64_t)f * L + l) * HW + p] = make_float4(gxs[l], gys[l], ap[l], gsa);
     }
     // the table's bound (an upper bound of any 16-pixel row sum of the cell): 16 * 2^(e_max - 126)
     // with e_max the largest exponent in the cell -- one packed 16-bit max-reduction per two

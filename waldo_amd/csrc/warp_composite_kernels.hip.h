@@ -384,8 +384,7 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
-    float2* __restrict__ rec_g, float2* __restrict__ rec_a, int* __restrict__ cellbox,
-    unsigned* __restrict__ cellbound,
+    float4* __restrict__ rec, int* __restrict__ cellbox, unsigned* __restrict__ cellbound,
     float* __restrict__ gmap_partial, float* __restrict__ grad_occ, int F, int Lrt, int H, int W,
     int ntx, int ntiles, int ncx, int ncells) {
   constexpr int K3 = kGmapK3;
@@ -501,8 +500,6 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
     lds[(4 * l + 1) * PP1 + pix] = sx[3];
     lds[(4 * l + 2) * PP1 + pix] = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
     lds[(4 * l + 3) * PP1 + pix] = sy[3];
-    // the grid point is final: half of the record goes out now, its registers are free afterwards
-    if (pm.live && !pad) rec_g[((int64_t)f * L + l) * HW + p] = make_float2(gxs[l], gys[l]);
     if (grad_alpha != nullptr && !pad)
       G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + lc) * HW + p], G[l]);
     // a wave can have 63 vector-memory operations outstanding: issue the 16 tap loads of
@@ -589,7 +586,7 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
       const float bnd = group16_sum(pm.live ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f);
       if (leader && prow < H && pcol < W)
         atomicMax(cellbound + ((int64_t)f * L + l) * ncells + cell, __float_as_uint(bnd));
-      if (pm.live) rec_a[((int64_t)f * L + l) * HW + p] = make_float2(ap[l], gsa);
+      if (pm.live) rec[((int64_t)f * L + l) * HW + p] = make_float4(gxs[l], gys[l], ap[l], gsa);
     }
   }
 #pragma unroll
@@ -680,7 +677,7 @@ static __global__ __launch_bounds__(kBlock) void warp_composite_gmap_reduce_kern
 }
 
 // K2 (compiled once, warp_composite_splat.hip)
-void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb, const int* cellbox,
+void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st);
 
@@ -771,8 +768,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   char* ws = reinterpret_cast<char*>(workspace);
   int* boxes = reinterpret_cast<int*>(ws);
   unsigned* bounds = reinterpret_cast<unsigned*>(ws + lo.box_bytes);
-  float2* rec_g = reinterpret_cast<float2*>(ws + lo.box_bytes + lo.bound_bytes);
-  float2* rec_a = reinterpret_cast<float2*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes / 2);
+  float4* rec = reinterpret_cast<float4*>(ws + lo.box_bytes + lo.bound_bytes);
   float* part = grad_mapping == nullptr
                     ? nullptr
                     : reinterpret_cast<float*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes);
@@ -788,7 +784,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     auto go = [&](auto exl, auto gocc) {
       constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
       hipLaunchKernelGGL((warp_composite_bwd_px16_kernel<LP, EXL, GOCC>), grid, dim3(kBlock), 0, st, layers,
-                         basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
+                         basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
                          grad_occ, F, L, H, W, lo.ntx16, ntiles, lo.ncx, lo.ncells);
     };
     if (L == LP) {
@@ -806,7 +802,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     auto go = [&](auto exl, auto gocc) {
       constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
       hipLaunchKernelGGL((warp_composite_bwd_px_kernel<LP, EXL, GOCC>), grid, dim3(kPxThreads), 0, st,
-                         layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec_g, rec_a, boxes, bounds, part,
+                         layers, basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
                          grad_occ, F, L, H, W, lo.ntx, ntiles, lo.ncx, lo.ncells);
     };
     if (L == LP) {
@@ -820,7 +816,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, st, part, grad_mapping, F, L, ntiles);
   }
-  launch_splat(reinterpret_cast<const float*>(rec_g), reinterpret_cast<const float*>(rec_a), grad_rgb,
+  launch_splat(reinterpret_cast<const float*>(rec), grad_rgb,
                boxes, bounds, grad_layers, F, L, H, W, st);
 }
 

@@ -17,7 +17,8 @@ constexpr int kStageCap = 512;                 // texels per channel plane of a 
 inline int64_t round256(int64_t b) { return ((b + 255) / 256) * 256; }
 __host__ __device__ constexpr int64_t gmap_partial_floats(int L) { return (int64_t)L * kGmapK3 * 2; }
 
-// ---- two-kernel backward: [cell boxes | cell bounds | records (grid) | records (alpha) | partials]
+// ---- two-kernel backward: [cell boxes | cell bounds | records (grid x, grid y, a', g_alpha: 16 B) |
+//                           partials]
 // The pixel kernel runs on 4 x 64 tiles (gather variant) or 16 x 16 tiles (LDS-staged variant,
 // 4 | W); the control-point partials are sized for whichever has more tiles.
 struct Bwd2Layout {

@@ -3,7 +3,7 @@
 // Restates the input-gradient of F.grid_sample (bilinear, zeros, align_corners=False) -- the
 // four-corner scatter of grad * weight that the reference gets from autograd through
 // models/nets/lvd.py:548,559 -- for the records the pixel kernel (K1) left behind:
-//   records (grid x, grid y) and (a'_l, g_alpha) per (frame, layer, pixel); the contribution of pixel p
+//   records (grid x, grid y, a'_l, g_alpha) per (frame, layer, pixel); the contribution of pixel p
 //   to channel c < 3 of layer l is a'_l * grad_rgb[c][p], to the alpha channel g_alpha.
 //
 // One workgroup OWNS one 32x64-texel tile S of one layer's gradient plane: it is the only writer
@@ -82,8 +82,7 @@ __device__ __forceinline__ bool touches(const TapCore& t, int sx0, int sy0) {
 }
 
 __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
-    const float2* __restrict__ rec_g, const float2* __restrict__ rec_a,
-    const float* __restrict__ grad_rgb,
+    const float4* __restrict__ rec, const float* __restrict__ grad_rgb,
     const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
     float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int ncx,
     int ncells) {
@@ -152,8 +151,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const float scale = __uint_as_float((unsigned)(127 + es) << 23);
   const float inv_scale = __uint_as_float((unsigned)(127 - es) << 23);
   const float* gplane = grad_rgb + f * 3 * HW;
-  const float2* rgp = rec_g + fl * HW;
-  const float2* rap = rec_a + fl * HW;
+  const float4* rcp = rec + fl * HW;
 
   if (bsum > 0.0f) {
     if (nhit <= kMaxHit) {
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       struct Cand {
         unsigned p;
         bool livep;
-        float2 rg, ra;
+        float4 rc;  // (grid x, grid y, a', g_alpha)
         float g0, g1, g2;
       };
       auto fetch = [&](int i, Cand& k) {
@@ -178,14 +176,13 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         k.livep = i < total && py < H && px < W;
         k.p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
         // 32-bit byte offsets from uniform bases (HW * 8 < 2^32 is implied by the launcher's check)
-        k.rg = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rgp) + k.p * 8u);
-        k.ra = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rap) + k.p * 8u);
+        k.rc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(rcp) + k.p * 16u);
         k.g0 = ldb(gplane, k.p * 4u);
         k.g1 = ldb(gplane + HW, k.p * 4u);
         k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
       };
       auto splat = [&](const Cand& k) {
-        const TapCore tc = tap_core(k.rg.x, k.rg.y, H, W);
+        const TapCore tc = tap_core(k.rc.x, k.rc.y, H, W);
         const bool any = k.livep && touches(tc, sx0, sy0);
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
         if (__ballot(any) != 0ull) {
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           } else {
             t = finish_taps(tc, H, W);
           }
-          splat_pixel(img, lane, any, t, make_float4(k.ra.x, k.ra.y, k.rg.x, k.rg.y), k.g0, k.g1, k.g2,
+          splat_pixel(img, lane, any, t, make_float4(k.rc.z, k.rc.w, k.rc.x, k.rc.y), k.g0, k.g1, k.g2,
                       scale, sx0, sy0);
         }
       };
@@ -227,8 +224,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         const int px = (c % ncx) * kCellCols + (threadIdx.x & 15);
         if (py < H && px < W) {
           const unsigned p = (unsigned)(__mul24(py, W) + px);
-          const float2 rg = rgp[p], ra = rap[p];
-          const float4 rec = make_float4(ra.x, ra.y, rg.x, rg.y);
+          const float4 rc = rcp[p];
+          const float4 rec = make_float4(rc.z, rc.w, rc.x, rc.y);
           const Taps t = make_taps(rec.z, rec.w, H, W);
           splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
                       scale, sx0, sy0);
@@ -250,14 +247,14 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   }
 }
 
-void launch_splat(const float* rec_g, const float* rec_a, const float* grad_rgb, const int* cellbox,
+void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
   const int ncx = (W + kCellCols - 1) / kCellCols, ncy = (H + kCellRows - 1) / kCellRows;
   dim3 grid((unsigned)xcd_grid(F, (int64_t)L * nsx * nsy));
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
-                     reinterpret_cast<const float2*>(rec_g), reinterpret_cast<const float2*>(rec_a),
+                     reinterpret_cast<const float4*>(rec),
                      grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
                      ncx * ncy);
 }
