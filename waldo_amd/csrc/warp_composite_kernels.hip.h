@@ -303,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 //
 //   K1  pixel-major, all layers of a pixel in one thread: re-sample with derivatives, composite
 //       backward, control-point gradient as an f32 MFMA contraction basis^T x grid-grad (per-tile
-//       partial, summed by a tiny second kernel), and per (pixel, layer) two 8-byte RECORDS
-//       (grid x, grid y) / (a'_l, d loss / d s_l3) that are all the splat needs, plus a footprint
+//       partial, summed by a tiny second kernel), and per (pixel, layer) one 16-byte RECORD
+//       (grid x, grid y, a'_l, d loss / d s_l3) that is all the splat needs, plus a footprint
 //       table per 8x16-pixel CELL: the bounding box of the source texels the cell's bilinear
 //       footprints touch and an upper bound of its contribution magnitudes.  Two variants:
 //       warp_composite_bwd_px16_kernel (warp_composite_bwd_px16.hip.h; 16x16 tiles, samples from an
