@@ -379,6 +379,36 @@ def test_warp_composite_full_size(dev, h, w, nl, smooth):
         close(rgb_0, layers[:, 0, :3], tol=2e-2, what="transparent objects = layer 0")
 
 
+def test_backward_reproducible_and_linear(dev):
+    """Size-independent properties at the benchmark shape (256x512, L = 8, 16 frames): the layer and
+    control-point gradients are BITWISE identical from run to run (no float atomics on that path:
+    source-tile ownership, fixed-point LDS sums, fixed-order partial reduction), and the backward is
+    linear in the incoming gradient (2x the loss => 2x every gradient, exactly: the fixed-point scale
+    is a power of two that follows the bound)."""
+    from waldo_amd import functional as WF
+    import waldo_amd
+    f, nl, h, w = 16, 8, 256, 512
+    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=5)
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+    od = occ.to(dev)
+    torch.manual_seed(3)
+    wgt = torch.randn(f, 3, h, w, device=dev)
+
+    def grads(scale):
+        ld, pd = layers.to(dev).requires_grad_(), pts.to(dev).requires_grad_()
+        rgb = WF.warp_composite(ld, pd, od, tps.inverse_kernel, tps.basis_t)
+        (rgb * wgt).sum().mul(scale).backward()
+        return rgb.detach(), ld.grad, pd.grad
+
+    r1, gl1, gp1 = grads(1.0)
+    r2, gl2, gp2 = grads(1.0)
+    assert torch.equal(r1, r2) and torch.equal(gl1, gl2) and torch.equal(gp1, gp2)
+    _, gl3, gp3 = grads(2.0)
+    assert torch.equal(gl3, 2 * gl1)
+    close(gp3, 2 * gp1, tol=1e-6, rel=True, what="grad_pts linear")
+    assert torch.isfinite(gl1).all() and gl1.abs().sum() > 0
+
+
 def test_graphed_forward_replay(dev):
     """A captured HIP graph of the fused forward replays bit-identically on new input contents
     (the library launches on the capturing stream and never synchronises)."""
