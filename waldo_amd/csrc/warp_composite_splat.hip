@@ -88,14 +88,16 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     int ncells) {
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  // a FRAME is pinned to one XCD and its L layer planes run back to back there: a plane's records
-  // (2 MB at 256x512) are read ~1.8 times by its source tiles and the frame's grad_rgb by all L
-  // planes -- from that XCD's L2, once from HBM
+  // a FRAME is pinned to one XCD, source-tile-major inside it: the L layer planes of one source
+  // tile run back to back.  Their candidate pixels are (nearly) the same neighbourhood of the
+  // frame, so its grad_rgb is read once from HBM instead of once per layer (it was 40 % of this
+  // kernel's FETCH_SIZE with layer-major order); the records of a plane are still read ~1.8
+  // times by neighbouring tiles, from L2.
   int fi, rest;
   if (!xcd_decode(blockIdx.x, F, L * nstiles, fi, rest)) return;
   const int64_t f = fi;
-  const int64_t fl = f * L + rest / nstiles;
-  const int stile = rest % nstiles;
+  const int64_t fl = f * L + rest % L;
+  const int stile = rest / L;
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
