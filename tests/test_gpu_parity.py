@@ -217,11 +217,14 @@ def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None
     l2 = layers.detach().to(dev).requires_grad_()
     p2 = pts.detach().to(dev).requires_grad_()
     o2 = occ.detach().to(dev).requires_grad_()
-    rgb, alpha = WF.warp_composite(l2, p2, o2, tps.inverse_kernel, tps.basis_t, return_alpha=True)
-    if loss == "weights":
-        ((rgb * w1.to(dev)).sum() + (alpha * w2.to(dev)).sum()).backward()
-    else:
-        rgb.square().mean().backward()
+    try:
+        rgb, alpha = WF.warp_composite(l2, p2, o2, tps.inverse_kernel, tps.basis_t, return_alpha=True)
+        if loss == "weights":
+            ((rgb * w1.to(dev)).sum() + (alpha * w2.to(dev)).sum()).backward()
+        else:
+            rgb.square().mean().backward()
+    finally:
+        WF._FORCE_GENERIC_BWD = False  # the hook must not leak into other tests
     return rgb, alpha, l2.grad, p2.grad, o2.grad
 
 
@@ -407,6 +410,32 @@ def test_backward_reproducible_and_linear(dev):
     assert torch.equal(gl3, 2 * gl1)
     close(gp3, 2 * gp1, tol=1e-6, rel=True, what="grad_pts linear")
     assert torch.isfinite(gl1).all() and gl1.abs().sum() > 0
+
+
+def test_long_batches_go_in_pieces(dev, monkeypatch):
+    """More frames than one launch / one workspace takes: the wrapper splits along the (independent)
+    frames; outputs and gradients equal the single call bit for bit."""
+    from waldo_amd import functional as WF
+    import waldo_amd
+    f, nl, h, w = 7, 4, 16, 32
+    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=9)
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+
+    def run():
+        ld, pd = layers.to(dev).requires_grad_(), pts.to(dev).requires_grad_()
+        rgb, alpha = WF.warp_composite(ld, pd, occ.to(dev), tps.inverse_kernel, tps.basis_t, return_alpha=True)
+        (rgb.square().mean() + alpha.mean()).backward()
+        return rgb.detach(), alpha.detach(), ld.grad, pd.grad
+
+    whole = run()
+    monkeypatch.setattr(WF, "MAX_FL_PER_LAUNCH", 3 * nl)       # 3 frames per call
+    assert WF._frames_per_call(f, nl, h, w, 19) == 3
+    pieces = run()
+    for a, b in zip(whole, pieces):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(WF, "MAX_FL_PER_LAUNCH", 65535)
+    monkeypatch.setattr(WF, "MAX_WORKSPACE_BYTES", 2 * WF._lib.load().waldo_warp_composite_bwd_workspace_bytes(1, nl, h, w, 19))
+    assert 1 <= WF._frames_per_call(f, nl, h, w, 19) <= 3
 
 
 def test_graphed_forward_replay(dev):

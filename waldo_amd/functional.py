@@ -431,5 +431,30 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
     inverse_kernel (N+3, N+3); basis_t (N+3, H*W).  Returns rgb (F, 3, H, W) and, if asked,
     the composited alpha (F, L, H, W), both in [-1, 1]."""
     mapping = tps_mapping(inverse_kernel, src_pts)
-    rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha))
+    f, nl = layers.shape[:2]
+    chunk = _frames_per_call(f, nl, layers.shape[-2], layers.shape[-1], mapping.shape[1])
+    if f <= chunk:
+        rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha))
+    else:  # frames are independent: long batches go in pieces (launch limits, bounded workspace)
+        outs = [_WarpComposite.apply(layers[i:i + chunk], mapping[i * nl:(i + chunk) * nl], occ[i:i + chunk],
+                                     basis_t, bool(return_alpha)) for i in range(0, f, chunk)]
+        rgb = torch.cat([o[0] for o in outs])
+        alpha = torch.cat([o[1] for o in outs]) if return_alpha else None
     return (rgb, alpha) if return_alpha else rgb
+
+
+MAX_WORKSPACE_BYTES = 8 << 30   # backward workspace per call of the fused path
+MAX_FL_PER_LAUNCH = 65535       # F * L limit of one launch (include/waldo_hip.h)
+
+
+def _frames_per_call(f, nl, h, w, k3):
+    """Largest number of frames one call of the fused path may take."""
+    if f == 0:
+        return 1
+    per = max(1, MAX_FL_PER_LAUNCH // nl)
+    query = _lib.load().waldo_warp_composite_bwd_workspace_bytes
+    ws1, ws8 = query(1, nl, h, w, k3), query(8, nl, h, w, k3)
+    per_frame = max((ws8 - ws1) / 7.0, 1.0) if ws8 > 0 else 0.0
+    if per_frame:
+        per = min(per, max(1, int(MAX_WORKSPACE_BYTES // per_frame)))
+    return per
