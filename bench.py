@@ -231,7 +231,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"C3: {args.clips} clips x {args.frames_per_clip} frames per GPU, "
+            "config": {"workload": f"{'C3' if (nl, h, w, args.frames_per_clip) == (8, 256, 512, 14) else 'custom'}: "
+                                   f"{args.clips} clips x {args.frames_per_clip} frames per GPU, "
                                    f"{nl} layers x 4x{h}x{w}, 16 TPS control points, fwd+bwd",
                        "frames_per_gpu": frames, "layers": nl, "height": h, "width": w,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
