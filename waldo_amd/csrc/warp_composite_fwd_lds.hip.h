@@ -63,7 +63,7 @@ __device__ __forceinline__ int block_origin(float c, int size) {
 // hipcc 7.2 parks MFMA accumulator components in AGPRs and reads some of them back wrong
 // (tools_dev/dbg_fwd.py: columns 4k of tile rows 0 and 3, layers 8..15); spilling is correct.
 template <int LP, bool EXL>
-__global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : 2)) void warp_composite_fwd_lds_kernel(
+__global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int frames_per_block, int ntx,
