@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   // 16 bytes per lane; a rolling window of kAhead layers is in flight (the load of layer l + kAhead
   // is issued when layer l leaves its registers for LDS); the image is double-buffered, one
   // barrier per layer.
-  constexpr int kAhead = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
+  constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
   constexpr int kItems = kStageCap / 4 / kWave;
   f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
   auto issue = [&](int l) {

@@ -5,7 +5,7 @@
 //  * the plain kernel fetches every texel four times through the vector-memory path (each lane
 //    loads its own 2x2 taps, 4 bytes per lane).  Here a workgroup (16 x 16 pixels, four rows per
 //    wavefront -- square tiles: the warp's skew over a 64-pixel-wide tile makes its footprint box
-//    ~4x the tile, over 16 pixels ~1.9x) finds, per layer, the bounding box of the 2x2 blocks its
+//    ~4x the tile, over 16 pixels ~1.5x) finds, per layer, the bounding box of the 2x2 blocks its
 //    pixels read, streams that box ONCE from global memory with 16-byte-per-lane loads (wave w
 //    stages channel plane w) and takes the bilinear taps out of LDS (ds_read2_b32 pairs);
 //  * with sampling off the vector-memory path the kernel is VALU-issue bound (rocprofv3:
@@ -13,8 +13,8 @@
 //    v_mfma_f32_16x16x4_f32 chain per 16 pixels (N = (layer, xy) columns), and the boxes come from
 //    the min / max of the grid coordinates in the accumulator layout (a lane holds 16 pixels of
 //    one column) instead of per-layer cross-lane reductions of tap indices.
-// Layers are staged in groups (all loads of a group in flight together) and double-buffered in LDS
-// (one barrier per layer).  A box that does not fit the LDS image (violent warp) falls back to
+// A rolling window of layers is in flight (registers -> LDS -> taps), double-buffered in LDS (one
+// barrier per layer).  A box that does not fit the LDS image (violent warp) falls back to
 // gathering that layer straight from memory.
 //
 // Tap pairs: instead of clamping the four corners separately, a pixel reads the 2x2 block at
@@ -26,8 +26,8 @@
 
 namespace waldo {
 
-#ifndef WALDO_STAGE_GROUP
-#define WALDO_STAGE_GROUP 4  // layers whose box loads are in flight together
+#ifndef WALDO_STAGE_AHEAD
+#define WALDO_STAGE_AHEAD 4  // layers whose box loads are in flight at a time
 #endif
 
 struct PairTaps {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
     // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
     // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
     // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
-    constexpr int kAhead = LP < WALDO_STAGE_GROUP ? LP : WALDO_STAGE_GROUP;
+    constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
     constexpr int kItems = kStageCap / 4 / kWave;
     float s[LP][4];
     f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
