@@ -71,7 +71,14 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   constexpr int PP1 = kBlock + 1;
   constexpr int kParkFloats = (4 * LP > GGC ? 4 * LP : GGC) * PP1;
   constexpr int kImgFloats = 2 * 4 * kStageCap, kTFloats = 4 * kWave * TP;
-  constexpr int kStageFloats = kImgFloats > kTFloats ? kImgFloats : kTFloats;
+  // phase (H) transposes each wave's 64 x 20 basis values through LDS (pitch 21): three slices fit
+  // the staged-image region; the fourth goes behind the gg rows when the parked rows reach that far
+  // (LP == 8), else the region is sized for four
+  constexpr int BP = 21, kBtFloats = kWave * BP;
+  constexpr bool kBtInPark = 4 * LP * PP1 >= GGC * PP1 + kBtFloats;
+  constexpr int kBtStage = (kBtInPark ? 3 : 4) * kBtFloats;
+  constexpr int kStage0 = kImgFloats > kTFloats ? kImgFloats : kTFloats;
+  constexpr int kStageFloats = (kStage0 > kBtStage ? kStage0 : kBtStage + 3) / 4 * 4;
   static_assert(kParkFloats % 4 == 0 && kStageFloats % 4 == 0, "16-byte alignment");
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
@@ -426,22 +433,34 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   // contracts the pixels it produced; the 4 wave results are summed through LDS in a fixed order
   // and stored as this tile's partial (no atomics, deterministic).
   if (gmap_partial != nullptr) {
+    // (H1) the A operand wants basis[k][pixel] with k along lane & 15: read that way from memory,
+    // an instruction touches 16 rows of basis_t x 16 bytes (0.44 ms of this kernel went into those
+    // 32 gathers per lane).  Instead the wave loads its 64 pixels x 20 values as phase (A) does
+    // (4 rows x 64 contiguous bytes per instruction) and transposes them through LDS.
+    float* Bt = (kBtInPark && wave == 3) ? lds + GGC * PP1 : img + wave * kBtFloats;  // [pixel][k], pitch 21
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint32_t pa = (uint32_t)(min(row0 + g, H - 1) * W + min(col0 + arow, W - 1));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kk;
+        const float v = ldb(basis_t, ((uint32_t)min(k, K3 - 1) * (uint32_t)HW + pa) * 4u);
+        Bt[(16 * g + arow) * BP + k] = (k < K3) ? v : 0.0f;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     f32x4 macc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) macc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) {
       const int pl = 4 * s4 + kk;  // lane index of the contracted pixel inside this wave
-      const uint32_t pq = (uint32_t)(min(row0 + (pl >> 4), H - 1) * W + min(col0 + (pl & 15), W - 1));
       const int px = wave * kWave + pl;
       float av[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int k = mt * 16 + arow;
-        const float v = ldb(basis_t, ((uint32_t)min(k, K3 - 1) * (uint32_t)HW + pq) * 4u);
-        av[mt] = (k < K3) ? v : 0.0f;  // dead pixels carry gg == 0
-      }
-      const float bv = gg[arow * PP1 + px];
+      av[0] = Bt[pl * BP + arow];                                     // k = arow
+      av[1] = (arow < 4) ? Bt[pl * BP + 16 + min(arow, 3)] : 0.0f;    // k = 16 + arow (19 is the zero pad)
+      const float bv = gg[arow * PP1 + px];  // dead pixels carry gg == 0
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
         macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv, macc[mt], 0, 0, 0);
