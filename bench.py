@@ -49,6 +49,22 @@ def synth(frames, nl, h, w, device, seed):
     return layers, pts, occ
 
 
+class _SquareMean(torch.autograd.Function):
+    """The benchmark's loss, out.square().mean(), with its gradient 2 * out / N written as
+    ONE elementwise kernel: autograd's own chain for it (expand, copy, two multiplies) is four passes
+    over the 176 MB output, ~0.2 ms per step of pure loss scaffolding at the headline shape."""
+
+    @staticmethod
+    def forward(ctx, out):
+        ctx.save_for_backward(out)
+        return out.square().mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return out * (g * (2.0 / out.numel()))
+
+
 def copy_bandwidth(device, nbytes=1 << 30, reps=10):
     """Measured device-to-device copy rate of this box (read + write bytes per second, GB/s): the
     second denominator SURVEY 8(d) asks for next to the 8 TB/s spec figure."""
@@ -180,7 +196,7 @@ def main():
         layers.grad = None
         pts.grad = None
         rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
-        rgb.square().mean().backward()
+        _SquareMean.apply(rgb).backward()
 
     def fence():
         if dist is not None:
