@@ -107,7 +107,11 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   int* wcount = hitlist + kMaxHit;                      // hits per wave (current chunk)
   float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);
 
-  for (int e = threadIdx.x; e < 4 * kPlane; e += kG2Threads) img[e] = 0;
+  {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    static_assert((4 * kPlane) % 4 == 0, "16-byte zero fill");
+    for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
+  }
 
   // ---- cells whose box reaches S, listed in cell order (deterministic), and the sum of their
   // contribution bounds.  Chunks of kG2Threads cells; ballot-based compaction inside a wave.
@@ -238,6 +242,24 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   __syncthreads();
   // ---- S is ours alone: plain row-coalesced stores (zeros included)
   float* gbase = grad_layers + fl * 4 * HW;
+  if ((W & 3) == 0) {  // 16 bytes per lane: four texels of a row (rows are 16-byte aligned)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int e = threadIdx.x; e < kSrcTex / 4; e += kG2Threads) {
+      const int y = sy0 + (e >> 4), x = sx0 + 4 * (e & 15);
+      if (y < H && x < W) {
+        const unsigned doff = (unsigned)(__mul24(y, W) + x);
+        const int li = (e >> 4) * kPitch + 4 * (e & 15);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
+          *reinterpret_cast<f32x4*>(gbase + c * HW + doff) =
+              (f32x4){(float)v[0] * inv_scale, (float)v[1] * inv_scale, (float)v[2] * inv_scale, (float)v[3] * inv_scale};
+        }
+      }
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < kSrcTex; e += kG2Threads) {
     const int y = sy0 + (e >> 6), x = sx0 + (e & 63);
     if (y < H && x < W) {
