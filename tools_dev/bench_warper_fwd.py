@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""dev: Warper.forward (A13 = TPS grids + grid inversion) at the recipe size R."""
+import json, os, sys, types
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waldo_amd.nets import Warper
+from waldo_amd.tools.utils import get_grid
+dev = torch.device('cuda:0')
+opt = types.SimpleNamespace(latent_shape=[8, 16], obj_shape=[4, 4], time_dropout=False, num_obj=16, patch_size=16,
+                            scale_factor=1, dim=128, aspect_ratio=2, load_dim=512, num_perm_grid=1,
+                            normalize_alpha=False, use_lyt_filtering=False, use_lyt_opacity=False,
+                            weight_cls=False, min_cls=0.0, include_self=False, no_filter=False, allow_ghost=False)
+b, t, no = int(sys.argv[1]) if len(sys.argv) > 1 else 1, 5, 16
+wp = Warper(opt).to(dev)
+g = torch.Generator(device=dev).manual_seed(0)
+obj_pose = get_grid(4, 4).view(1, 1, 1, 16, 2).to(dev) * 0.5 + 0.1 * torch.randn(b, t, no, 16, 2, generator=g, device=dev)
+bg_pose = get_grid(8, 16).view(1, 1, 1, 128, 2).to(dev) + 0.02 * torch.randn(b, t, 1, 128, 2, generator=g, device=dev)
+with torch.no_grad():
+    for _ in range(3):
+        wp(obj_pose, bg_pose)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        wp(obj_pose, bg_pose)
+    e1.record()
+    torch.cuda.synchronize()
+print(json.dumps({"config": f"R: B={b} T={t} -> {b*t*no} object maps 64x64->128x256 + {b*t} background maps 128x256", "ms": round(e0.elapsed_time(e1) / 20, 3)}))
