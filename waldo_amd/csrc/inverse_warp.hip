@@ -14,6 +14,8 @@
 //   5. unfilled cells sample far out of range (offset 2W, 2H px); crop            warp.py:164-174
 // The integer path (cells, winners, masks) carries no gradient; the value path is linear and is
 // differentiated exactly by replaying the passes in reverse with the stored fill order.
+#include <stdlib.h>
+
 #include "waldo_common.hip.h"
 
 namespace waldo {
@@ -194,6 +196,135 @@ __global__ __launch_bounds__(kBlock) void iw_finalize_kernel(const float* __rest
   out[(b * HW + s) * 2 + 1] = tgt_id[s * 2 + 1] + vy * 2.0f / (float)H;
 }
 
+// ---- steps 3-5 in one launch: a workgroup owns a 32 x 32 tile of the padded raster and redoes the
+// fill / erosion passes on the tile plus a halo of 2 * niter cells in LDS (a cell's value depends on
+// cells at most niter away, its eroded mask on fill states niter further).  Same arithmetic, in the
+// same order, as the per-pass kernels above (which remain for niter too large for the LDS); instead of
+// 3 * niter + 3 streaming passes over the padded raster, the winners are read once and the
+// outputs written once.  A pass writes IN PLACE: the cells it fills are not read by anyone during
+// the pass (readers only touch cells filled earlier), their fill state changes after a barrier.
+constexpr int kFusedTH = 32, kFusedTW = 32;  // tile of the padded raster owned by a workgroup (32 x 64: slower)
+constexpr size_t kFusedMaxLds = 65536;
+constexpr unsigned char kOut = 254;  // outside the raster / outside the region: never filled, never a hole
+
+__global__ __launch_bounds__(kBlock) void iw_fused_kernel(
+    const float* __restrict__ dxy, const int* __restrict__ winner, const float* __restrict__ kern,
+    const float* __restrict__ tgt_id, float* __restrict__ out, unsigned char* __restrict__ fill_iter,
+    float* __restrict__ denom, unsigned char* __restrict__ mask, int H, int W, int niter, int erode,
+    int tiles_x, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int pad = niter + 1, halo = 2 * niter;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
+  const int RW = kFusedTW + 2 * halo + 2, RH = kFusedTH + 2 * halo + 2;  // region incl. a one-cell kOut border
+  const int cells = RH * RW;
+  float* fx = reinterpret_cast<float*>(smem);
+  float* fy = fx + cells;
+  unsigned char* fi = reinterpret_cast<unsigned char*>(fy + cells);
+  unsigned char* m0 = fi + cells;
+  unsigned char* m1 = m0 + cells;
+  const int64_t b = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const int ty0 = (tile / tiles_x) * kFusedTH, tx0 = (tile % tiles_x) * kFusedTW;  // padded coords
+  const int oy = ty0 - halo - 1, ox = tx0 - halo - 1;                                  // of region cell (0, 0)
+  float k9[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k9[i] = kern[i];
+
+  // ---- load: winners' (negated) displacement, fill state 0 / 255, kOut outside
+  for (int c = threadIdx.x; c < cells; c += kBlock) {
+    const int i = c / RW, j = c - i * RW;
+    const int yp = oy + i, xp = ox + j;
+    float vx = 0.0f, vy = 0.0f;
+    unsigned char st = kOut;
+    if (i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp) {
+      st = 255;
+      const int y = yp - pad, x = xp - pad;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const int w = winner[b * HW + y * W + x];
+        if (w != kNoWinner) {
+          vx = -dxy[(b * 2 + 0) * HW + w];
+          vy = -dxy[(b * 2 + 1) * HW + w];
+          st = 0;
+        }
+      }
+    }
+    fx[c] = vx;
+    fy[c] = vy;
+    fi[c] = st;
+  }
+  // ---- Jacobi fill passes
+  for (int it = 1; it <= niter; ++it) {
+    __syncthreads();
+    unsigned long long marks = 0;
+    int q = 0;
+    for (int c = threadIdx.x; c < cells; c += kBlock, ++q) {
+      if (fi[c] != 255) continue;
+      // 4-neighbour ring of the set filled before this pass
+      if (!(fi[c - RW] < it || fi[c + RW] < it || fi[c - 1] < it || fi[c + 1] < it)) continue;
+      float sx = 0.0f, sy = 0.0f, sm = 0.0f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int n = c + dy * RW + dx;
+          if (fi[n] < it) {  // unfilled cells hold 0 and contribute nothing
+            const float k = k9[(dy + 1) * 3 + (dx + 1)];
+            sx = fmaf(k, fx[n], sx);
+            sy = fmaf(k, fy[n], sy);
+            sm += k;
+          }
+        }
+      fx[c] = sx / sm;
+      fy[c] = sy / sm;
+      marks |= 1ull << q;
+      const int i = c / RW, j = c - i * RW;
+      const int yp = oy + i, xp = ox + j;
+      if (yp >= ty0 && yp < ty0 + kFusedTH && xp >= tx0 && xp < tx0 + kFusedTW)
+        denom[b * HWp + yp * Wp + xp] = sm;  // this workgroup's own cells (inside the raster: state 255)
+    }
+    __syncthreads();
+    q = 0;
+    for (int c = threadIdx.x; c < cells; c += kBlock, ++q)
+      if (marks & (1ull << q)) fi[c] = (unsigned char)it;
+  }
+  __syncthreads();
+  // ---- mask (1 = filled), erosion passes; kOut counts as filled (it is not part of the raster)
+  for (int c = threadIdx.x; c < cells; c += kBlock) m0[c] = fi[c] != 255;
+  unsigned char* mi = m0;
+  unsigned char* mo = m1;
+  if (erode) {
+    for (int it = 0; it < niter; ++it) {
+      __syncthreads();
+      for (int c = threadIdx.x; c < cells; c += kBlock) {
+        unsigned char v = mi[c];
+        if (v && fi[c] != kOut && !(mi[c - RW] && mi[c + RW] && mi[c - 1] && mi[c + 1])) v = 0;
+        mo[c] = v;
+      }
+      unsigned char* t = mi;
+      mi = mo;
+      mo = t;
+    }
+  }
+  __syncthreads();
+  // ---- the tile's own cells: fill state, final mask, and (inside the image) the inverted grid
+  for (int e = threadIdx.x; e < kFusedTH * kFusedTW; e += kBlock) {
+    const int yp = ty0 + e / kFusedTW, xp = tx0 + e % kFusedTW;
+    if (yp >= Hp || xp >= Wp) continue;
+    const int c = (yp - oy) * RW + (xp - ox);
+    fill_iter[b * HWp + yp * Wp + xp] = fi[c];
+    const bool m = mi[c] != 0;
+    mask[b * HWp + yp * Wp + xp] = m ? 1 : 0;
+    const int y = yp - pad, x = xp - pad;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const int s = y * W + x;
+      const float vx = m ? fx[c] : 2.0f * (float)W;
+      const float vy = m ? fy[c] : 2.0f * (float)H;
+      out[(b * HW + s) * 2 + 0] = tgt_id[s * 2 + 0] + vx * 2.0f / (float)W;
+      out[(b * HW + s) * 2 + 1] = tgt_id[s * 2 + 1] + vy * 2.0f / (float)H;
+    }
+  }
+}
+
 // ---- backward
 __global__ __launch_bounds__(kBlock) void iw_bwd_init_kernel(const float* __restrict__ gout,
                                                              const unsigned char* __restrict__ mask,
@@ -320,6 +451,15 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
   (void)hipMemsetAsync(winner, 0x7f, sizeof(int) * (size_t)B * HW, st);
   hipLaunchKernelGGL(iw_splat_kernel, gs, dim3(kBlock), 0, st, src_grid, src_id, dxy, cell, winner,
                      Hs, Ws, H, W);
+  static const bool passes = getenv("WALDO_IW_PASSES") != nullptr;  // A/B switch for testing
+  const int tiles_x = (Wp + kFusedTW - 1) / kFusedTW, tiles_y = (Hp + kFusedTH - 1) / kFusedTH;
+  const size_t lds = (size_t)(kFusedTH + 4 * niter + 2) * (kFusedTW + 4 * niter + 2) * (2 * sizeof(float) + 3);
+  if (!passes && lds <= kFusedMaxLds && (int64_t)B * tiles_x * tiles_y <= 2147483647) {
+    hipLaunchKernelGGL(iw_fused_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(kBlock), lds, st, dxy,
+                       winner, gauss3x3, tgt_id, out, fill_iter, denom, mask_a, H, W, niter, erode, tiles_x,
+                       tiles_x * tiles_y);
+    return launch_status("waldo_inverse_warp_fwd");
+  }
   hipLaunchKernelGGL(iw_gather_kernel, gp, dim3(kBlock), 0, st, dxy, winner, field_a, fill_iter, H,
                      W, pad);
   float* fin = field_a;
