@@ -654,26 +654,39 @@ __global__ __launch_bounds__(kPxThreads, GOCC ? 2 : WALDO_PX_WPE) void warp_comp
   }
 }
 
-// second stage of the control-point gradient: grad_mapping[f,l,k,c] += sum_tile partial
+// second stage of the control-point gradient: grad_mapping[f,l,k,c] += sum_tile partial.
+// A workgroup sums 32 outputs of one frame: 8 thread groups take an eighth of the tiles each (32
+// consecutive floats per tile: 128-byte segments), then the eight partial sums are added in a
+// fixed order (deterministic).
+constexpr int kRedOut = 32, kRedSlices = kBlock / kRedOut;
+
 static __global__ __launch_bounds__(kBlock) void warp_composite_gmap_reduce_kernel(
     const float* __restrict__ gmap_partial, float* __restrict__ grad_mapping, int F, int L,
-    int ntiles) {
+    int ntiles, int groups) {
   const int per = L * kGmapK3 * 2;
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= (int64_t)F * per) return;
-  const int64_t f = e / per;
-  const int o = (int)(e % per);
-  const float* src = gmap_partial + f * ntiles * per + o;
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int t = 0;
-  for (; t + 3 < ntiles; t += 4) {
-    s0 += src[(int64_t)t * per];
-    s1 += src[(int64_t)(t + 1) * per];
-    s2 += src[(int64_t)(t + 2) * per];
-    s3 += src[(int64_t)(t + 3) * per];
+  const int64_t f = blockIdx.x / groups;
+  const int o = (blockIdx.x % groups) * kRedOut + (threadIdx.x % kRedOut);
+  const int slice = threadIdx.x / kRedOut;
+  __shared__ float red[kRedSlices][kRedOut];
+  float s0 = 0.0f, s1 = 0.0f;
+  if (o < per) {
+    const int t0 = (int)((int64_t)ntiles * slice / kRedSlices), t1 = (int)((int64_t)ntiles * (slice + 1) / kRedSlices);
+    const float* src = gmap_partial + f * ntiles * per + o;
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+      s0 += src[(int64_t)t * per];
+      s1 += src[(int64_t)(t + 1) * per];
+    }
+    if (t < t1) s0 += src[(int64_t)t * per];
   }
-  for (; t < ntiles; ++t) s0 += src[(int64_t)t * per];
-  grad_mapping[e] += (s0 + s1) + (s2 + s3);
+  red[slice][threadIdx.x % kRedOut] = s0 + s1;
+  __syncthreads();
+  if (slice == 0 && o < per) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRedSlices; ++k) sum += red[k][threadIdx.x];
+    grad_mapping[f * per + o] += sum;
+  }
 }
 
 // K2 (compiled once, warp_composite_splat.hip)
@@ -812,9 +825,9 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     }
   }
   if (part != nullptr) {
-    const int64_t n = (int64_t)F * gmap_partial_floats(L);
-    hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, part, grad_mapping, F, L, ntiles);
+    const int groups = (int)((gmap_partial_floats(L) + kRedOut - 1) / kRedOut);
+    hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((int64_t)F * groups)), dim3(kBlock),
+                       0, st, part, grad_mapping, F, L, ntiles, groups);
   }
   launch_splat(reinterpret_cast<const float*>(rec), grad_rgb,
                boxes, bounds, grad_layers, F, L, H, W, st);
