@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   }
   __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
   // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 turn the range of "their" column
-  // (layer, xy) into block origins -- per 8-row cell of the footprint table (this tile owns its
-  // two cells: plain stores in the splat kernel's format (min x, -max x, min y, -max y)), and for
+  // (layer, xy) into block origins -- per cell of the footprint table (this tile owns its
+  // cells: plain stores in the splat kernel's format (min x, -max x, min y, -max y)), and for
   // the whole tile (the box that is staged; corners to SGPRs)
   int bx0[LP], by0[LP], bw[LP], bh[LP];
   bool fits[LP];
@@ -176,14 +176,20 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
     const int size = (arow & 1) ? H : W;
     int lo_t = 0x7fffffff, hi_t = -1;
     const int l2 = arow >> 1;
+    constexpr int kCellsPerTile = kLdsTile / kCellRows, kWavesPerCell = 4 / kCellsPerTile;
+    static_assert(kCellsPerTile * kCellRows == kLdsTile && kWavesPerCell * kCellsPerTile == 4, "cell rows: 4, 8 or 16");
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float mn = fminf(boxred[((2 * c) * GGC + arow) * 2 + 0], boxred[((2 * c + 1) * GGC + arow) * 2 + 0]);
-      const float mx = fmaxf(boxred[((2 * c) * GGC + arow) * 2 + 1], boxred[((2 * c + 1) * GGC + arow) * 2 + 1]);
+    for (int c = 0; c < kCellsPerTile; ++c) {
+      float mn = boxred[((kWavesPerCell * c) * GGC + arow) * 2 + 0], mx = boxred[((kWavesPerCell * c) * GGC + arow) * 2 + 1];
+#pragma unroll
+      for (int w = 1; w < kWavesPerCell; ++w) {
+        mn = fminf(mn, boxred[((kWavesPerCell * c + w) * GGC + arow) * 2 + 0]);
+        mx = fmaxf(mx, boxred[((kWavesPerCell * c + w) * GGC + arow) * 2 + 1]);
+      }
       const int lo_c = block_origin(mn, size), hi_c = block_origin(mx, size) + 1;
       lo_t = min(lo_t, lo_c);
       hi_t = max(hi_t, hi_c);
-      const int crow = (tile / ntx) * 2 + c;
+      const int crow = (tile / ntx) * kCellsPerTile + c;
       if (wave == 0 && kk == 0 && l2 < L && crow * ncx < ncells) {
         int* bb = cellbox + (((int64_t)f * L + l2) * ncells + crow * ncx + (tile % ntx)) * 4 + (arow & 1) * 2;
         *reinterpret_cast<int2*>(bb) = make_int2(lo_c, -hi_c);
@@ -415,15 +421,20 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
     for (int c = 2 * LP; c < GGC; ++c) gg[c * PP1 + pix] = 0.0f;
   }
   __syncthreads();  // gg rows and the waves' bounds are complete
-  if (threadIdx.x < 2 * LP) {
-    const int c = threadIdx.x / LP, l = threadIdx.x % LP;
-    const int crow = (tile / ntx) * 2 + c;
-    if (l < L && crow * ncx < ncells) {
-      const int v = pk_max_u16(wbound[(2 * c) * (LP / 2) + l / 2], wbound[(2 * c + 1) * (LP / 2) + l / 2]);
-      const int e = (l & 1) ? (v >> 16) & 0xffff : v & 0xffff;
-      // 16 * 2^(e - 126) as float bits; nothing but zeros / denormals in the cell: 0
-      cellbound[((int64_t)f * L + l) * ncells + crow * ncx + (tile % ntx)] =
-          e == 0 ? 0u : (unsigned)min(e + 5, 254) << 23;
+  {
+    constexpr int kCellsPerTile = kLdsTile / kCellRows, kWavesPerCell = 4 / kCellsPerTile;
+    if (threadIdx.x < kCellsPerTile * LP) {
+      const int c = threadIdx.x / LP, l = threadIdx.x % LP;
+      const int crow = (tile / ntx) * kCellsPerTile + c;
+      if (l < L && crow * ncx < ncells) {
+        int v = wbound[(kWavesPerCell * c) * (LP / 2) + l / 2];
+#pragma unroll
+        for (int w = 1; w < kWavesPerCell; ++w) v = pk_max_u16(v, wbound[(kWavesPerCell * c + w) * (LP / 2) + l / 2]);
+        const int e = (l & 1) ? (v >> 16) & 0xffff : v & 0xffff;
+        // 16 * 2^(e - 126) as float bits; nothing but zeros / denormals in the cell: 0
+        cellbound[((int64_t)f * L + l) * ncells + crow * ncx + (tile % ntx)] =
+            e == 0 ? 0u : (unsigned)min(e + 5, 254) << 23;
+      }
     }
   }
 

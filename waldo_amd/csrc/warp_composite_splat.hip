@@ -23,9 +23,11 @@ namespace waldo {
 constexpr int kSrcRows = 32, kSrcCols = 64;          // S tile
 constexpr int kSrcTex = kSrcRows * kSrcCols;          // 2048 texels (x4 channels)
 constexpr int kCellPix = kCellRows * kCellCols;       // 128
+constexpr int kCellShift = kCellPix == 64 ? 6 : (kCellPix == 128 ? 7 : 8);
+static_assert((1 << kCellShift) == kCellPix, "cell rows: 4, 8 or 16");
 constexpr int kG2Waves = 8;
 constexpr int kG2Threads = kG2Waves * kWave;          // 512
-constexpr int kMaxHit = 192;                          // cells listed per tile (else: slow scan)
+constexpr int kMaxHit = 192 * 8 / kCellRows;                          // cells listed per tile (else: slow scan)
 
 __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
   const int4 r = reinterpret_cast<const int4*>(cellbox)[idx];
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       };
       auto fetch = [&](int i, Cand& k) {
         const int ic = min(i, total - 1);  // past the end: a valid candidate, masked by livep
-        const int org = hitlist[ic >> 7];
+        const int org = hitlist[ic >> kCellShift];
         const int within = ic & (kCellPix - 1);
         const int py = (org >> 16) + (within >> 4);
         const int px = (org & 0xffff) + (within & 15);
