@@ -380,6 +380,14 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
   // ---- (G) a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Second half of the records,
   // contribution bounds, and the grid gradient of every layer (read this thread's parked
   // derivatives, then overwrite the same LDS column with gg -- no other thread touches it).
+  // The records go out FIRST: phase (H)'s loads complete only after every older store of the wave
+  // (vector-memory operations complete in order), so the stores get the rest of this phase to drain.
+  if (live) {
+#pragma unroll
+    for (int l = 0; l < LP; ++l)
+      if (EXL || l < L)
+        rec[((int64_t)f * L + l) * HW + p] = make_float4(gxs[l], gys[l], ap[l], l >= 1 ? 0.5f * ga[l] : 0.0f);
+  }
   {
     float ggx[LP], ggy[LP];
     int eb[LP];
@@ -395,7 +403,6 @@ __global__ __launch_bounds__(kBlock, GOCC ? 2 : 3) void warp_composite_bwd_px16_
       // exponent: bilinear weights are <= 1.  Only e goes into the bound (see below).
       const float cb = (live && !pad) ? fmaxf(fabsf(ap[l]) * gmax, fabsf(gsa)) : 0.0f;
       eb[l] = (int)(__float_as_uint(cb) >> 23);  // cb >= 0: sign bit clear
-      if (live && !pad) rec[((int64_t)f * L + l) * HW + p] = make_float4(gxs[l], gys[l], ap[l], gsa);
     }
     // the table's bound (an upper bound of any 16-pixel row sum of the cell): 16 * 2^(e_max - 126)
     // with e_max the largest exponent in the cell -- one packed 16-bit max-reduction per two
