@@ -249,7 +249,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{'C3' if (nl, h, w, args.frames_per_clip) == (8, 256, 512, 14) else 'custom'}: "
                                    f"{args.clips} clips x {args.frames_per_clip} frames per GPU, "
-                                   f"{nl} layers x 4x{h}x{w}, 16 TPS control points, fwd+bwd",
+                                   f"{nl} layers x 4x{h}x{w}, 16 TPS control points, " + ("fwd+bwd" if args.mode == "train" else "fwd"),
                        "frames_per_gpu": frames, "layers": nl, "height": h, "width": w,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": roof,
