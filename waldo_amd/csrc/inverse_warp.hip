@@ -231,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   for (int i = 0; i < 9; ++i) k9[i] = kern[i];
 
   // ---- load: winners' (negated) displacement, fill state 0 / 255, kOut outside
+  int any_filled = 0;
   for (int c = threadIdx.x; c < cells; c += kBlock) {
     const int i = c / RW, j = c - i * RW;
     const int yp = oy + i, xp = ox + j;
@@ -251,9 +252,13 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
     fx[c] = vx;
     fy[c] = vy;
     fi[c] = st;
+    any_filled |= st == 0;
   }
+  // a region without a single winner stays empty through every pass (objects cover a few percent of
+  // their canvas: most tiles): skip straight to the outputs
+  const int n_pass = __syncthreads_or(any_filled) ? niter : 0;
   // ---- Jacobi fill passes
-  for (int it = 1; it <= niter; ++it) {
+  for (int it = 1; it <= n_pass; ++it) {
     __syncthreads();
     unsigned long long marks = 0;
     int q = 0;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   unsigned char* mi = m0;
   unsigned char* mo = m1;
   if (erode) {
-    for (int it = 0; it < niter; ++it) {
+    for (int it = 0; it < n_pass; ++it) {
       __syncthreads();
       for (int c = threadIdx.x; c < cells; c += kBlock) {
         unsigned char v = mi[c];
