@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: warped+composited frames/sec at 256x512, 8 layers, fwd+bwd.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 10           # config C3, the headline
+    python bench.py --config C5                                # the other BASELINE.json configs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,6 +13,14 @@ occ = compute_occ(randn).  One step = one pass of the hot path over that batch:
   bwd  rgb.square().mean().backward()              grads on layers and control points
 Inputs are resident in HBM when the timed region starts.  Frames are independent, so ranks shard
 them with no data-path collective ("scaling": "weak", per-GPU work fixed).
+
+Named workloads (--config; BASELINE.json `configs`); C3 is the default and the
+only one the headline metric is quoted on, the others print the same JSON shape with their own
+metric string:
+  C2  8 frames of 128x128, L=8, forward only (launch-bound: replayed from a HIP graph)
+  C3  8 clips x 14 frames of 256x512, L=8, fwd+bwd
+  C4  8 clips x 9 frames of 256x832 (KITTI), L=8, forward + all-gather of the composited frames
+  C5  4 clips x 14 frames of 512x1024, L=12, forward + all-gather
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel, algorithmic bytes per launch / mean launch duration measured live
@@ -33,13 +42,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def synth(frames, nl, h, w, device, seed):
+def synth(frames, nl, h, w, device, seed, sigma=0.05):
     """Same recipe as oracle.wif_oracle.make_synthetic, generated on the device."""
     from waldo_amd.tools.utils import get_grid
     g = torch.Generator(device=device).manual_seed(seed)
     layers = torch.rand(frames, nl, 4, h, w, generator=g, device=device) * 2 - 1
     ctrl = get_grid(4, 4).view(1, 16, 2).to(device)
-    sigma = float(os.environ.get("WALDO_BENCH_SIGMA", "0.05"))  # dev knob; the benchmark is 0.05
     pts = ctrl + sigma * torch.randn(frames * nl, 16, 2, generator=g, device=device)
     score = torch.randn(frames, nl - 1, generator=g, device=device)
     s = torch.exp(-score ** 2) + 1e-6
@@ -110,10 +118,19 @@ def cpu_baseline(nl, h, w, frames, reps):
     torch.set_num_threads(cores)
     times = sorted(once() for _ in range(reps))
     med = times[len(times) // 2]
+    # SURVEY 8(d) also asks for the single-thread figure: a few frames, one repetition after warm-up
+    f1 = max(1, min(4, frames))
+    layers, pts, occ = layers.detach()[:f1].requires_grad_(), pts.detach()[:f1 * nl].requires_grad_(), occ[:f1]
+    torch.set_num_threads(1)
+    once()
+    t1 = once()
+    torch.set_num_threads(cores)
     return {"value": round(frames / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(f1 / t1, 3),
             "sample": f"{frames} frames of the same workload ({nl}x4x{h}x{w}, fwd+bwd), "
                       f"median of {reps} after warm-up, torch {torch.__version__} CPU, "
-                      f"{cores} threads (fastest of {sorted(probe)} probed on {ncpu} logical CPUs)"}
+                      f"{cores} threads (fastest of {sorted(probe)} probed on {ncpu} logical CPUs); "
+                      f"value_1_thread: {f1} frames, one run after warm-up"}
 
 
 def measured_traffic(entry_point, frames, nl, h, w):
@@ -131,19 +148,31 @@ def measured_traffic(entry_point, frames, nl, h, w):
     return None
 
 
+CONFIGS = {
+    # name: (clips per GPU, frames per clip, layers, height, width, mode)
+    "C2": (1, 8, 8, 128, 128, "fwd"),
+    "C3": (8, 14, 8, 256, 512, "train"),
+    "C4": (8, 9, 8, 256, 832, "infer"),
+    "C5": (4, 14, 12, 512, 1024, "infer"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--clips", type=int, default=8, help="clips per GPU (T=14 frames each)")
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--layers", type=int, default=8)
-    ap.add_argument("--frames-per-clip", type=int, default=14)
-    ap.add_argument("--mode", choices=["train", "infer"], default="train",
-                    help="train: fwd+bwd (the headline metric); infer: fwd only + RCCL all-gather "
-                         "of the composited frames (not the headline; vs_baseline/roofline differ)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3",
+                    help="BASELINE.json workload; C3 (the default) is the one the headline metric is quoted on")
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU (overrides the config)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--frames-per-clip", type=int, default=None)
+    ap.add_argument("--sigma", type=float, default=0.05, help="control-point noise (the benchmark is 0.05)")
+    ap.add_argument("--mode", choices=["train", "infer", "fwd"], default=None,
+                    help="train: fwd+bwd (the headline metric); infer: fwd only + RCCL all-gather of the "
+                         "composited frames; fwd: forward only, replayed from a HIP graph")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL on ROCm) is the real thing; gloo only to smoke-test the "
                          "multi-rank code path on a box with fewer GPUs than ranks")
@@ -151,16 +180,23 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
     args = ap.parse_args()
+    c_clips, c_fpc, c_nl, c_h, c_w, c_mode = CONFIGS[args.config]
+    clips = args.clips if args.clips is not None else c_clips
+    fpc = args.frames_per_clip if args.frames_per_clip is not None else c_fpc
+    nl = args.layers if args.layers is not None else c_nl
+    h = args.height if args.height is not None else c_h
+    w = args.width if args.width is not None else c_w
+    mode = args.mode or c_mode
+    custom = (clips, fpc, nl, h, w, mode) != CONFIGS[args.config] or args.sigma != 0.05
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  f"python -m torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(1)
@@ -176,19 +212,29 @@ def main():
 
     import waldo_amd
     from waldo_amd import _lib, functional as WF
+    from waldo_amd.graphs import GraphedCall
     from waldo_amd.tools.utils import get_grid
 
-    nl, h, w = args.layers, args.height, args.width
-    frames = args.clips * args.frames_per_clip
+    frames = clips * fpc
     tps = waldo_amd.TPSWarp(h, w, get_grid(4, 4).view(-1, 2)).to(device)
-    layers, pts, occ = synth(frames, nl, h, w, device, seed=rank)
-    layers.requires_grad_()
-    pts.requires_grad_()
+    layers, pts, occ = synth(frames, nl, h, w, device, seed=rank, sigma=args.sigma)
+    if mode == "train":
+        layers.requires_grad_()
+        pts.requires_grad_()
 
     from waldo_amd.dist import all_gather_frames
 
-    def step():
-        if args.mode == "infer":
+    graphed = None
+    if mode == "fwd":  # launch-bound shapes: the call sequence replayed from one HIP graph
+        graphed = GraphedCall(lambda l, p, o: WF.warp_composite(l, p, o, tps.inverse_kernel, tps.basis_t),
+                              layers, pts, occ)
+
+    def step(loss=None):
+        if mode == "fwd":
+            with torch.no_grad():
+                graphed(*graphed.inputs)  # the graph's own static buffers: no input copy in the step
+            return
+        if mode == "infer":
             with torch.no_grad():
                 rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
                 all_gather_frames(rgb, frames * world)
@@ -196,66 +242,98 @@ def main():
         layers.grad = None
         pts.grad = None
         rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
-        _SquareMean.apply(rgb).backward()
+        (loss or _SquareMean.apply)(rgb).backward()
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        fence()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
         step()
-    fence()
     with _lib.KernelTimer() as kt:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed(args.steps)
     if dist is not None:
         t = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    # the same step with the loss written as the specification has it, rgb.square().mean(), and
+    # autograd's own four-pass gradient chain for it: reported next to the headline, never as it
+    loss_variants = None
+    if mode == "train" and world == 1:
+        n = max(5, min(args.steps, 20))
+        plain = lambda rgb: rgb.square().mean()  # noqa: E731
+        for _ in range(2):
+            step(loss=plain)
+        loss_variants = {"one_pass_loss_gradient_ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                         "autograd_loss_ms_per_step": round(timed(n, loss=plain) / n * 1e3, 4),
+                         "note": "value / ms_per_step use _SquareMean (same numbers, gradient 2*rgb/N in one "
+                                 "elementwise pass); the second line is out.square().mean().backward() as is"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_frames = frames * world
         value = total_frames / (elapsed / args.steps)
-        ks = kt.summary()
         hw = h * w
         alg = {"waldo_warp_composite_fwd": (16 * nl + 12) * hw * frames,
                "waldo_warp_composite_bwd": (32 * nl + 12) * hw * frames}
-        if args.mode == "infer":
+        if mode != "train":
             alg.pop("waldo_warp_composite_bwd")
+        if mode == "fwd":
+            # inside a graph the per-call events are not recorded: the replay time is the kernel
+            # time plus the graph's launch floor
+            ks = {"waldo_warp_composite_fwd": (args.steps, ms_per_step)}
+        else:
+            ks = kt.summary()
         dom = max(alg, key=lambda k: ks[k][1])
         kern = {}
         for k in alg:
             gbs = alg[k] / (ks[k][1] * 1e-3) / 1e9
             kern[k] = {"launches": ks[k][0], "ms": round(ks[k][1], 4), "alg_bytes": alg[k],
                        "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        traffic = measured_traffic(dom, frames, nl, h, w)
         roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": measured_traffic(dom, frames, nl, h, w),
+                "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+                "traffic_source": ("profiles/traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "workload, committed; not re-measured in this run") if traffic else None,
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": alg[dom],
                 "kernels": kern}
         copy_gbs = copy_bandwidth(device)
         roof["copy_GBps"] = round(copy_gbs, 1)  # measured D2D copy rate of this box (read + write)
         roof["frac_of_copy"] = round(kern[dom]["GBps"] / copy_gbs, 4)
+        what = {"train": "fwd+bwd", "infer": "fwd only + all-gather", "fwd": "fwd only (HIP-graph replay)"}[mode]
+        if args.config == "C3" and not custom:
+            metric = "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd"
+        else:
+            metric = f"warped+composited frames/sec at {h}x{w}, {nl} layers; {what} (not the headline metric)"
         out = {
-            "metric": "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd" if args.mode == "train"
-            else "warped+composited frames/sec, fwd only + all-gather (not the headline metric)",
+            "metric": metric,
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{'C3' if (nl, h, w, args.frames_per_clip) == (8, 256, 512, 14) else 'custom'}: "
-                                   f"{args.clips} clips x {args.frames_per_clip} frames per GPU, "
-                                   f"{nl} layers x 4x{h}x{w}, 16 TPS control points, " + ("fwd+bwd" if args.mode == "train" else "fwd"),
+            "config": {"workload": f"{'custom (from ' + args.config + ')' if custom else args.config}: "
+                                   f"{clips} clips x {fpc} frames per GPU, "
+                                   f"{nl} layers x 4x{h}x{w}, 16 TPS control points, {what}",
                        "frames_per_gpu": frames, "layers": nl, "height": h, "width": w,
-                       "parallelism": f"frames sharded x{world}, no data-path collective"},
+                       "parallelism": f"frames sharded x{world}, "
+                                      + ("one all-gather of the composited frames" if mode == "infer"
+                                         else "no data-path collective")},
             "roofline": roof,
         }
+        if loss_variants is not None:
+            out["loss_variants"] = loss_variants
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nl, h, w, args.cpu_frames, args.cpu_reps)
+            out["cpu_baseline"] = cpu_baseline(nl, h, w, min(args.cpu_frames, max(1, 28 * 131072 // hw)),
+                                               args.cpu_reps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -11,7 +11,8 @@
  *   - kernels are launched on `stream` (a hipStream_t passed as void*) of the CURRENT device;
  *   - returns 0 on success, a negative WALDO_E* code otherwise; no C++ exception crosses the ABI;
  *     waldo_last_error_string() gives the message of the last failure on the calling thread;
- *   - re-entrant: no global mutable state except the thread-local error string.
+ *   - re-entrant: no global mutable state except the thread-local error string and the
+ *     process-wide debug options below (tests only; all off unless a test switches one on).
  *
  * Build: hipcc --offload-arch=gfx950 -shared -fPIC (see waldo_amd/build.py).
  */
@@ -35,6 +36,13 @@ int waldo_version(void);
 const char* waldo_last_error_string(void);
 /* Largest layer count L the fused composite kernels accept. */
 int waldo_max_layers(void);
+
+/* Test-only switches between kernel variants that compute the same thing (A/B parity tests of the
+ * fast paths against the plain ones).  Process-wide, off by default; nothing reads the environment. */
+#define WALDO_DEBUG_FWD_PLAIN 0   /* fused forward: gather kernel instead of the LDS-staged one */
+#define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
+#define WALDO_DEBUG_COUNT 2
+int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------
  * A2. Thin-plate-spline grid synthesis -- replaces TPSWarp.forward

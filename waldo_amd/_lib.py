@@ -47,7 +47,12 @@ SIGNATURES = {
 }
 PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
          "waldo_warp_composite_bwd_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int]),
-         "waldo_last_error_string": (ctypes.c_char_p, [])}
+         "waldo_last_error_string": (ctypes.c_char_p, []),
+         "waldo_set_debug_option": (_int, [_int, _int])}
+
+# include/waldo_hip.h: test-only switches between kernel variants (waldo_set_debug_option)
+DEBUG_FWD_PLAIN = 0
+DEBUG_IW_PASSES = 1
 
 _lock = threading.Lock()
 _lib = None

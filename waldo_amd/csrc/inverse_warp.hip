@@ -456,7 +456,7 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
   (void)hipMemsetAsync(winner, 0x7f, sizeof(int) * (size_t)B * HW, st);
   hipLaunchKernelGGL(iw_splat_kernel, gs, dim3(kBlock), 0, st, src_grid, src_id, dxy, cell, winner,
                      Hs, Ws, H, W);
-  static const bool passes = getenv("WALDO_IW_PASSES") != nullptr;  // A/B switch for testing
+  const bool passes = debug_option(WALDO_DEBUG_IW_PASSES);
   const int tiles_x = (Wp + kFusedTW - 1) / kFusedTW, tiles_y = (Hp + kFusedTH - 1) / kFusedTH;
   const size_t lds = (size_t)(kFusedTH + 4 * niter + 2) * (kFusedTW + 4 * niter + 2) * (2 * sizeof(float) + 3);
   if (!passes && lds <= kFusedMaxLds && (int64_t)B * tiles_x * tiles_y <= 2147483647) {

@@ -1,6 +1,8 @@
-// Error reporting and version of the C ABI (include/waldo_hip.h).
+// Error reporting, version and the test-only debug options of the C ABI (include/waldo_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+
+#include <atomic>
 
 #include "waldo_common.hip.h"
 
@@ -24,8 +26,23 @@ int launch_status(const char* what) {
   return WALDO_OK;
 }
 
+static std::atomic<int> g_debug[WALDO_DEBUG_COUNT];
+
+bool debug_option(int option) {
+  return option >= 0 && option < WALDO_DEBUG_COUNT && g_debug[option].load(std::memory_order_relaxed) != 0;
+}
+
 }  // namespace waldo
 
-extern "C" int waldo_version(void) { return 1000; }
+extern "C" int waldo_version(void) { return 1001; }
+
+extern "C" int waldo_set_debug_option(int option, int value) {
+  if (option < 0 || option >= WALDO_DEBUG_COUNT) {
+    waldo::set_error("waldo_set_debug_option: unknown option %d", option);
+    return WALDO_EINVAL;
+  }
+  waldo::g_debug[option].store(value, std::memory_order_relaxed);
+  return WALDO_OK;
+}
 
 extern "C" const char* waldo_last_error_string(void) { return waldo::g_err; }

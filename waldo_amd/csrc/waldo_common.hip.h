@@ -13,6 +13,7 @@ namespace waldo {
 
 void set_error(const char* fmt, ...);
 int launch_status(const char* what);
+bool debug_option(int option);  // waldo_set_debug_option (tests only; all off by default)
 
 constexpr int kWave = 64;   // gfx950 wavefront
 constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU

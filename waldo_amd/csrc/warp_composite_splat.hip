@@ -16,6 +16,18 @@
 // the taps that fall into S in a 32-bit FIXED-POINT LDS image: integer LDS atomics run at the
 // plain ds_write rate on gfx950 while ds_add_f32 retires ~3 cycles per lane
 // (tools_dev/lds_atomic_bench*.hip); integer sums are also order-independent.
+//
+// The table is scanned in two levels: the boxes of K1's 16x16-pixel tiles first (one per thread at
+// the headline shape), then only the cells of the tiles that reach S.
+//
+// Precision contract (also in include/waldo_hip.h): a tile's sums are exact integers of a quantum
+// 2^-s per channel GROUP (the three colour planes share one scale, the alpha plane has its own),
+// with s chosen from an upper bound B of any texel sum in the tile -- the sum over the listed cells
+// of (pixels per cell) x (largest contribution in the cell, as a power of two) -- so that no sum
+// can overflow: quantum = 2^(ceil(log2 B) - 29).  Every contribution is rounded to that quantum, so
+// the error of a texel is at most (number of taps that reach it) / 2 quanta, ABSOLUTE for the tile
+// and group: texels far below the tile's largest sums lose relative precision.  A non-finite
+// contribution anywhere in a listed cell turns the whole tile (all four planes) into NaN.
 #include "waldo_common.hip.h"
 
 namespace waldo {
@@ -27,7 +39,9 @@ constexpr int kCellShift = kCellPix == 64 ? 6 : (kCellPix == 128 ? 7 : 8);
 static_assert((1 << kCellShift) == kCellPix, "cell rows: 4, 8 or 16");
 constexpr int kG2Waves = 8;
 constexpr int kG2Threads = kG2Waves * kWave;          // 512
-constexpr int kMaxHit = 192 * 8 / kCellRows;                          // cells listed per tile (else: slow scan)
+constexpr int kMaxHit = 192 * 8 / kCellRows;         // cells listed per tile (else: slow scan)
+constexpr int kMaxTileHit = 128;                      // 16x16 tiles of K1 listed per S (else: slow scan)
+static_assert(kCellCols == kLdsTile, "a K1 tile spans one column of cells");
 
 __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
   const int4 r = reinterpret_cast<const int4*>(cellbox)[idx];
@@ -52,7 +66,7 @@ constexpr int kDump = kImgWords;                       // + lane
 // the four corner addresses are selected once, the channel planes are immediate offsets.
 __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const Taps& t,
                                             const float4 rec, float g0, float g1, float g2,
-                                            float scale, int sx0, int sy0) {
+                                            float scale_rgb, float scale_a, int sx0, int sy0) {
   const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
   const bool cx0 = (unsigned)lx0 < (unsigned)kSrcCols, cx1 = (unsigned)(lx0 + 1) < (unsigned)kSrcCols;
   const bool cy0 = on && (unsigned)ly0 < (unsigned)kSrcRows, cy1 = on && (unsigned)(ly0 + 1) < (unsigned)kSrcRows;
@@ -62,14 +76,15 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
   int* a01 = img + ((cx1 && cy0) ? base + 1 : dump);
   int* a10 = img + ((cx0 && cy1) ? base + kPitch : dump);
   int* a11 = img + ((cx1 && cy1) ? base + kPitch + 1 : dump);
+  const float as = rec.x * scale_rgb;
   float gv[4];
-  gv[0] = rec.x * g0;
-  gv[1] = rec.x * g1;
-  gv[2] = rec.x * g2;
-  gv[3] = rec.y;
+  gv[0] = as * g0;
+  gv[1] = as * g1;
+  gv[2] = as * g2;
+  gv[3] = rec.y * scale_a;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float gs = gv[c] * scale;
+    const float gs = gv[c];
     atomicAdd(a00 + c * kPlane, cvt_round(gs * t.w00));
     atomicAdd(a01 + c * kPlane, cvt_round(gs * t.w01));
     atomicAdd(a10 + c * kPlane, cvt_round(gs * t.w10));
@@ -85,9 +100,9 @@ __device__ __forceinline__ bool touches(const TapCore& t, int sx0, int sy0) {
 
 __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     const float4* __restrict__ rec, const float* __restrict__ grad_rgb,
-    const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
-    float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int ncx,
-    int ncells) {
+    const int* __restrict__ cellbox, const int* __restrict__ tilebox,
+    const unsigned* __restrict__ cellbound, float* __restrict__ grad_layers, int F, int L, int H,
+    int W, int nsx, int nstiles, int ncx, int ncells, int ntiles16) {
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   // a FRAME is pinned to one XCD, source-tile-major inside it: the L layer planes of one source
@@ -103,11 +118,12 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
-  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + 2 * kG2Waves + 4];
+  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + kMaxTileHit + 3 * kG2Waves + 4];
   int* img = lds;
   int* hitlist = lds + 4 * kPlane;
-  int* wcount = hitlist + kMaxHit;                      // hits per wave (current chunk)
-  float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);
+  int* tilehits = hitlist + kMaxHit;
+  int* wcount = tilehits + kMaxTileHit;                 // hits per wave (current chunk)
+  float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);  // [wave][rgb, alpha]
 
   {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -115,53 +131,128 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
   }
 
-  // ---- cells whose box reaches S, listed in cell order (deterministic), and the sum of their
-  // contribution bounds.  Chunks of kG2Threads cells; ballot-based compaction inside a wave.
-  int nhit = 0;
-  float bsum = 0.0f;
-  const float cell_rows = (float)kCellRows;
-  for (int c0 = 0; c0 < ncells; c0 += kG2Threads) {
-    const int c = c0 + threadIdx.x;
-    bool hit = false;
-    float bnd = 0.0f;
-    if (c < ncells) {
-      const int4 ob = load_box(cellbox, fl * ncells + c);
-      hit = ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
-      // K1 publishes the largest 16-pixel row sum of the cell; a cell has kCellRows rows
-      if (hit) bnd = __uint_as_float(cellbound[fl * ncells + c]) * cell_rows;
-    }
+  auto reaches = [&](const int4 ob) {
+    return ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
+  };
+  // ---- level 1: the 16x16-pixel tiles of K1 whose box reaches S, in tile order.  Chunks of
+  // kG2Threads tiles; ballot-based compaction inside a wave, wave counts through LDS.
+  int ntile_hits = 0;
+  for (int t0 = 0; t0 < ntiles16; t0 += kG2Threads) {
+    const int t = t0 + threadIdx.x;
+    const bool hit = t < ntiles16 && reaches(load_box(tilebox, fl * ntiles16 + t));
     const unsigned long long m = __ballot(hit);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
-    float wsum = bnd;  // fixed butterfly: deterministic
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
-    if (lane == 0) {
-      wcount[wave] = __popcll(m);
-      wbound[wave] = wsum;
-    }
+    if (lane == 0) wcount[wave] = __popcll(m);
     __syncthreads();
-    int base = nhit;
+    int base = ntile_hits;
 #pragma unroll
     for (int w = 0; w < kG2Waves; ++w) {
       if (w < wave) base += wcount[w];
-      nhit += wcount[w];
-      bsum += wbound[w];
+      ntile_hits += wcount[w];
     }
-    // listed as the cell's pixel origin (row << 16 | column): the division happens once per cell
-    if (hit && base + before < kMaxHit)
-      hitlist[base + before] = (((c / ncx) * kCellRows) << 16) | ((c % ncx) * kCellCols);
+    if (hit && base + before < kMaxTileHit) tilehits[base + before] = t;
     __syncthreads();
   }
-  // fixed-point scale: bsum bounds the magnitude of ANY texel sum (bilinear weights are <= 1);
-  // scale = 2^(29 - floor(log2 bsum)) keeps |sum| * scale < 2^30
-  const int eB = (int)((__float_as_uint(bsum) >> 23) & 0xffu) - 127;
-  const int es = min(29 - eB, 126);
-  const float scale = __uint_as_float((unsigned)(127 + es) << 23);
-  const float inv_scale = __uint_as_float((unsigned)(127 - es) << 23);
+  // ---- level 2: the cells of those tiles whose own box reaches S, and the sums of their
+  // contribution bounds (fixed butterfly, fixed wave order: deterministic).
+  int nhit = 0;
+  float bsum_rgb = 0.0f, bsum_a = 0.0f;
+  const bool listed = ntile_hits <= kMaxTileHit;
+  if (listed) {
+    constexpr int kCellsPerTile = kLdsTile / kCellRows;
+    const int ncy = ncells / ncx;
+    const float cell_rows = (float)kCellRows;  // K1 publishes a bound of a 16-pixel row sum
+    const int ncand = ntile_hits * kCellsPerTile;
+    for (int i0 = 0; i0 < ncand; i0 += kG2Threads) {
+      const int i = i0 + threadIdx.x;
+      bool hit = false;
+      float brgb = 0.0f, ba = 0.0f;
+      int org = 0;
+      if (i < ncand) {
+        const int t = tilehits[i / kCellsPerTile];
+        const int crow = (t / ncx) * kCellsPerTile + i % kCellsPerTile, ccol = t % ncx;  // ntx16 == ncx
+        if (crow < ncy) {
+          const int c = crow * ncx + ccol;
+          hit = reaches(load_box(cellbox, fl * ncells + c));
+          if (hit) {
+            const unsigned e = cellbound[fl * ncells + c];
+            brgb = __uint_as_float((e & 0xffu) << 23) * cell_rows;
+            ba = __uint_as_float(((e >> 8) & 0xffu) << 23) * cell_rows;
+            org = ((crow * kCellRows) << 16) | (ccol * kCellCols);  // pixel origin of the cell
+          }
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        brgb += __shfl_xor(brgb, d, kWave);
+        ba += __shfl_xor(ba, d, kWave);
+      }
+      if (lane == 0) {
+        wcount[wave] = __popcll(m);
+        wbound[2 * wave] = brgb;
+        wbound[2 * wave + 1] = ba;
+      }
+      __syncthreads();
+      int base = nhit;
+#pragma unroll
+      for (int w = 0; w < kG2Waves; ++w) {
+        if (w < wave) base += wcount[w];
+        nhit += wcount[w];
+        bsum_rgb += wbound[2 * w];
+        bsum_a += wbound[2 * w + 1];
+      }
+      if (hit && base + before < kMaxHit) hitlist[base + before] = org;
+      __syncthreads();
+    }
+  } else {
+    // violent warp (more tiles reach S than the list holds): bounds over every cell that reaches S
+    for (int c0 = 0; c0 < ncells; c0 += kG2Threads) {
+      const int c = c0 + threadIdx.x;
+      float brgb = 0.0f, ba = 0.0f;
+      if (c < ncells && reaches(load_box(cellbox, fl * ncells + c))) {
+        const unsigned e = cellbound[fl * ncells + c];
+        brgb = __uint_as_float((e & 0xffu) << 23) * (float)kCellRows;
+        ba = __uint_as_float(((e >> 8) & 0xffu) << 23) * (float)kCellRows;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        brgb += __shfl_xor(brgb, d, kWave);
+        ba += __shfl_xor(ba, d, kWave);
+      }
+      if (lane == 0) {
+        wbound[2 * wave] = brgb;
+        wbound[2 * wave + 1] = ba;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < kG2Waves; ++w) {
+        bsum_rgb += wbound[2 * w];
+        bsum_a += wbound[2 * w + 1];
+      }
+      __syncthreads();
+    }
+    nhit = kMaxHit + 1;
+  }
+  // fixed-point scales: a bound B of the magnitude of ANY texel sum of the group (bilinear weights
+  // are <= 1); scale = 2^(29 - floor(log2 B)) keeps |sum| * scale < 2^30
+  auto scale_exp = [](float b) {
+    const int eB = (int)((__float_as_uint(b) >> 23) & 0xffu) - 127;
+    return min(29 - eB, 126);
+  };
+  const int es_rgb = scale_exp(bsum_rgb), es_a = scale_exp(bsum_a);
+  const float scale_rgb = __uint_as_float((unsigned)(127 + es_rgb) << 23);
+  const float scale_a = __uint_as_float((unsigned)(127 + es_a) << 23);
+  const float inv_rgb = __uint_as_float((unsigned)(127 - es_rgb) << 23);
+  const float inv_a = __uint_as_float((unsigned)(127 - es_a) << 23);
+  // an infinity / NaN in a listed cell (exponent 255 from K1) or bounds that overflow: the sums
+  // cannot be represented -- the tile becomes NaN, as loud as the reference's gradient would be
+  const bool poison = !(bsum_rgb < __builtin_huge_valf()) || !(bsum_a < __builtin_huge_valf());
   const float* gplane = grad_rgb + f * 3 * HW;
   const float4* rcp = rec + fl * HW;
 
-  if (bsum > 0.0f) {
+  if ((bsum_rgb > 0.0f || bsum_a > 0.0f) && !poison) {
     if (nhit <= kMaxHit) {
       // candidates: 128 pixels per listed cell; a wave takes 4 rows x 16 columns of one cell.
       // Two candidates per thread are in flight (ping-pong A / B; deeper rings measured slower):
@@ -208,7 +299,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
             t = finish_taps(tc, H, W);
           }
           splat_pixel(img, lane, any, t, make_float4(k.rc.z, k.rc.w, k.rc.x, k.rc.y), k.g0, k.g1, k.g2,
-                      scale, sx0, sy0);
+                      scale_rgb, scale_a, sx0, sy0);
         }
       };
       Cand ka, kb;
@@ -225,8 +316,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     } else {
       // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
       for (int c = 0; c < ncells; ++c) {
-        const int4 ob = load_box(cellbox, fl * ncells + c);
-        const bool hit = ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
+        const bool hit = reaches(load_box(cellbox, fl * ncells + c));
         if (!hit || threadIdx.x >= kCellPix) continue;
         const int py = (c / ncx) * kCellRows + (threadIdx.x >> 4);
         const int px = (c % ncx) * kCellCols + (threadIdx.x & 15);
@@ -236,7 +326,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           const float4 rec = make_float4(rc.z, rc.w, rc.x, rc.y);
           const Taps t = make_taps(rec.z, rec.w, H, W);
           splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
-                      scale, sx0, sy0);
+                      scale_rgb, scale_a, sx0, sy0);
         }
       }
     }
@@ -244,6 +334,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   __syncthreads();
   // ---- S is ours alone: plain row-coalesced stores (zeros included)
   float* gbase = grad_layers + fl * 4 * HW;
+  const float qnan = __builtin_nanf("");
   if ((W & 3) == 0) {  // 16 bytes per lane: four texels of a row (rows are 16-byte aligned)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -255,8 +346,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
+          const float inv = c < 3 ? inv_rgb : inv_a;
           *reinterpret_cast<f32x4*>(gbase + c * HW + doff) =
-              (f32x4){(float)v[0] * inv_scale, (float)v[1] * inv_scale, (float)v[2] * inv_scale, (float)v[3] * inv_scale};
+              poison ? (f32x4){qnan, qnan, qnan, qnan}
+                     : (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv};
         }
       }
     }
@@ -268,12 +361,13 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const unsigned doff = (unsigned)(__mul24(y, W) + x);
       const int li = (e >> 6) * kPitch + (e & 63);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * inv_scale;
+      for (int c = 0; c < 4; ++c)
+        (gbase + c * HW)[doff] = poison ? qnan : (float)img[c * kPlane + li] * (c < 3 ? inv_rgb : inv_a);
     }
   }
 }
 
-void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
+void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox, const int* tilebox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
@@ -281,8 +375,8 @@ void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
   dim3 grid((unsigned)xcd_grid(F, (int64_t)L * nsx * nsy));
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
                      reinterpret_cast<const float4*>(rec),
-                     grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
-                     ncx * ncy);
+                     grad_rgb, cellbox, tilebox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
+                     ncx * ncy, ncx * ((H + kLdsTile - 1) / kLdsTile));
 }
 
 }  // namespace waldo

@@ -12,8 +12,9 @@ import torch
 class GraphedCall:
     """Captures ``fn(*inputs)`` (forward only, fixed shapes) and replays it.
 
-    ``inputs`` are copied into static buffers on every call; the returned tensors are the graph's
-    static outputs (clone them if they must survive the next call)."""
+    ``inputs`` are copied into static buffers on every call (``self.inputs``: pass those themselves
+    to skip the copy); the returned tensors are the graph's static outputs (clone them if they must
+    survive the next call)."""
 
     def __init__(self, fn, *example_inputs, warmup=3):
         self._static = [x.clone() if torch.is_tensor(x) else x for x in example_inputs]
@@ -23,6 +24,7 @@ class GraphedCall:
             for _ in range(warmup):  # allocator / lazy-init work must not happen during capture
                 fn(*self._static)
         torch.cuda.current_stream().wait_stream(side)
+        self.inputs = tuple(self._static)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph), torch.no_grad():
             self._out = fn(*self._static)
@@ -35,6 +37,7 @@ class GraphedCall:
                 if dst.shape != src.shape or dst.dtype != src.dtype:
                     raise ValueError(f"graphed call was captured for {tuple(dst.shape)} {dst.dtype}, "
                                      f"got {tuple(src.shape)} {src.dtype}")
-                dst.copy_(src)
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
         self._graph.replay()
         return self._out
