@@ -82,6 +82,35 @@ __device__ __forceinline__ TapCore tap_core(float gx, float gy, int Hi, int Wi) 
   return c;
 }
 
+// ---------------------------------------------------------------------------------------
+// Pixel-unit grids.  The fused kernels evaluate the TPS grid directly in UNNORMALISED coordinates:
+//   ix = ((gx + 1) W - 1) / 2 = gx (W / 2) + (W - 1) / 2,   gx = sum_k basis_k m_k
+// by scaling the mapping column with W / 2 and adding (W - 1) / 2 to the coefficient of the
+// constant basis function (k == K3 - 3: tgt_grid_repr = [phi, 1, x, y], warp.py:36-37) -- the
+// un-normalisation of grid_sample then costs nothing per (pixel, layer).  scaled_map() is the ONE
+// definition of that operand: the MFMA kernels and the scalar chain of tps_eval() use it, so their
+// coordinates are bit-identical.  (Against the reference's two-step evaluation the coordinate
+// moves by rounding only, ~1e-5 px at 512 px -- the size of the fp32 noise of its own matmul.)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float scaled_map(float m, bool is_const_term, float half_size, float half_size_m1) {
+  return is_const_term ? fmaf(m, half_size, half_size_m1) : m * half_size;
+}
+
+// tap_core() for coordinates that are already unnormalised
+__device__ __forceinline__ TapCore tap_core_px(float ix, float iy, int Hi, int Wi) {
+  // keep the float->int conversion defined for wild / NaN coordinates; anything clamped here has
+  // all four corners outside the image anyway
+  ix = __builtin_amdgcn_fmed3f(ix, -2.0f, (float)Wi + 1.0f);
+  iy = __builtin_amdgcn_fmed3f(iy, -2.0f, (float)Hi + 1.0f);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  TapCore c;
+  c.fx = ix - x0f;
+  c.fy = iy - y0f;
+  c.x0 = (int)x0f;
+  c.y0 = (int)y0f;
+  return c;
+}
+
 // all four corners inside the layer: every validity factor is exactly 1
 __device__ __forceinline__ bool tap_interior(const TapCore& c, int Hi, int Wi) {
   return (unsigned)c.x0 < (unsigned)(Wi - 1) && (unsigned)c.y0 < (unsigned)(Hi - 1);
@@ -120,6 +149,10 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Hi, int Wi) {
   return finish_taps(tap_core(gx, gy, Hi, Wi), Hi, Wi);
 }
 
+__device__ __forceinline__ Taps make_taps_px(float ix, float iy, int Hi, int Wi) {
+  return finish_taps(tap_core_px(ix, iy, Hi, Wi), Hi, Wi);
+}
+
 // round(x) to int32 in one instruction (floor(x + 0.5); __float2int_rn is v_rndne + v_cvt)
 __device__ __forceinline__ int cvt_round(float x) {
   int r;
@@ -131,10 +164,18 @@ __device__ __forceinline__ float ldb(const float* __restrict__ base, uint32_t by
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// Bilinear value in the "lerp" form, top + fy (bot - top) with top = v00 + fx (v01 - v00), on the
+// corner values times their validity: the same number as the four-weight sum of grid_sample up to
+// rounding, in 6 operations per channel instead of 8, and the ONE form every kernel of the fused
+// path uses (the LDS-staged kernels evaluate it on packed channel pairs: bit-identical).
 __device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const Taps& t) {
-  float v00 = ldb(plane, t.o00), v01 = ldb(plane, t.o01);
-  float v10 = ldb(plane, t.o10), v11 = ldb(plane, t.o11);
-  return fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
+  const float p00 = ldb(plane, t.o00), p01 = ldb(plane, t.o01);
+  const float p10 = ldb(plane, t.o10), p11 = ldb(plane, t.o11);
+  const float v00 = p00 * (t.vx0 * t.vy0), v01 = p01 * (t.vx1 * t.vy0);
+  const float v10 = p10 * (t.vx0 * t.vy1), v11 = p11 * (t.vx1 * t.vy1);
+  const float top = fmaf(t.fx, v01 - v00, v00);
+  const float bot = fmaf(t.fx, v11 - v10, v10);
+  return fmaf(t.fy, bot - top, top);
 }
 
 // sample + partial derivatives w.r.t. the UNNORMALISED coordinates (ix, iy)
@@ -148,7 +189,7 @@ __device__ __forceinline__ float tap_sample_d(const float* __restrict__ plane, c
   float bot = fmaf(t.fx, v11 - v10, v10);
   ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
   ddy = bot - top;
-  return fmaf(p11, t.w11, fmaf(p10, t.w10, fmaf(p01, t.w01, p00 * t.w00)));
+  return fmaf(t.fy, ddy, top);
 }
 
 // ---------------------------------------------------------------------------------------

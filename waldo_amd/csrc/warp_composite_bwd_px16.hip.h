@@ -4,10 +4,11 @@
 // Restates, for one (frame, tile), the backward of TPSWarp -> F.grid_sample -> reduce_comp
 // (models/modules/warp.py:57-64, models/nets/lvd.py:100-114 and the autograd the reference gets
 // for them) and leaves, for the splat kernel (K2, warp_composite_splat.hip):
-//   * one 16-byte record (grid x, grid y, a'_l, d loss / d s_l3) per (frame, layer, pixel);
-//   * the footprint table: per 8 x 16-pixel CELL and per 16 x 16-pixel TILE the bounding box of
-//     the source texels its bilinear footprints touch, and per cell the exponents of an upper
-//     bound of its contribution magnitudes (colour planes and alpha plane separately);
+//   * one 16-byte record (grid x, grid y in pixel units, a'_l, d loss / d s_l3) per (frame, layer,
+//     pixel);
+//   * the footprint table: per 8 x 16-pixel CELL the bounding box of the source texels its
+//     bilinear footprints touch and the exponents of an upper bound of its contribution
+//     magnitudes (colour planes and alpha plane separately);
 //   * the control-point gradient of the tile (f32 MFMA contraction basis^T x grid-grad) as a
 //     per-tile partial that a small reduce kernel sums in a fixed order.
 // Data movement:
@@ -21,39 +22,11 @@
 //     the image (violent warp) is gathered from memory instead;
 //   * the tile OWNS its cells of the footprint table: plain stores, no atomics, no memset.
 // The 4 L tap derivatives of a pixel are parked in LDS between sampling and the composite backward
-// (registers at L == 12, where the LDS rows would leave one workgroup per CU).
+// (L <= 8; in registers above, where the LDS rows would leave one workgroup per CU).
 #pragma once
 // included at the end of warp_composite_kernels.hip.h, after warp_composite_fwd_lds.hip.h
 
 namespace waldo {
-
-struct BoxTaps {
-  float w00, w01, w10, w11;      // corner weights, identical to Taps
-  float fx, fy;                  // fractional parts
-  float v00, v01, v10, v11;      // 1 / 0 validity of the corners
-  int xb, yb;                    // origin of the 2x2 block that is read (inside the layer)
-  int cs, rs;                    // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
-};
-
-__device__ __forceinline__ BoxTaps make_box_taps(const TapCore& tc, int Hi, int Wi) {
-  const Taps t = finish_taps(tc, Hi, Wi);
-  BoxTaps p;
-  p.w00 = t.w00;
-  p.w01 = t.w01;
-  p.w10 = t.w10;
-  p.w11 = t.w11;
-  p.fx = t.fx;
-  p.fy = t.fy;
-  p.v00 = t.vx0 * t.vy0;
-  p.v01 = t.vx1 * t.vy0;
-  p.v10 = t.vx0 * t.vy1;
-  p.v11 = t.vx1 * t.vy1;
-  p.xb = min(max(t.x0, 0), Wi - 2);
-  p.yb = min(max(t.y0, 0), Hi - 2);
-  p.cs = t.x0 - p.xb;
-  p.rs = t.y0 - p.yb;
-  return p;
-}
 
 __device__ __forceinline__ int pk_max_u16(int a, int b) {
   typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -73,11 +46,14 @@ template <int LP>
 struct Px16Cfg {
   static constexpr int K3 = kGmapK3, KS = (K3 + 3) / 4;
   static constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  static constexpr bool kPark = LP != 12;        // tap derivatives in LDS instead of registers
+  // tap derivatives parked in LDS (L <= 8) or kept in registers / scratch: above 8 layers the LDS
+  // rows would leave ONE workgroup per CU, and at one wave per SIMD hipcc 7.2 allocates AGPRs as
+  // extra registers and reads MFMA results back wrong through them (see warp_composite_fwd_lds.hip.h)
+  static constexpr bool kPark = LP <= 8;
   static constexpr int PP1 = kBlock + 1;         // pitch of the per-pixel columns (gg, park)
   static constexpr int BP = 21;                  // pitch of the transposed basis [pixel][k]
   static constexpr int kBtFloats = kWave * BP;   // one wave's slice of it
-  static constexpr int kImgFloats = 2 * 4 * kStageCap;           // two buffers of four channel planes
+  static constexpr int kImgFloats = 2 * kImgBufFloats;           // two buffers of two pair planes
   static constexpr int kTFloats = 4 * kWave * TP;                // transposition slices of the grid
   static constexpr int kGgFloats = GGC * PP1;                    // grid gradients (MFMA B operand)
   static constexpr int kAccFloats = 4 * 2 * NT * 256;            // per-wave MFMA accumulators
@@ -103,7 +79,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
-    float4* __restrict__ rec, int* __restrict__ cellbox, int* __restrict__ tilebox,
+    float4* __restrict__ rec, int* __restrict__ cellbox,
     unsigned* __restrict__ cellbound, float* __restrict__ gmap_partial, float* __restrict__ grad_occ,
     int F, int Lrt, int H, int W, int frames_per_block, int ntx, int ntiles, int nchunks, int ncx,
     int ncells) {
@@ -157,11 +133,15 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
   }
   __syncthreads();
 
+  // pixel-unit grid: the MFMA column of this lane is an x column (even) or a y column (odd)
+  const float half_size = 0.5f * (float)((arow & 1) ? H : W);
+  const float half_size_m1 = 0.5f * (float)(((arow & 1) ? H : W) - 1);
   const int f0 = chunk * frames_per_block;
   const int f1 = min(F, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
     const float* oc = occ + (int64_t)f * L * L;
-    // ---- (A) TPS grid of every layer on the matrix pipe (see warp_composite_fwd_lds_kernel):
+    // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (see
+    // warp_composite_fwd_lds_kernel):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
     f32x4 acc[4][NT];
 #pragma unroll
@@ -178,7 +158,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         for (int nt = 0; nt < NT; ++nt) {
           const int col = nt * 16 + arow, l = col >> 1;
           const float m = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
-          bv[nt] = (k < K3 && l < L) ? m : 0.0f;
+          bv[nt] = (k < K3 && l < L) ? scaled_map(m, k == K3 - 3, half_size, half_size_m1) : 0.0f;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -227,9 +207,9 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     }
     __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
     // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 turn the range of "their" column
-    // (layer, xy) into block origins -- per cell of the footprint table and for the whole tile
-    // (this tile owns both entries: plain stores in the splat kernel's format (min x, -max x,
-    // min y, -max y)); the tile's box is also the one that is staged (corners to SGPRs)
+    // (layer, xy) into block origins -- per cell of the footprint table (this tile owns its cells:
+    // plain stores in the splat kernel's format (min x, -max x, min y, -max y)) and for the whole
+    // tile (the box that is staged; corners to SGPRs)
     int bx0[LP], by0[LP], bw[LP], bh[LP];
     bool fits[LP];
     {
@@ -260,10 +240,6 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             *reinterpret_cast<int2*>(bb) = make_int2(lo_c, -hi_c);
           }
         }
-        if (wave == 1 && kk == 0 && l2 < L) {
-          int* bb = tilebox + (((int64_t)f * L + l2) * ntiles + tile) * 4 + (arow & 1) * 2;
-          *reinterpret_cast<int2*>(bb) = make_int2(lo_t[nt], -hi_t[nt]);
-        }
       }
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
@@ -286,30 +262,29 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     float a[LP], G[LP];
     float dxr[kPark ? 1 : LP], dxa[kPark ? 1 : LP], dyr[kPark ? 1 : LP], dya[kPark ? 1 : LP];
 
-    // ---- (E) staged sampling with derivatives.  Wave w moves channel plane w of a layer's box,
-    // 16 bytes per lane; a rolling window of kAhead layers is in flight (the load of layer l + kAhead
-    // is issued when layer l leaves its registers for LDS); the image is double-buffered, one
-    // barrier per layer.
+    // ---- (E) staged sampling with derivatives.  Waves 2q / 2q + 1 move the two halves of channel
+    // pair q of a layer's box, 16 bytes per lane and plane, interleaved as float2 texels (see
+    // warp_composite_fwd_lds_kernel); a rolling window of kAhead layers is in flight (the load of
+    // layer l + kAhead is issued when layer l leaves its registers for LDS); the image is
+    // double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
-    constexpr int kItems = kStageCap / 4 / kWave;
-    f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
+    const int pairq = wave >> 1, item_l = lane + (wave & 1) * kWave;
+    StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
+      const float* src = layers + (((int64_t)f * L + lc) * 4 + 2 * pairq) * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
       const int bw4 = bw[l] >> 2, n = fits[l] ? bh[l] * bw4 : 1;
       const int ox = fits[l] ? __mul24(by0[l], W) + bx0[l] : 0;
       // item, bw4 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
       const float rcp = __builtin_amdgcn_rcpf((float)bw4);
-#pragma unroll
-      for (int j = 0; j < kItems; ++j) {
-        const int item = min(lane + j * kWave, n - 1);
-        const int r = (int)(((float)item + 0.5f) * rcp);
-        const int xg = item - r * bw4;
-        const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-        stg[l][j] = *reinterpret_cast<const f32x4*>(src + off);
-      }
+      const int item = min(item_l, n - 1);
+      const int r = (int)(((float)item + 0.5f) * rcp);
+      const int xg = item - r * bw4;
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
+      stg[l].a = *reinterpret_cast<const f32x4*>(src + off);
+      stg[l].b = *reinterpret_cast<const f32x4*>(src + HW + off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -329,57 +304,59 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         }
         if (fits[l]) {
           const int n = bh[l] * (bw[l] >> 2);
-          f32x4* dst = reinterpret_cast<f32x4*>(img + ((l & 1) * 4 + wave) * kStageCap);
-#pragma unroll
-          for (int j = 0; j < kItems; ++j) {
-            const int item = lane + j * kWave;
-            if (item < n) dst[item] = stg[l][j];  // row-major with pitch bw: item = r * bw4 + xg
-          }
+          if (item_l < n)  // row-major with pitch bw: item = r * bw4 + xg
+            stage_store(img + (l & 1) * kImgBufFloats + pairq * kPairFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
-        const TapCore tc = tap_core(gxs[l], gys[l], H, W);
-        const float* b0 = img + (l & 1) * 4 * kStageCap;
+        const TapCore tc = tap_core_px(gxs[l], gys[l], H, W);
+        const float* b0 = img + (l & 1) * kImgBufFloats;
         float sv[4], sx[4], sy[4];
         if (!fits[l]) {  // box larger than the LDS image (violent warp): gather straight from memory
           const Taps tg = finish_taps(tc, H, W);
           const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
           for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, tg, sx[c], sy[c]);
-        } else if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
-          // wave-uniform: all corners inside the layer, every validity factor is exactly 1
-          const float wx0 = 1.0f - tc.fx, wy0 = 1.0f - tc.fy;
-          const float w00 = wx0 * wy0, w01 = tc.fx * wy0, w10 = wx0 * tc.fy, w11 = tc.fx * tc.fy;
-          const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float* pc = b0 + c * kStageCap + idx;
-            const float p00 = pc[0], p01 = pc[1], p10 = pc[bw[l]], p11 = pc[bw[l] + 1];
-            const float top = fmaf(tc.fx, p01 - p00, p00);
-            const float bot = fmaf(tc.fx, p11 - p10, p10);
-            sx[c] = fmaf(tc.fy, (p11 - p10) - (p01 - p00), p01 - p00);
-            sy[c] = bot - top;
-            sv[c] = fmaf(p11, w11, fmaf(p10, w10, fmaf(p01, w01, p00 * w00)));
-          }
         } else {
-          const BoxTaps t = make_box_taps(tc, H, W);
-          // inside the box by construction; the clamp only matters for NaN coordinates
-          const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+          PairBlock pb;
+          float fx, fy;
+          if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
+            // wave-uniform: all corners inside the layer, every validity factor is exactly 1
+            const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
+            pb = read_block(b0, idx, bw[l]);
+            fx = tc.fx;
+            fy = tc.fy;
+          } else {
+            const BoxTaps t = make_box_taps(tc, H, W);
+            // inside the box by construction; the clamp only matters for NaN coordinates
+            const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+            pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float* pc = b0 + c * kStageCap + idx;
-            const float a0 = pc[0], b0v = pc[1], a1 = pc[bw[l]], b1v = pc[bw[l] + 1];
-            // rows: block row 0/1 -> corner rows y0 / y0+1 (rs = y0 - yb)
-            const float ta = t.rs > 0 ? a1 : a0, tb = t.rs > 0 ? b1v : b0v;  // corner row y0
-            const float ua = t.rs < 0 ? a0 : a1, ub = t.rs < 0 ? b0v : b1v;  // corner row y0 + 1
-            const float p00 = t.cs > 0 ? tb : ta, p01 = t.cs < 0 ? ta : tb;
-            const float p10 = t.cs > 0 ? ub : ua, p11 = t.cs < 0 ? ua : ub;
-            const float v00 = p00 * t.v00, v01 = p01 * t.v01, v10 = p10 * t.v10, v11 = p11 * t.v11;
-            const float top = fmaf(t.fx, v01 - v00, v00);
-            const float bot = fmaf(t.fx, v11 - v10, v10);
-            sx[c] = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
-            sy[c] = bot - top;
-            sv[c] = fmaf(p11, t.w11, fmaf(p10, t.w10, fmaf(p01, t.w01, p00 * t.w00)));
+            for (int q = 0; q < 2; ++q) {
+              pb.p00[q] = pb.p00[q] * t.v00;
+              pb.p01[q] = pb.p01[q] * t.v01;
+              pb.p10[q] = pb.p10[q] * t.v10;
+              pb.p11[q] = pb.p11[q] * t.v11;
+            }
+            fx = t.fx;
+            fy = t.fy;
+          }
+          // value and derivatives w.r.t. the pixel coordinates, two channels per instruction
+          const f32x2_t fx2 = {fx, fx}, fy2 = {fy, fy};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x2_t d0 = pb.p01[q] - pb.p00[q], d1 = pb.p11[q] - pb.p10[q];
+            const f32x2_t top = __builtin_elementwise_fma(fx2, d0, pb.p00[q]);
+            const f32x2_t bot = __builtin_elementwise_fma(fx2, d1, pb.p10[q]);
+            const f32x2_t dy = bot - top;
+            const f32x2_t dx = __builtin_elementwise_fma(fy2, d1 - d0, d0);
+            const f32x2_t v = __builtin_elementwise_fma(fy2, dy, top);
+            sv[2 * q] = v[0];
+            sv[2 * q + 1] = v[1];
+            sx[2 * q] = dx[0];
+            sx[2 * q + 1] = dx[1];
+            sy[2 * q] = dy[0];
+            sy[2 * q + 1] = dy[1];
           }
         }
         a[l] = (sv[3] + 1.0f) * 0.5f;

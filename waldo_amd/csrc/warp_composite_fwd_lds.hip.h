@@ -17,10 +17,21 @@
 // barrier per layer).  A box that does not fit the LDS image (violent warp) falls back to
 // gathering that layer straight from memory.
 //
-// Tap pairs: instead of clamping the four corners separately, a pixel reads the 2x2 block at
+// The kernel is VALU-issue bound, so the per-(pixel, layer) arithmetic is kept minimal:
+//  * the grid comes out of the MFMA chain already in PIXEL units (scaled_map(): the
+//    un-normalisation of grid_sample is folded into the B operand);
+//  * the staged image keeps the channels of a texel in PAIRS, (c0, c1) and (c2, c3) interleaved
+//    as float2 -- waves 0 / 1 stage the two halves of pair 0's box (each lane loads the same four
+//    texels of both planes and writes them interleaved), waves 2 / 3 pair 1 -- so a tap arrives as
+//    one 8-byte LDS read that is already a packed-fp32 operand: four ds_read2_b64 and twelve
+//    v_pk_* instructions per (pixel, layer) in the bilinear "lerp" form
+//    top + fy (bot - top), top = p00 + fx (p01 - p00), instead of sixteen fmas on four corner
+//    weights (same value up to rounding).
+//
+// Tap blocks: instead of clamping the four corners separately, a pixel reads the 2x2 block at
 // (xb, yb) = clamp((x0, y0), 0, (W-2, H-2)), which lies inside the layer; the block's cells are
 // re-assigned to the corners when x0 / y0 was clamped (only within one texel of the border), and
-// corners outside the layer carry zero weight exactly as in make_taps().
+// corners outside the layer are multiplied by a validity of 0 exactly as in tap_sample().
 #pragma once
 // included at the end of warp_composite_kernels.hip.h (uses its tps_eval / pixel_of / opaque)
 
@@ -30,19 +41,22 @@ namespace waldo {
 #define WALDO_STAGE_AHEAD 4  // layers whose box loads are in flight at a time
 #endif
 
-struct PairTaps {
-  float w00, w01, w10, w11;  // corner weights, identical to Taps
-  int xb, yb;                // origin of the 2x2 block that is read (inside the layer)
-  int cs, rs;                // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
+struct BoxTaps {
+  float fx, fy;                  // fractional parts
+  float v00, v01, v10, v11;      // 1 / 0 validity of the corners
+  int xb, yb;                    // origin of the 2x2 block that is read (inside the layer)
+  int cs, rs;                    // x0 - xb, y0 - yb: 0 in the interior, +-1 at a clamped border
 };
 
-__device__ __forceinline__ PairTaps make_pair_taps(const TapCore& tc, int Hi, int Wi) {
+__device__ __forceinline__ BoxTaps make_box_taps(const TapCore& tc, int Hi, int Wi) {
   const Taps t = finish_taps(tc, Hi, Wi);
-  PairTaps p;
-  p.w00 = t.w00;
-  p.w01 = t.w01;
-  p.w10 = t.w10;
-  p.w11 = t.w11;
+  BoxTaps p;
+  p.fx = t.fx;
+  p.fy = t.fy;
+  p.v00 = t.vx0 * t.vy0;
+  p.v01 = t.vx1 * t.vy0;
+  p.v10 = t.vx0 * t.vy1;
+  p.v11 = t.vx1 * t.vy1;
   p.xb = min(max(t.x0, 0), Wi - 2);
   p.yb = min(max(t.y0, 0), Hi - 2);
   p.cs = t.x0 - p.xb;
@@ -50,13 +64,77 @@ __device__ __forceinline__ PairTaps make_pair_taps(const TapCore& tc, int Hi, in
   return p;
 }
 
-// first texel column / row of the 2x2 block a coordinate reads: the xb / yb of make_pair_taps
+// first texel column / row of the 2x2 block a coordinate reads: the xb / yb of make_box_taps
 // (same instruction chain; monotonic in c, so the block origins of a set of pixels lie between
 // the origins of the set's smallest and largest coordinate)
-__device__ __forceinline__ int block_origin(float c, int size) {
-  float i = unnormalize(c, size);
-  i = fminf(fmaxf(i, -2.0f), (float)size + 1.0f);
+__device__ __forceinline__ int block_origin(float i, int size) {  // i: pixel units
+  i = __builtin_amdgcn_fmed3f(i, -2.0f, (float)size + 1.0f);
   return min(max((int)floorf(i), 0), size - 2);
+}
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---- staged image of one layer's footprint box: two pair planes of float2 texels, row-major with
+// pitch bw; pair q starts kPairFloats further.  Item = four consecutive texels of a row.
+constexpr int kPairFloats = 2 * kStageCap;      // one pair plane: kStageCap texels x 2 channels
+constexpr int kImgBufFloats = 2 * kPairFloats;  // one layer image
+
+// the lane's staging loads of layer `src` (channel plane 2q, then 2q + 1) for box item `item`
+struct StageRegs {
+  f32x4_t a, b;
+};
+
+__device__ __forceinline__ void stage_store(float* pairplane, int item, const StageRegs& r) {
+  f32x4_t* dst = reinterpret_cast<f32x4_t*>(pairplane + 8 * item);
+  dst[0] = (f32x4_t){r.a[0], r.b[0], r.a[1], r.b[1]};
+  dst[1] = (f32x4_t){r.a[2], r.b[2], r.a[3], r.b[3]};
+}
+
+// the four taps of both channel pairs at texel index idx (row-major, pitch bw) of a layer image
+struct PairBlock {
+  f32x2_t p00[2], p01[2], p10[2], p11[2];  // [pair]
+};
+
+__device__ __forceinline__ PairBlock read_block(const float* imgbuf, int idx, int bw) {
+  PairBlock b;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x2_t* r0 = reinterpret_cast<const f32x2_t*>(imgbuf + q * kPairFloats + 2 * idx);
+    const f32x2_t* r1 = r0 + bw;
+    b.p00[q] = r0[0];
+    b.p01[q] = r0[1];
+    b.p10[q] = r1[0];
+    b.p11[q] = r1[1];
+  }
+  return b;
+}
+
+// the block was read at the clamped origin (xb, yb); re-assign its cells to the corners of the
+// footprint when x0 / y0 was clamped (cs = x0 - xb, rs = y0 - yb: 0 in the interior, +-1 within
+// one texel of the border; corners outside the layer carry zero weight / validity)
+__device__ __forceinline__ PairBlock assign_corners(const PairBlock& raw, int cs, int rs) {
+  PairBlock o;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x2_t a0 = raw.p00[q], b0 = raw.p01[q], a1 = raw.p10[q], b1 = raw.p11[q];
+    const f32x2_t ta = rs > 0 ? a1 : a0, tb = rs > 0 ? b1 : b0;  // corner row y0
+    const f32x2_t ua = rs < 0 ? a0 : a1, ub = rs < 0 ? b0 : b1;  // corner row y0 + 1
+    o.p00[q] = cs > 0 ? tb : ta;
+    o.p01[q] = cs < 0 ? ta : tb;
+    o.p10[q] = cs > 0 ? ub : ua;
+    o.p11[q] = cs < 0 ? ua : ub;
+  }
+  return o;
+}
+
+// bilinear value of a pair in the lerp form
+__device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, const f32x2_t p10,
+                                         const f32x2_t p11, float fx, float fy) {
+  const f32x2_t fx2 = {fx, fx}, fy2 = {fy, fy};
+  const f32x2_t top = __builtin_elementwise_fma(fx2, p01 - p00, p00);
+  const f32x2_t bot = __builtin_elementwise_fma(fx2, p11 - p10, p10);
+  return __builtin_elementwise_fma(fy2, bot - top, top);
 }
 
 // At least 2 waves per SIMD (<= 256 VGPRs) for every LP: with 1 (LP >= 24 wants ~310 registers)
@@ -71,7 +149,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  constexpr int kImgFloats = 2 * 4 * kStageCap;  // two buffers of four channel planes
+  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of two pair planes
   constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
@@ -109,10 +187,13 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
   }
   __syncthreads();
 
+  // pixel-unit grid: the MFMA column of this lane is an x column (even) or a y column (odd)
+  const float half_size = 0.5f * (float)((arow & 1) ? H : W);
+  const float half_size_m1 = 0.5f * (float)(((arow & 1) ? H : W) - 1);
   const int f0 = chunk * frames_per_block;
   const int f1 = min(F, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
-    // ---- (A) TPS grid of every layer on the matrix pipe:
+    // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (scaled_map):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
     f32x4 acc[4][NT];
 #pragma unroll
@@ -128,7 +209,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
       for (int nt = 0; nt < NT; ++nt) {
         const int col = nt * 16 + arow, l = col >> 1;
         const float m = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
-        bv[nt] = (k < K3 && l < L) ? m : 0.0f;
+        bv[nt] = (k < K3 && l < L) ? scaled_map(m, k == K3 - 3, half_size, half_size_m1) : 0.0f;
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -205,31 +286,32 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
       bh[l] = ymax - ymin + 1;
     }
 
-    // ---- (E) staging: wave w moves channel plane w of a layer's box, 16 bytes per lane.  A
-    // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
-    // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
-    // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
+    // ---- (E) staging: waves 2q / 2q + 1 move the two halves of channel pair q of a layer's box,
+    // 16 bytes per lane and plane.  A rolling window of kAhead layers is in flight (the load of
+    // layer l + kAhead is issued when layer l leaves its registers for LDS): memory latency is
+    // exposed once per frame; then each layer goes registers -> LDS -> taps; the image is
+    // double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
-    constexpr int kItems = kStageCap / 4 / kWave;
+    static_assert(kStageCap / 4 == 2 * kWave, "one box item per lane of a wave pair");
+    const int pairq = wave >> 1, item_l = lane + (wave & 1) * kWave;
     float s[LP][4];
-    f32x4 stg[LP][kItems];  // fully unrolled: a layer's registers live from its load to its LDS store
+    StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + (((int64_t)f * L + lc) * 4 + wave) * HW;
+      const float* src = layers + (((int64_t)f * L + lc) * 4 + 2 * pairq) * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
       const bool fits = bh[l] * bw[l] <= kStageCap;
       const int bw4 = bw[l] >> 2, n = fits ? bh[l] * bw4 : 1;
       const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
-      const float rcp = 1.0f / (float)bw4;
-#pragma unroll
-      for (int j = 0; j < kItems; ++j) {
-        const int item = min(lane + j * kWave, n - 1);
-        const int r = (int)(((float)item + 0.5f) * rcp);  // item, bw4 < 2^9: exact
-        const int xg = item - r * bw4;
-        const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-        stg[l][j] = *reinterpret_cast<const f32x4*>(src + off);
-      }
+      // item, bw4 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
+      const float rcp = __builtin_amdgcn_rcpf((float)bw4);
+      const int item = min(item_l, n - 1);
+      const int r = (int)(((float)item + 0.5f) * rcp);
+      const int xg = item - r * bw4;
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
+      stg[l].a = *reinterpret_cast<const f32x4*>(src + off);
+      stg[l].b = *reinterpret_cast<const f32x4*>(src + HW + off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -244,48 +326,36 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
         const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
         if (fits) {
           const int n = bh[l] * (bw[l] >> 2);
-          f32x4* dst = reinterpret_cast<f32x4*>(img + ((l & 1) * 4 + wave) * kStageCap);
-#pragma unroll
-          for (int j = 0; j < kItems; ++j) {
-            const int item = lane + j * kWave;
-            if (item < n) dst[item] = stg[l][j];  // row-major with pitch bw: item = r * bw4 + xg
-          }
+          if (item_l < n)  // row-major with pitch bw: item = r * bw4 + xg
+            stage_store(img + (l & 1) * kImgBufFloats + pairq * kPairFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
-          const TapCore tc = tap_core(gx[l], gy[l], H, W);
-          const float* b0 = img + (l & 1) * 4 * kStageCap;
+          const TapCore tc = tap_core_px(gx[l], gy[l], H, W);
+          const float* b0 = img + (l & 1) * kImgBufFloats;
+          f32x2_t sv[2];
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
-            // wave-uniform: all corners inside the layer, every validity factor is exactly 1 --
-            // the weights are those of make_taps() without the (v_cmp, v_cndmask, v_mul) per corner
-            const float wx0 = 1.0f - tc.fx, wy0 = 1.0f - tc.fy;
-            const float w00 = wx0 * wy0, w01 = tc.fx * wy0, w10 = wx0 * tc.fy, w11 = tc.fx * tc.fy;
+            // wave-uniform: all corners inside the layer, every validity factor is exactly 1
             const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
+            const PairBlock pb = read_block(b0, idx, bw[l]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float* pc = b0 + c * kStageCap + idx;
-              const float v00 = pc[0], v01 = pc[1], v10 = pc[bw[l]], v11 = pc[bw[l] + 1];
-              s[l][c] = fmaf(v11, w11, fmaf(v10, w10, fmaf(v01, w01, v00 * w00)));
-            }
+            for (int q = 0; q < 2; ++q) sv[q] = lerp2(pb.p00[q], pb.p01[q], pb.p10[q], pb.p11[q], tc.fx, tc.fy);
           } else {
-            const PairTaps t = make_pair_taps(tc, H, W);
+            const BoxTaps t = make_box_taps(tc, H, W);
             // inside the box by construction; the clamp only matters for NaN coordinates
             const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+            const PairBlock pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float* pc = b0 + c * kStageCap + idx;
-              const float a0 = pc[0], b0v = pc[1], a1 = pc[bw[l]], b1v = pc[bw[l] + 1];
-              // rows: block row 0/1 -> corner rows y0 / y0+1 (rs = y0 - yb)
-              const float ta = t.rs > 0 ? a1 : a0, tb = t.rs > 0 ? b1v : b0v;  // corner row y0
-              const float ua = t.rs < 0 ? a0 : a1, ub = t.rs < 0 ? b0v : b1v;  // corner row y0 + 1
-              const float v00 = t.cs > 0 ? tb : ta, v01 = t.cs < 0 ? ta : tb;
-              const float v10 = t.cs > 0 ? ub : ua, v11 = t.cs < 0 ? ua : ub;
-              s[l][c] = fmaf(v11, t.w11, fmaf(v10, t.w10, fmaf(v01, t.w01, v00 * t.w00)));
-            }
+            for (int q = 0; q < 2; ++q)
+              sv[q] = lerp2(pb.p00[q] * t.v00, pb.p01[q] * t.v01, pb.p10[q] * t.v10, pb.p11[q] * t.v11, t.fx, t.fy);
           }
+          s[l][0] = sv[0][0];
+          s[l][1] = sv[0][1];
+          s[l][2] = sv[1][0];
+          s[l][3] = sv[1][1];
         } else {  // box larger than the LDS image (violent warp): gather straight from memory
-          const Taps t = make_taps(gx[l], gy[l], H, W);
+          const Taps t = make_taps_px(gx[l], gy[l], H, W);
           const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
           for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t);

@@ -51,18 +51,21 @@ __device__ __forceinline__ void load_basis(float (&bas)[K3P], const float* __res
   }
 }
 
-// map: (K3,2) wave-uniform.  Sequential fmaf chain in k: the ONE definition of the grid that
-// forward, bounding-box pre-pass and backward share (bit-identical coordinates).
+// map: (K3,2) wave-uniform.  Sequential fmaf chain in k over the pixel-unit operands of
+// scaled_map(): the ONE definition of the grid that every kernel of the fused path shares (the
+// MFMA kernels accumulate the same products in the same order: bit-identical coordinates).
 template <int K3P, bool EXK>
 __device__ __forceinline__ void tps_eval(const float (&bas)[K3P], const float* __restrict__ map,
-                                         int K3, float& gx, float& gy) {
-  gx = 0.0f;
-  gy = 0.0f;
+                                         int K3, int H, int W, float& ix, float& iy) {
+  ix = 0.0f;
+  iy = 0.0f;
+  const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+  const float ow = 0.5f * (float)(W - 1), oh = 0.5f * (float)(H - 1);
 #pragma unroll
   for (int k = 0; k < K3P; ++k) {
     const int kc = EXK ? k : min(k, K3 - 1);  // bas[k] == 0 beyond K3
-    gx = fmaf(bas[k], map[2 * kc], gx);
-    gy = fmaf(bas[k], map[2 * kc + 1], gy);
+    ix = fmaf(bas[k], scaled_map(map[2 * kc], kc == K3 - 3, hw, ow), ix);
+    iy = fmaf(bas[k], scaled_map(map[2 * kc + 1], kc == K3 - 3, hh, oh), iy);
   }
 }
 
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 17 ? 2 : 1))) void wa
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
       const int lc = EXL ? l : min(l, L - 1);  // padding layers re-read layer L-1, then masked
-      float gx, gy;
-      tps_eval<K3P, EXK>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, gx, gy);
-      const Taps t = make_taps(gx, gy, H, W);
+      float ix, iy;
+      tps_eval<K3P, EXK>(bas, mapping + ((int64_t)f * L + lc) * K3 * 2, K3, H, W, ix, iy);
+      const Taps t = make_taps_px(ix, iy, H, W);
       const float* base = layers + ((int64_t)f * L + lc) * 4 * HW;
 #pragma unroll
       for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t);
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 #pragma unroll
   for (int l = 0; l < LP; ++l) {
     if (l < L) {
-      tps_eval<K3P, false>(bas, mapping + ((int64_t)f * L + l) * K3 * 2, K3, gxs[l], gys[l]);
-      Taps t = make_taps(gxs[l], gys[l], H, W);
+      tps_eval<K3P, false>(bas, mapping + ((int64_t)f * L + l) * K3 * 2, K3, H, W, gxs[l], gys[l]);
+      Taps t = make_taps_px(gxs[l], gys[l], H, W);
       const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
       for (int c = 0; c < 4; ++c) s[l][c] = tap_sample_d(base + c * HW, t, dsx[l][c], dsy[l][c]);
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 #pragma unroll
   for (int l = 0; l < LP; ++l) {
     if (l < L) {
-      Taps t = make_taps(gxs[l], gys[l], H, W);
+      Taps t = make_taps_px(gxs[l], gys[l], H, W);
       float* gbase = grad_layers + ((int64_t)f * L + l) * 4 * HW;
       float gix = 0.0f, giy = 0.0f;
 #pragma unroll
@@ -395,7 +398,7 @@ static __global__ __launch_bounds__(kBlock) void warp_composite_gmap_reduce_kern
 }
 
 // K2 (compiled once, warp_composite_splat.hip)
-void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox, const int* tilebox,
+void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st);
 
@@ -486,12 +489,11 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   const Bwd2Layout lo = bwd2_layout(F, L, H, W);
   char* ws = reinterpret_cast<char*>(workspace);
   int* boxes = reinterpret_cast<int*>(ws);
-  int* tboxes = reinterpret_cast<int*>(ws + lo.box_bytes);
-  unsigned* bounds = reinterpret_cast<unsigned*>(ws + lo.box_bytes + lo.tbox_bytes);
-  float4* rec = reinterpret_cast<float4*>(ws + lo.box_bytes + lo.tbox_bytes + lo.bound_bytes);
+  unsigned* bounds = reinterpret_cast<unsigned*>(ws + lo.box_bytes);
+  float4* rec = reinterpret_cast<float4*>(ws + lo.box_bytes + lo.bound_bytes);
   float* part = grad_mapping == nullptr
                     ? nullptr
-                    : reinterpret_cast<float*>(ws + lo.box_bytes + lo.tbox_bytes + lo.bound_bytes + lo.rec_bytes);
+                    : reinterpret_cast<float*>(ws + lo.box_bytes + lo.bound_bytes + lo.rec_bytes);
   using T = std::true_type;
   using N = std::false_type;
   const int ntiles = lo.ntiles16;
@@ -501,7 +503,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   auto go = [&](auto exl, auto gocc) {
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
     hipLaunchKernelGGL((warp_composite_bwd_px16_kernel<LP, EXL, GOCC>), grid, dim3(kBlock), 0, st, layers,
-                       basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, tboxes, bounds, part,
+                       basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
                        grad_occ, F, L, H, W, fpb, lo.ntx16, ntiles, nchunks, lo.ncx, lo.ncells);
   };
   if (L == LP) {
@@ -514,8 +516,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     hipLaunchKernelGGL(warp_composite_gmap_reduce_kernel, dim3((unsigned)((int64_t)F * groups)), dim3(kBlock),
                        0, st, part, grad_mapping, F, L, ntiles, groups);
   }
-  launch_splat(reinterpret_cast<const float*>(rec), grad_rgb, boxes, tboxes, bounds, grad_layers, F, L,
-               H, W, st);
+  launch_splat(reinterpret_cast<const float*>(rec), grad_rgb, boxes, bounds, grad_layers, F, L, H, W, st);
 }
 
 }  // namespace waldo

@@ -18,12 +18,12 @@ constexpr int kStageCap = 512;                 // texels per channel plane of a 
 inline int64_t round256(int64_t b) { return ((b + 255) / 256) * 256; }
 __host__ __device__ constexpr int64_t gmap_partial_floats(int L) { return (int64_t)L * kGmapK3 * 2; }
 
-// ---- two-kernel backward: [cell boxes | tile boxes | cell bounds | records (grid x, grid y, a',
-//                           g_alpha: 16 B) | partials]
+// ---- two-kernel backward: [cell boxes | cell bounds | records (grid x, grid y, a', g_alpha: 16 B) |
+//                           partials]
 // The pixel kernel (K1) runs on 16 x 16-pixel tiles; a tile covers kLdsTile / kCellRows cells of
 // one table column.
 struct Bwd2Layout {
-  int64_t box_bytes, tbox_bytes, bound_bytes, rec_bytes, part_bytes, total;
+  int64_t box_bytes, bound_bytes, rec_bytes, part_bytes, total;
   int ntx16, ntiles16;    // 16 x 16 tiles
   int ncx, ncells;
 };
@@ -48,11 +48,10 @@ inline Bwd2Layout bwd2_layout(int64_t F, int L, int H, int W) {
   o.ncx = (W + kCellCols - 1) / kCellCols;
   o.ncells = o.ncx * ((H + kCellRows - 1) / kCellRows);
   o.box_bytes = round256(F * L * o.ncells * 16);
-  o.tbox_bytes = round256(F * L * o.ntiles16 * 16);
   o.bound_bytes = round256(F * L * o.ncells * 4);
   o.rec_bytes = 2 * round256(F * L * (int64_t)H * W * 8);
   o.part_bytes = round256(F * o.ntiles16 * gmap_partial_floats(L) * 4);
-  o.total = o.box_bytes + o.tbox_bytes + o.bound_bytes + o.rec_bytes + o.part_bytes;
+  o.total = o.box_bytes + o.bound_bytes + o.rec_bytes + o.part_bytes;
   return o;
 }
 

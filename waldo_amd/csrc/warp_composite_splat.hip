@@ -3,7 +3,7 @@
 // Restates the input-gradient of F.grid_sample (bilinear, zeros, align_corners=False) -- the
 // four-corner scatter of grad * weight that the reference gets from autograd through
 // models/nets/lvd.py:548,559 -- for the records the pixel kernel (K1) left behind:
-//   records (grid x, grid y, a'_l, g_alpha) per (frame, layer, pixel); the contribution of pixel p
+//   records (grid x, grid y in PIXEL units, a'_l, g_alpha) per (frame, layer, pixel); the contribution of pixel p
 //   to channel c < 3 of layer l is a'_l * grad_rgb[c][p], to the alpha channel g_alpha.
 //
 // One workgroup OWNS one 32x64-texel tile S of one layer's gradient plane: it is the only writer
@@ -16,9 +16,6 @@
 // the taps that fall into S in a 32-bit FIXED-POINT LDS image: integer LDS atomics run at the
 // plain ds_write rate on gfx950 while ds_add_f32 retires ~3 cycles per lane
 // (tools_dev/lds_atomic_bench*.hip); integer sums are also order-independent.
-//
-// The table is scanned in two levels: the boxes of K1's 16x16-pixel tiles first (one per thread at
-// the headline shape), then only the cells of the tiles that reach S.
 //
 // Precision contract (also in include/waldo_hip.h): a tile's sums are exact integers of a quantum
 // 2^-s per channel GROUP (the three colour planes share one scale, the alpha plane has its own),
@@ -40,8 +37,7 @@ static_assert((1 << kCellShift) == kCellPix, "cell rows: 4, 8 or 16");
 constexpr int kG2Waves = 8;
 constexpr int kG2Threads = kG2Waves * kWave;          // 512
 constexpr int kMaxHit = 192 * 8 / kCellRows;         // cells listed per tile (else: slow scan)
-constexpr int kMaxTileHit = 128;                      // 16x16 tiles of K1 listed per S (else: slow scan)
-static_assert(kCellCols == kLdsTile, "a K1 tile spans one column of cells");
+constexpr int kScanPer = 2;                           // cells per thread and trip of the table scan
 
 __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
   const int4 r = reinterpret_cast<const int4*>(cellbox)[idx];
@@ -100,9 +96,9 @@ __device__ __forceinline__ bool touches(const TapCore& t, int sx0, int sy0) {
 
 __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     const float4* __restrict__ rec, const float* __restrict__ grad_rgb,
-    const int* __restrict__ cellbox, const int* __restrict__ tilebox,
-    const unsigned* __restrict__ cellbound, float* __restrict__ grad_layers, int F, int L, int H,
-    int W, int nsx, int nstiles, int ncx, int ncells, int ntiles16) {
+    const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
+    float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int ncx,
+    int ncells) {
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   // a FRAME is pinned to one XCD, source-tile-major inside it: the L layer planes of one source
@@ -118,12 +114,11 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
-  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + kMaxTileHit + 3 * kG2Waves + 4];
+  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + (kScanPer + 2) * kG2Waves + 4];
   int* img = lds;
   int* hitlist = lds + 4 * kPlane;
-  int* tilehits = hitlist + kMaxHit;
-  int* wcount = tilehits + kMaxTileHit;                 // hits per wave (current chunk)
-  float* wbound = reinterpret_cast<float*>(wcount + kG2Waves);  // [wave][rgb, alpha]
+  int* wcount = hitlist + kMaxHit;                      // [cell of the trip][wave]: hits
+  float* wbound = reinterpret_cast<float*>(wcount + kScanPer * kG2Waves);  // [wave][rgb, alpha]
 
   {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -134,106 +129,64 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   auto reaches = [&](const int4 ob) {
     return ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
   };
-  // ---- level 1: the 16x16-pixel tiles of K1 whose box reaches S, in tile order.  Chunks of
-  // kG2Threads tiles; ballot-based compaction inside a wave, wave counts through LDS.
-  int ntile_hits = 0;
-  for (int t0 = 0; t0 < ntiles16; t0 += kG2Threads) {
-    const int t = t0 + threadIdx.x;
-    const bool hit = t < ntiles16 && reaches(load_box(tilebox, fl * ntiles16 + t));
-    const unsigned long long m = __ballot(hit);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wcount[wave] = __popcll(m);
-    __syncthreads();
-    int base = ntile_hits;
-#pragma unroll
-    for (int w = 0; w < kG2Waves; ++w) {
-      if (w < wave) base += wcount[w];
-      ntile_hits += wcount[w];
-    }
-    if (hit && base + before < kMaxTileHit) tilehits[base + before] = t;
-    __syncthreads();
-  }
-  // ---- level 2: the cells of those tiles whose own box reaches S, and the sums of their
-  // contribution bounds (fixed butterfly, fixed wave order: deterministic).
+  // ---- cells whose box reaches S, listed in cell order, and the sums of their contribution
+  // bounds (fixed butterfly, fixed wave order: deterministic).  kScanPer cells per thread and
+  // trip -- their loads are independent and in flight together, one barrier pair per
+  // kScanPer * kG2Threads cells (one trip at 256x512); ballot-based compaction inside a wave.
   int nhit = 0;
   float bsum_rgb = 0.0f, bsum_a = 0.0f;
-  const bool listed = ntile_hits <= kMaxTileHit;
-  if (listed) {
-    constexpr int kCellsPerTile = kLdsTile / kCellRows;
-    const int ncy = ncells / ncx;
-    const float cell_rows = (float)kCellRows;  // K1 publishes a bound of a 16-pixel row sum
-    const int ncand = ntile_hits * kCellsPerTile;
-    for (int i0 = 0; i0 < ncand; i0 += kG2Threads) {
-      const int i = i0 + threadIdx.x;
-      bool hit = false;
-      float brgb = 0.0f, ba = 0.0f;
-      int org = 0;
-      if (i < ncand) {
-        const int t = tilehits[i / kCellsPerTile];
-        const int crow = (t / ncx) * kCellsPerTile + i % kCellsPerTile, ccol = t % ncx;  // ntx16 == ncx
-        if (crow < ncy) {
-          const int c = crow * ncx + ccol;
-          hit = reaches(load_box(cellbox, fl * ncells + c));
-          if (hit) {
-            const unsigned e = cellbound[fl * ncells + c];
-            brgb = __uint_as_float((e & 0xffu) << 23) * cell_rows;
-            ba = __uint_as_float(((e >> 8) & 0xffu) << 23) * cell_rows;
-            org = ((crow * kCellRows) << 16) | (ccol * kCellCols);  // pixel origin of the cell
-          }
-        }
-      }
-      const unsigned long long m = __ballot(hit);
-      const int before = __popcll(m & ((1ull << lane) - 1ull));
+  const float cell_rows = (float)kCellRows;  // K1 publishes a bound of a 16-pixel row sum
+  for (int c0 = 0; c0 < ncells; c0 += kScanPer * kG2Threads) {
+    bool hit[kScanPer];
+    unsigned eb[kScanPer];
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        brgb += __shfl_xor(brgb, d, kWave);
-        ba += __shfl_xor(ba, d, kWave);
+    for (int u = 0; u < kScanPer; ++u) {
+      const int c = min(c0 + u * kG2Threads + (int)threadIdx.x, ncells - 1);  // unconditional loads
+      hit[u] = c0 + u * kG2Threads + (int)threadIdx.x < ncells && reaches(load_box(cellbox, fl * ncells + c));
+      eb[u] = cellbound[fl * ncells + c];
+    }
+    float brgb = 0.0f, ba = 0.0f;
+    int cnt[kScanPer];
+#pragma unroll
+    for (int u = 0; u < kScanPer; ++u) {
+      if (hit[u]) {
+        brgb += __uint_as_float((eb[u] & 0xffu) << 23) * cell_rows;
+        ba += __uint_as_float(((eb[u] >> 8) & 0xffu) << 23) * cell_rows;
       }
-      if (lane == 0) {
-        wcount[wave] = __popcll(m);
-        wbound[2 * wave] = brgb;
-        wbound[2 * wave + 1] = ba;
-      }
-      __syncthreads();
+      const unsigned long long m = __ballot(hit[u]);
+      cnt[u] = __popcll(m);
+      if (lane == 0) wcount[u * kG2Waves + wave] = cnt[u];
+      cnt[u] = __popcll(m & ((1ull << lane) - 1ull));  // hits of this wave before this lane
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      brgb += __shfl_xor(brgb, d, kWave);
+      ba += __shfl_xor(ba, d, kWave);
+    }
+    if (lane == 0) {
+      wbound[2 * wave] = brgb;
+      wbound[2 * wave + 1] = ba;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kScanPer; ++u) {
       int base = nhit;
 #pragma unroll
       for (int w = 0; w < kG2Waves; ++w) {
-        if (w < wave) base += wcount[w];
-        nhit += wcount[w];
-        bsum_rgb += wbound[2 * w];
-        bsum_a += wbound[2 * w + 1];
+        if (w < wave) base += wcount[u * kG2Waves + w];
+        nhit += wcount[u * kG2Waves + w];
       }
-      if (hit && base + before < kMaxHit) hitlist[base + before] = org;
-      __syncthreads();
+      // listed as the cell's pixel origin (row << 16 | column): the division happens once per cell
+      const int c = c0 + u * kG2Threads + (int)threadIdx.x;
+      if (hit[u] && base + cnt[u] < kMaxHit)
+        hitlist[base + cnt[u]] = (((c / ncx) * kCellRows) << 16) | ((c % ncx) * kCellCols);
     }
-  } else {
-    // violent warp (more tiles reach S than the list holds): bounds over every cell that reaches S
-    for (int c0 = 0; c0 < ncells; c0 += kG2Threads) {
-      const int c = c0 + threadIdx.x;
-      float brgb = 0.0f, ba = 0.0f;
-      if (c < ncells && reaches(load_box(cellbox, fl * ncells + c))) {
-        const unsigned e = cellbound[fl * ncells + c];
-        brgb = __uint_as_float((e & 0xffu) << 23) * (float)kCellRows;
-        ba = __uint_as_float(((e >> 8) & 0xffu) << 23) * (float)kCellRows;
-      }
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        brgb += __shfl_xor(brgb, d, kWave);
-        ba += __shfl_xor(ba, d, kWave);
-      }
-      if (lane == 0) {
-        wbound[2 * wave] = brgb;
-        wbound[2 * wave + 1] = ba;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int w = 0; w < kG2Waves; ++w) {
-        bsum_rgb += wbound[2 * w];
-        bsum_a += wbound[2 * w + 1];
-      }
-      __syncthreads();
+    for (int w = 0; w < kG2Waves; ++w) {
+      bsum_rgb += wbound[2 * w];
+      bsum_a += wbound[2 * w + 1];
     }
-    nhit = kMaxHit + 1;
+    __syncthreads();
   }
   // fixed-point scales: a bound B of the magnitude of ANY texel sum of the group (bilinear weights
   // are <= 1); scale = 2^(29 - floor(log2 B)) keeps |sum| * scale < 2^30
@@ -281,7 +234,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
       };
       auto splat = [&](const Cand& k) {
-        const TapCore tc = tap_core(k.rc.x, k.rc.y, H, W);
+        const TapCore tc = tap_core_px(k.rc.x, k.rc.y, H, W);
         const bool any = k.livep && touches(tc, sx0, sy0);
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
         if (__ballot(any) != 0ull) {
@@ -324,7 +277,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           const unsigned p = (unsigned)(__mul24(py, W) + px);
           const float4 rc = rcp[p];
           const float4 rec = make_float4(rc.z, rc.w, rc.x, rc.y);
-          const Taps t = make_taps(rec.z, rec.w, H, W);
+          const Taps t = make_taps_px(rec.z, rec.w, H, W);
           splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
                       scale_rgb, scale_a, sx0, sy0);
         }
@@ -367,7 +320,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   }
 }
 
-void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox, const int* tilebox,
+void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
                   const unsigned* cellbound, float* grad_layers, int F, int L, int H, int W,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
@@ -375,8 +328,8 @@ void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox, c
   dim3 grid((unsigned)xcd_grid(F, (int64_t)L * nsx * nsy));
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
                      reinterpret_cast<const float4*>(rec),
-                     grad_rgb, cellbox, tilebox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
-                     ncx * ncy, ncx * ((H + kLdsTile - 1) / kLdsTile));
+                     grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
+                     ncx * ncy);
 }
 
 }  // namespace waldo
