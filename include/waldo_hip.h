@@ -174,6 +174,13 @@ int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float
  *   rgb      (F,3,H,W)  out, in [-1,1]
  *   alpha    (F,L,H,W)  out, composited alpha in [-1,1]; may be NULL (not written)
  * K3 <= 32, L <= waldo_max_layers().
+ * Padding: taps outside a layer contribute 0 (grid_sample's zeros padding on the raw values, i.e.
+ * delta = 0 in the notation of A4: alpha 0.5 / grey after the (x + 1) / 2 of reduce_comp).  The
+ * reference's layer_to_output shifts by delta = 1 so that out-of-range taps read -1 (alpha 0): a
+ * caller that needs that behaviour at the image border composes waldo_grid_sample2d (delta = 1)
+ * with waldo_occ_composite instead of this entry point.
+ * Coordinates: the grid is evaluated directly in pixel units (the mapping column scaled by W/2 or
+ * H/2 inside the kernels), which moves a sample position by rounding only (~1e-5 px at 512 px).
  * ------------------------------------------------------------------------------------- */
 int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const float* mapping,
                              const float* occ, float* rgb, float* alpha, int64_t F, int L, int H,
@@ -181,10 +188,19 @@ int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const fl
 /* Backward of the above.
  *   grad_rgb (F,3,H,W); grad_alpha (F,L,H,W) or NULL;
  *   workspace: scratch of at least waldo_warp_composite_bwd_workspace_bytes() bytes (256-byte
- *       aligned, contents irrelevant).  Non-NULL selects the two-kernel path (K3 == 19, L <= 8:
- *       pixel kernel + per-source-tile gather, no global atomics, bitwise reproducible
+ *       aligned, contents irrelevant).  Non-NULL selects the two-kernel path (K3 == 19, L <= 17,
+ *       4 | W: pixel kernel + per-source-tile gather, no global atomics, bitwise reproducible
  *       grad_layers / grad_mapping); NULL -- and every other shape, for which the size query
  *       returns 0 -- selects the generic per-tap-atomics kernel.
+ *   Precision of grad_layers on the two-kernel path: every 32x64-texel tile of a layer's gradient
+ *       is summed in 32-bit FIXED POINT, one power-of-two quantum for its three colour planes and
+ *       one for its alpha plane, chosen from an upper bound of the tile's sums so that nothing can
+ *       overflow: quantum ~ 2^-17 of the largest possible sum of the group in that tile.  The
+ *       error of a texel is therefore ABSOLUTE per tile and group (a few quanta), not relative to
+ *       the texel: gradients several orders of magnitude below their tile's largest lose relative
+ *       precision (the generic path keeps fp32 relative precision).  An infinity or NaN among the
+ *       contributions that can reach a tile turns that whole tile (all four planes) into NaN --
+ *       never into finite garbage.
  *   grad_layers (F,L,4,H,W): with a workspace it is OVERWRITTEN (every texel written once);
  *       without, it must be ZERO-FILLED by the caller (accumulated with float atomics);
  *   grad_mapping (F*L,K3,2): must be ZERO-FILLED by the caller (accumulated into); NULL to skip;

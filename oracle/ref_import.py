@@ -103,7 +103,7 @@ def load():
         TPSWarp=warp.TPSWarp, InverseWarp=warp.InverseWarp, kernel_distance=warp.kernel_distance,
         Warper=lvd.Warper, LVD=lvd.LVD, gather_time=lvd.gather_time, scale=lvd.scale,
         WIF=wif.WIF, UNet=conv.UNet, get_grid=utils.get_grid,
-        get_gaussian_kernel=utils.get_gaussian_kernel, _orig_cuda=orig_cuda)
+        get_gaussian_kernel=utils.get_gaussian_kernel, expand=utils.expand, _orig_cuda=orig_cuda)
     _cache["ns"] = ns
     # keep the stubs out of the way of real imports done later by the test session
     for k in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.io",

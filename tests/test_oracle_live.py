@@ -118,3 +118,24 @@ def test_wif_forward_against_reference(ns):
     v = vid.permute(0, 2, 1, 3, 4, 5)
     out = lin(v.reshape(b * t * tc, c, h, w)).reshape(b, t, tc, 5, h, w)
     close(ref, WO.wif_fuse(v, out), 1e-6)
+
+
+def test_expand_equals_reference_bit_for_bit(ns):
+    """tools/utils.py:300-323 against the product's restatement (waldo_amd/tools/utils.py): hard and
+    soft masks, every `dir`, several rounds -- and the product must leave its argument alone."""
+    from waldo_amd.tools.utils import expand
+    torch.manual_seed(5)
+    hard = (torch.rand(2, 3, 17, 23) > 0.9).float()
+    soft = torch.rand(2, 1, 19, 21) * (torch.rand(2, 1, 19, 21) > 0.8)
+    for d in (None, "south", "north", "east", "west"):
+        for num in (1, 2, 5):
+            keep = hard.clone()
+            assert torch.equal(expand(hard, num, dir=d), ns.expand(hard.clone(), num, dir=d))
+            assert torch.equal(hard, keep)
+            keep = soft.clone()
+            assert torch.equal(expand(soft, num, dir=d, soft=True), ns.expand(soft.clone(), num, dir=d, soft=True))
+            assert torch.equal(soft, keep)
+    b = hard.bool()
+    keep = b.clone()
+    expand(b, 3)
+    assert torch.equal(b, keep)

@@ -46,12 +46,15 @@ def corrected(kernel_sub, width):
     return tot
 per = {
     "waldo_warp_composite_fwd": corrected("warp_composite_fwd_lds_kernel", "16B") + corrected("warp_composite_fwd_kernel", "4B"),
-    "waldo_warp_composite_bwd": corrected("warp_composite_bwd_px16_kernel", "16B") + corrected("warp_composite_bwd_px_kernel", "4B")
-                                + corrected("warp_composite_splat_kernel", "8B") + corrected("gmap_reduce", "4B"),
+    "waldo_warp_composite_bwd": corrected("warp_composite_bwd_px16_kernel", "16B")
+                                + corrected("warp_composite_splat_kernel", "16B") + corrected("gmap_reduce", "4B"),
 }
+per_kernel = {k.split("<")[0].split("::")[-1]: {c: raw[c].get(k, 0.0) * 1024.0 * calib.get("16B", {}).get(c, 1.0) for c in raw}
+              for k in set(raw["FETCH_SIZE"]) | set(raw["WRITE_SIZE"]) if "waldo::warp" in k}
+res["bytes_per_dispatch_by_kernel"] = per_kernel
 res.update(frames=112, layers=8, height=256, width=512, bytes_per_launch=per,
-           note="fwd = LDS-staged kernel (16-byte box loads); bwd = staged pixel kernel (16-byte box loads, "
-                "8-byte record stores) + gather splat (8-byte records) + partial reduce; workspace records "
-                "written by K1 and re-read by K2 are real HBM traffic of this design")
+           note="fwd = LDS-staged kernel (16-byte box loads); bwd = pixel kernel K1 (16-byte box loads, 16-byte "
+                "record stores) + splat K2 (16-byte record loads) + partial reduce; workspace records written "
+                "by K1 and re-read by K2 are real HBM traffic of this design")
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

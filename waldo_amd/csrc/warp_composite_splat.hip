@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     for (int u = 0; u < kScanPer; ++u) {
       const int c = min(c0 + u * kG2Threads + (int)threadIdx.x, ncells - 1);  // unconditional loads
       hit[u] = c0 + u * kG2Threads + (int)threadIdx.x < ncells && reaches(load_box(cellbox, fl * ncells + c));
-      eb[u] = cellbound[fl * ncells + c];
+      eb[u] = hit[u] ? cellbound[fl * ncells + c] : 0u;
     }
     float brgb = 0.0f, ba = 0.0f;
     int cnt[kScanPer];
@@ -287,7 +287,17 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   __syncthreads();
   // ---- S is ours alone: plain row-coalesced stores (zeros included)
   float* gbase = grad_layers + fl * 4 * HW;
-  const float qnan = __builtin_nanf("");
+  if (poison) {  // block-uniform
+    const float qnan = __builtin_nanf("");
+    for (int e = threadIdx.x; e < kSrcTex; e += kG2Threads) {
+      const int y = sy0 + (e >> 6), x = sx0 + (e & 63);
+      if (y < H && x < W) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) (gbase + c * HW)[(unsigned)(__mul24(y, W) + x)] = qnan;
+      }
+    }
+    return;
+  }
   if ((W & 3) == 0) {  // 16 bytes per lane: four texels of a row (rows are 16-byte aligned)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -301,8 +311,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
           const float inv = c < 3 ? inv_rgb : inv_a;
           *reinterpret_cast<f32x4*>(gbase + c * HW + doff) =
-              poison ? (f32x4){qnan, qnan, qnan, qnan}
-                     : (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv};
+              (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv};
         }
       }
     }
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const int li = (e >> 6) * kPitch + (e & 63);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        (gbase + c * HW)[doff] = poison ? qnan : (float)img[c * kPlane + li] * (c < 3 ? inv_rgb : inv_a);
+        (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * (c < 3 ? inv_rgb : inv_a);
     }
   }
 }

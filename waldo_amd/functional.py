@@ -429,7 +429,12 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
 
     layers (F, L, 4, H, W) in [-1, 1]; src_pts (F*L, N, 2); occ (F, L, L);
     inverse_kernel (N+3, N+3); basis_t (N+3, H*W).  Returns rgb (F, 3, H, W) and, if asked,
-    the composited alpha (F, L, H, W), both in [-1, 1]."""
+    the composited alpha (F, L, H, W), both in [-1, 1].
+
+    Taps outside a layer contribute 0 (delta = 0): this is the BASELINE pipeline, not
+    a drop-in for ``Warper.layer_to_output`` (delta = 1: out-of-range taps read -1, i.e. alpha 0)
+    followed by ``reduce_comp`` -- at the image border use ``grid_sample(..., delta=1)`` +
+    ``occ_composite`` for that.  Precision / NaN contract of the backward: include/waldo_hip.h."""
     mapping = tps_mapping(inverse_kernel, src_pts)
     f, nl = layers.shape[:2]
     chunk = _frames_per_call(f, nl, layers.shape[-2], layers.shape[-1], mapping.shape[1])

@@ -28,32 +28,31 @@ def get_gaussian_kernel(k, sigma_div=6):
     return g / g.sum()
 
 
+# one-pixel growth steps of expand(), in the reference's order: (name, tensor dim, shift)
+_GROW_STEPS = (("south", 2, 1), ("north", 2, -1), ("east", 3, 1), ("west", 3, -1))
+
+
 def expand(mask, num=1, dir=None, soft=False, alpha=0.97):
-    """Mask dilation of the reference (tools/utils.py:300-323): ``num`` rounds of one-pixel growth
-    to the south, north, east and west IN THAT ORDER (each direction sees the result of the
-    previous one, so a round with ``dir=None`` is a 3x3 box dilation).  Hard masks are OR-ed
-    (returned as float 0/1); ``soft`` masks take ``max(mask, alpha * neighbour)``.  Unlike the
-    reference's soft branch this does not modify its argument."""
+    """Mask dilation with the semantics of the reference's tools/utils.py:300-323: ``num`` rounds of
+    one-pixel growth towards the south, north, east and west IN THAT ORDER, each step seeing the
+    result of the previous one (a round with ``dir=None`` is a 3x3 box dilation; ``dir`` keeps one
+    step).  A step combines every pixel with its neighbour ``shift`` pixels back along the step's
+    axis: OR for hard masks (returned as float 0 / 1), ``max(pixel, alpha * neighbour)`` for
+    ``soft`` ones.  Never modifies its argument (the reference's soft branch does; so would a
+    bool input through ``.bool()``)."""
     if soft:
-        mask = mask.clone()
-        for _ in range(num):
-            if not dir or dir == "south":
-                mask[:, :, 1:, :] = torch.maximum(mask[:, :, 1:, :], alpha * mask[:, :, :-1, :])
-            if not dir or dir == "north":
-                mask[:, :, :-1, :] = torch.maximum(mask[:, :, :-1, :], alpha * mask[:, :, 1:, :])
-            if not dir or dir == "east":
-                mask[:, :, :, 1:] = torch.maximum(mask[:, :, :, 1:], alpha * mask[:, :, :, :-1])
-            if not dir or dir == "west":
-                mask[:, :, :, :-1] = torch.maximum(mask[:, :, :, :-1], alpha * mask[:, :, :, 1:])
-        return mask
-    m = mask.bool()
+        out = mask.clone()
+
+        def combine(dst, src):
+            return torch.maximum(dst, alpha * src)
+    else:
+        out = mask.to(torch.bool, copy=True)
+        combine = torch.logical_or
+    steps = [st for st in _GROW_STEPS if not dir or dir == st[0]]
     for _ in range(num):
-        if not dir or dir == "south":
-            m[:, :, 1:, :] = m[:, :, 1:, :] | m[:, :, :-1, :]
-        if not dir or dir == "north":
-            m[:, :, :-1, :] = m[:, :, :-1, :] | m[:, :, 1:, :]
-        if not dir or dir == "east":
-            m[:, :, :, 1:] = m[:, :, :, 1:] | m[:, :, :, :-1]
-        if not dir or dir == "west":
-            m[:, :, :, :-1] = m[:, :, :, :-1] | m[:, :, :, 1:]
-    return m.float()
+        for _, dim, shift in steps:
+            n = out.shape[dim] - 1
+            dst = out.narrow(dim, max(shift, 0), n)
+            src = out.narrow(dim, max(-shift, 0), n)
+            dst.copy_(combine(dst, src))  # the combination is evaluated before it is written back
+    return out if soft else out.float()
