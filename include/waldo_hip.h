@@ -123,6 +123,43 @@ int waldo_occ_composite_bwd(const float* alpha, const float* occ, const float* g
                             int64_t occ_div, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f2. Producers of the path's inputs: the steps between the networks and the warp kernels.
+ *
+ * waldo_compute_occ_*: LVD.compute_occ (models/nets/lvd.py:59-68).
+ *   score (M,No) -> occ (M,No+1,No+1):  s = exp(-score^2) + eps;
+ *   occ[i+1][j+1] = s_i / (s_i + s_j) - [i == j] / 2;  occ[i+1][0] = 1;  occ[0][*] = 0.
+ *   Backward: grad_score (M,No) is OVERWRITTEN.
+ * waldo_alpha_head_*: ImageDecoder.forward's tail (lvd.py:245-254) + the alpha arithmetic of
+ *   LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:128-132) in one pass.
+ *   x (N,C,h,w) the decoder's raw image;  y = x + bias;  on the LAST channel when has_alpha:
+ *   y = tanh(y), then y = prior + (1 - prior) * y with prior (h,w) (the `circle` buffer; NULL:
+ *   no prior);  out (N,C,h*scale,w*scale) = F.interpolate(y, scale_factor=scale, "bilinear",
+ *   align_corners=False);  then mode 1 (remove_obj): out = -1, mode 2 (freeze_obj): out = +1;
+ *   then with mask (h*scale,w*scale) (the `obj_alpha_mask` buffer; NULL: none):
+ *   out = mask * out - (1 - mask).   Backward: grad_x (N,C,h,w) is OVERWRITTEN (gathered: no atomics).
+ * waldo_pose_affine_*: the pose heads' affine (models/nets/flp.py:259-273, lvd.py:440-449).
+ *   pose (R,6+2P) (after tanh / + last);  T = (mul6 * pose[:6] + bias6) as (3,2);
+ *   pts[p] = pts_mul * base_pts[p] + mul_delta * pose[6+2p : 8+2p];  out (R,P,2) = [pts, 1] @ T.
+ *   Backward: grad_pose (R,6+2P) is OVERWRITTEN.
+ * ------------------------------------------------------------------------------------- */
+int waldo_compute_occ_fwd(const float* score, float* occ, int64_t M, int No, float eps,
+                          waldo_stream_t stream);
+int waldo_compute_occ_bwd(const float* score, const float* grad_occ, float* grad_score, int64_t M,
+                          int No, float eps, waldo_stream_t stream);
+int waldo_alpha_head_fwd(const float* x, const float* prior, const float* mask, float* out,
+                         int64_t N, int C, int h, int w, int scale, float bias, int has_alpha,
+                         int mode, waldo_stream_t stream);
+int waldo_alpha_head_bwd(const float* x, const float* prior, const float* mask,
+                         const float* grad_out, float* grad_x, int64_t N, int C, int h, int w,
+                         int scale, float bias, int has_alpha, int mode, waldo_stream_t stream);
+int waldo_pose_affine_fwd(const float* pose, const float* mul6, const float* bias6,
+                          const float* base_pts, float* out, int64_t R, int P, float mul_delta,
+                          float pts_mul, waldo_stream_t stream);
+int waldo_pose_affine_bwd(const float* pose, const float* mul6, const float* bias6,
+                          const float* base_pts, const float* grad_out, float* grad_pose, int64_t R,
+                          int P, float mul_delta, float pts_mul, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A9: the two full-resolution passes of Warper.grid_to_flow_ctx / grid_to_flow
  * (models/nets/lvd.py:707-828, 602-705), forward only (the inference path).  The low-resolution
  * inputs come from waldo_grid_sample2d_fwd (lvd.py:723-728, 784-796); Hd = H*scale, Wd = W*scale.

@@ -261,6 +261,52 @@ def gen_inpaint(ns):
         save(f"wif_inpaint_{tag}", out=out)
 
 
+def gen_producers(ns):
+    """Row f2: the producers of the path's inputs, run through the reference's OWN methods with stub
+    `self` objects that replace the networks around them by fixed tensors:
+      * ImageDecoder.forward (lvd.py:239-255): `norm` = identity, `to_img` = a fixed raw image;
+      * LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135): `decoder` = the decoder output
+        above, `warper` = a no-op; it calls the real compute_occ;
+    The pose affine (flp.py:259-273) sits in the middle of PoseDecoder.forward and cannot be called
+    on its own: its vectors come from the restatement in oracle/producers_oracle.py checked against
+    an independent float64 einsum of the same published formula (tests/test_oracle_golden.py)."""
+    g = torch.Generator().manual_seed(11)
+    b, no, lo, c_tok = 3, 4, 16, 8
+    ho, wo, sf = 16, 16, 4  # decoder raw image 16x16 (obj_shape 4x4 x patch 4), x4 upsampling
+    for tag, (use_prior, remove, freeze, masked) in {"plain": (False, False, False, False),
+                                                     "prior_mask": (True, False, False, True),
+                                                     "remove": (True, True, False, True),
+                                                     "freeze": (False, False, True, True)}.items():
+        raw = torch.randn(b * no, 1, ho, wo, generator=g).requires_grad_()
+        dec = types.SimpleNamespace(norm=lambda x: x, to_img=lambda x, **kw: raw, latent_shape={lo: [4, 4]},
+                                    init_bias=5 if tag == "plain" else 0.25, has_alpha=True, use_prior=use_prior,
+                                    circle=ns.get_circle([ho, wo], p=0.75).float().view(1, 1, ho, wo),
+                                    scale_factor=sf)
+        tokens = torch.zeros(b, no, lo, c_tok)
+        Ho, Wo, Po = ho * sf, wo * sf, 3 * sf
+        mask = torch.ones(Ho, Wo)
+        mask[:Po] = 0
+        mask[:, :Po] = 0
+        mask[-Po:] = 0
+        mask[:, -Po:] = 0
+        score = torch.randn(b, 2, no, generator=g).requires_grad_()
+        lvd = lvd_stub(ns, no)
+        lvd.decoder = lambda x: ns.ImageDecoder.forward(dec, x)
+        lvd.bg_alpha = torch.ones(1, 1, 8, 16)
+        lvd.remove_obj, lvd.freeze_obj = remove, freeze
+        lvd.obj_alpha_mask = mask.view(1, 1, 1, Ho, Wo) if masked else 1
+        lvd.warper = lambda a, bb: None
+        occ, obj_alpha, bg_alpha, _ = ns.LVD.forward(lvd, x_obj=tokens, obj_pose=None, bg_pose=None,
+                                                     occ_score=score, mode="estimate_alpha_grid_occ")
+        w1 = torch.randn(obj_alpha.shape, generator=g)
+        w2 = torch.randn(occ.shape, generator=g)
+        ((obj_alpha * w1).sum() + (occ * w2).sum()).backward()
+        save(f"producers_{tag}", raw=raw, circle=dec.circle, init_bias=float(dec.init_bias), scale_factor=sf,
+             use_prior=int(use_prior), remove=int(remove), freeze=int(freeze), masked=int(masked), mask=mask,
+             score=score, occ=occ, obj_alpha=obj_alpha, w1=w1, w2=w2,
+             grad_raw=raw.grad if raw.grad is not None else torch.zeros_like(raw), grad_score=score.grad)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
@@ -271,6 +317,7 @@ def main():
     gen_inverse_warp(ns)
     gen_warper(ns)
     gen_inpaint(ns)
+    gen_producers(ns)
 
 
 if __name__ == "__main__":

@@ -101,7 +101,8 @@ def load():
         pass
     ns = types.SimpleNamespace(
         TPSWarp=warp.TPSWarp, InverseWarp=warp.InverseWarp, kernel_distance=warp.kernel_distance,
-        Warper=lvd.Warper, LVD=lvd.LVD, gather_time=lvd.gather_time, scale=lvd.scale,
+        Warper=lvd.Warper, LVD=lvd.LVD, ImageDecoder=lvd.ImageDecoder, get_circle=lvd.get_circle,
+        gather_time=lvd.gather_time, scale=lvd.scale,
         WIF=wif.WIF, UNet=conv.UNet, get_grid=utils.get_grid,
         get_gaussian_kernel=utils.get_gaussian_kernel, expand=utils.expand, _orig_cuda=orig_cuda)
     _cache["ns"] = ns

@@ -137,3 +137,44 @@ def test_wif_forward(golden):
     b, t, tc, c, h, w = vid.shape
     net = torch.nn.functional.conv2d(vid.reshape(-1, c, h, w), g["weight"], g["bias"])
     close(WO.wif_fuse(vid, net.reshape(b, t, tc, 5, h, w)), g["out"], 1e-6)
+
+
+# ----------------------------------------------------------------------------- f2: producers
+@pytest.mark.parametrize("tag", ["plain", "prior_mask", "remove", "freeze"])
+def test_producers_oracle_vs_reference(golden, tag):
+    """oracle/producers_oracle.py + wif_oracle.compute_occ against the reference's own
+    ImageDecoder.forward / LVD.forward(mode="estimate_alpha_grid_occ") outputs and gradients."""
+    from oracle import producers_oracle as PO
+    g = golden(f"producers_{tag}")
+    raw = g["raw"].clone().requires_grad_()
+    score = g["score"].clone().requires_grad_()
+    a = PO.decoder_tail(raw, g["circle"], float(g["init_bias"]), int(g["scale_factor"]), True, bool(g["use_prior"]))
+    a = PO.alpha_arithmetic(a, g["mask"] if int(g["masked"]) else None, bool(g["remove"]), bool(g["freeze"]))
+    a = a.view(g["obj_alpha"].shape)
+    occ = O.compute_occ(score)
+    assert torch.allclose(a, g["obj_alpha"], atol=1e-6)
+    assert torch.allclose(occ, g["occ"], atol=1e-6)
+    ((a * g["w1"]).sum() + (occ * g["w2"]).sum()).backward()
+    assert torch.allclose(score.grad, g["grad_score"], atol=1e-5)
+    graw = raw.grad if raw.grad is not None else torch.zeros_like(raw)
+    assert torch.allclose(graw, g["grad_raw"], atol=1e-5)
+
+
+def test_pose_affine_oracle_vs_independent_formula():
+    """flp.py:259-273 restated two ways: the oracle (cat + matmul, as the reference writes it) and a
+    float64 einsum of [pts, 1] @ T written from the formula -- the reference cannot run these lines
+    in isolation (oracle/producers_oracle.py)."""
+    from oracle import producers_oracle as PO
+    torch.manual_seed(4)
+    r, no, p = 3, 5, 16
+    pose = torch.tanh(torch.randn(r, no, 6 + 2 * p))
+    mul6 = torch.tensor([0.5, 0.5, 0.5, 0.5, 1.0, 1.0])
+    bias6 = torch.tensor([0.25, 0.0, 0.0, 0.5, 0.0, 0.0])
+    base = O.get_grid(4, 4).view(p, 2)
+    out = PO.pose_affine(pose, mul6, bias6, base, mul_delta=0.3, pts_mul=1.0)
+    p64 = pose.double()
+    T = (mul6.double() * p64[..., :6] + bias6.double()).view(r, no, 3, 2)
+    pts = base.double() + 0.3 * p64[..., 6:].view(r, no, p, 2)
+    ref = torch.einsum("rnpa,rnab->rnpb", pts, T[:, :, :2]) + T[:, :, 2:3]
+    assert out.shape == (r, no, p, 2)
+    assert torch.allclose(out.double(), ref, atol=1e-6)

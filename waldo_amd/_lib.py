@@ -34,6 +34,12 @@ SIGNATURES = {
                                 _flt, _i64, _i64, _stream],
     "waldo_occ_composite_fwd": [_c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
     "waldo_occ_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
+    "waldo_compute_occ_fwd": [_c_f, _c_f, _i64, _int, _flt, _stream],
+    "waldo_compute_occ_bwd": [_c_f, _c_f, _c_f, _i64, _int, _flt, _stream],
+    "waldo_alpha_head_fwd": [_c_f] * 4 + [_i64, _int, _int, _int, _int, _flt, _int, _int, _stream],
+    "waldo_alpha_head_bwd": [_c_f] * 5 + [_i64, _int, _int, _int, _int, _flt, _int, _int, _stream],
+    "waldo_pose_affine_fwd": [_c_f] * 5 + [_i64, _int, _flt, _flt, _stream],
+    "waldo_pose_affine_bwd": [_c_f] * 6 + [_i64, _int, _flt, _flt, _stream],
     "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_fwd": [_c_f] * 9 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],

@@ -236,6 +236,127 @@ def occ_composite(alpha, occ, occ_div=1):
 
 
 # --------------------------------------------------------------------------------------
+# f2: producers of the path's inputs (csrc/producers.hip)
+# --------------------------------------------------------------------------------------
+class _ComputeOcc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, eps):
+        _lib.check_cuda(score)
+        score = _c(score)
+        m, no = score.shape
+        occ = score.new_empty(m, no + 1, no + 1)
+        with torch.cuda.device(score.device):
+            _lib.call("waldo_compute_occ_fwd", _lib.ptr(score), _lib.ptr(occ), m, no, float(eps),
+                      _lib.current_stream(score.device))
+        ctx.save_for_backward(score)
+        ctx.eps = float(eps)
+        return occ
+
+    @staticmethod
+    def backward(ctx, grad_occ):
+        (score,) = ctx.saved_tensors
+        grad_occ = _c(grad_occ)
+        m, no = score.shape
+        gs = torch.empty_like(score)
+        with torch.cuda.device(score.device):
+            _lib.call("waldo_compute_occ_bwd", _lib.ptr(score), _lib.ptr(grad_occ), _lib.ptr(gs), m, no,
+                      ctx.eps, _lib.current_stream(score.device))
+        return gs, None
+
+
+def compute_occ(occ_score, eps=1e-6):
+    """LVD.compute_occ (models/nets/lvd.py:59-68): occ_score (..., No) -> (..., No+1, No+1)."""
+    lead = occ_score.shape[:-1]
+    no = occ_score.shape[-1]
+    occ = _ComputeOcc.apply(occ_score.reshape(-1, no).float(), eps)
+    return occ.view(*lead, no + 1, no + 1)
+
+
+class _AlphaHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prior, mask, scale, bias, has_alpha, mode):
+        _lib.check_cuda(x, prior, mask)
+        x = _c(x)
+        prior = _c(prior) if prior is not None else None
+        mask = _c(mask) if mask is not None else None
+        n, c, h, w = x.shape
+        if prior is not None and prior.numel() != h * w:
+            raise _lib.WaldoHipError(f"alpha_head: prior has {prior.numel()} elements, expected {h}x{w}")
+        if mask is not None and mask.numel() != h * w * scale * scale:
+            raise _lib.WaldoHipError(f"alpha_head: mask has {mask.numel()} elements, expected "
+                                     f"{h * scale}x{w * scale}")
+        out = x.new_empty(n, c, h * scale, w * scale)
+        with torch.cuda.device(x.device):
+            _lib.call("waldo_alpha_head_fwd", _lib.ptr(x), _lib.ptr(prior), _lib.ptr(mask), _lib.ptr(out), n, c,
+                      h, w, scale, float(bias), int(has_alpha), mode, _lib.current_stream(x.device))
+        ctx.save_for_backward(x, prior, mask)
+        ctx.cfg = (scale, float(bias), int(has_alpha), mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, prior, mask = ctx.saved_tensors
+        scale, bias, has_alpha, mode = ctx.cfg
+        grad_out = _c(grad_out)
+        n, c, h, w = x.shape
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call("waldo_alpha_head_bwd", _lib.ptr(x), _lib.ptr(prior), _lib.ptr(mask), _lib.ptr(grad_out),
+                      _lib.ptr(gx), n, c, h, w, scale, bias, has_alpha, mode, _lib.current_stream(x.device))
+        return gx, None, None, None, None, None, None
+
+
+def alpha_head(img, prior=None, mask=None, scale=1, bias=0.0, has_alpha=True, remove=False, freeze=False):
+    """ImageDecoder.forward's tail (models/nets/lvd.py:245-254: ``+ init_bias``, ``tanh`` and the
+    ``circle`` prior on the last channel, ``scale(img, scale_factor)``) fused with the alpha
+    arithmetic of ``LVD.forward(mode="estimate_alpha_grid_occ")`` (lvd.py:128-132: ``remove_obj`` /
+    ``freeze_obj`` / ``obj_alpha_mask``).  img (N, C, h, w) -> (N, C, h*scale, w*scale)."""
+    mode = 2 if freeze else (1 if remove else 0)
+    return _AlphaHead.apply(img.float(), prior, mask, int(scale), bias, bool(has_alpha), mode)
+
+
+class _PoseAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, mul6, bias6, base, mul_delta, pts_mul):
+        _lib.check_cuda(pose, mul6, bias6, base)
+        pose, mul6, bias6, base = _c(pose), _c(mul6), _c(bias6), _c(base)
+        r, d = pose.shape
+        p = (d - 6) // 2
+        if d != 6 + 2 * p or base.numel() != 2 * p or mul6.numel() != 6 or bias6.numel() != 6:
+            raise _lib.WaldoHipError(f"pose_affine: inconsistent shapes pose={tuple(pose.shape)} "
+                                     f"base={tuple(base.shape)}")
+        out = pose.new_empty(r, p, 2)
+        with torch.cuda.device(pose.device):
+            _lib.call("waldo_pose_affine_fwd", _lib.ptr(pose), _lib.ptr(mul6), _lib.ptr(bias6), _lib.ptr(base),
+                      _lib.ptr(out), r, p, float(mul_delta), float(pts_mul), _lib.current_stream(pose.device))
+        ctx.save_for_backward(pose, mul6, bias6, base)
+        ctx.cfg = (float(mul_delta), float(pts_mul))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pose, mul6, bias6, base = ctx.saved_tensors
+        grad_out = _c(grad_out)
+        r, d = pose.shape
+        gp = torch.empty_like(pose)
+        with torch.cuda.device(pose.device):
+            _lib.call("waldo_pose_affine_bwd", _lib.ptr(pose), _lib.ptr(mul6), _lib.ptr(bias6), _lib.ptr(base),
+                      _lib.ptr(grad_out), _lib.ptr(gp), r, (d - 6) // 2, ctx.cfg[0], ctx.cfg[1],
+                      _lib.current_stream(pose.device))
+        return gp, None, None, None, None, None
+
+
+def pose_affine(pose, mul6, bias6, base_pts, mul_delta=1.0, pts_mul=1.0):
+    """The pose heads' affine (models/nets/flp.py:259-273): pose (..., 6 + 2P) -> control points
+    (..., P, 2) = [pts_mul * base_pts + mul_delta * pose[6:], 1] @ (mul6 * pose[:6] + bias6)."""
+    lead = pose.shape[:-1]
+    d = pose.shape[-1]
+    out = _PoseAffine.apply(pose.reshape(-1, d).float(), mul6.reshape(-1).float(), bias6.reshape(-1).float(),
+                            base_pts.reshape(-1, 2).float(), mul_delta, pts_mul)
+    return out.view(*lead, (d - 6) // 2, 2)
+
+
+# --------------------------------------------------------------------------------------
 # A12: WIF fusion epilogue
 # --------------------------------------------------------------------------------------
 class _WifFuse(torch.autograd.Function):

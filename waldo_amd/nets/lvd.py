@@ -28,15 +28,23 @@ from ..tools.utils import get_grid
 def compute_occ(occ_score, eps=1e-6):
     """Pairwise occlusion matrix, reference LVD.compute_occ (models/nets/lvd.py:59-68).
     occ_score (B, T, No) -> (B, T, No+1, No+1): occ[i, j] = s_i / (s_i + s_j) - [i == j] / 2 with
-    s = exp(-score^2) + eps; first column ones (objects occlude the background), first row zeros."""
-    b, t, no = occ_score.shape
-    s = torch.exp(-occ_score * occ_score) + eps
-    pair = s.unsqueeze(3) / (s.unsqueeze(3) + s.unsqueeze(2))
-    pair = pair - 0.5 * torch.eye(no, device=occ_score.device, dtype=occ_score.dtype)
-    occ = occ_score.new_zeros(b, t, no + 1, no + 1)
-    occ[:, :, 1:, 1:] = pair
-    occ[:, :, 1:, 0] = 1.0
-    return occ
+    s = exp(-score^2) + eps; first column ones (objects occlude the background), first row zeros.
+    One kernel forward, one backward (csrc/producers.hip)."""
+    return WF.compute_occ(occ_score, eps)
+
+
+def decoder_tail(img, circle=None, init_bias=0.0, scale_factor=1, has_alpha=True, use_prior=False,
+                 drop_alpha=False, obj_alpha_mask=None, remove_obj=False, freeze_obj=False):
+    """The tail of the reference's ImageDecoder.forward (models/nets/lvd.py:245-254) on the raw image
+    ``img`` (N, C, h, w) of its conv stack (a network outside this path): ``+ init_bias``; on the
+    alpha channel ``tanh`` and, with ``use_prior``, the blend with the ``circle`` buffer;
+    ``scale(img, scale_factor)``.  ``obj_alpha_mask`` / ``remove_obj`` / ``freeze_obj`` fold the
+    arithmetic of ``LVD.forward(mode="estimate_alpha_grid_occ")`` (lvd.py:128-132) into the same
+    kernel -- for the object decoder, whose only channel is alpha."""
+    out = WF.alpha_head(img, prior=circle if (has_alpha and use_prior) else None, mask=obj_alpha_mask,
+                        scale=scale_factor, bias=init_bias, has_alpha=has_alpha, remove=remove_obj,
+                        freeze=freeze_obj)
+    return out[:, :-1] if (has_alpha and drop_alpha) else out
 
 
 def reduce_comp(vid, occ, flow=None):
@@ -396,12 +404,11 @@ def estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose, bg_pose, occ_
     net outside this path), ``bg_alpha`` the model's (1, 1, H, W) parameter; ``obj_alpha_mask`` the
     padding mask of lvd.py:132.  Returns ``(occ, obj_alpha, bg_alpha, grid)``."""
     bg_alpha = bg_alpha.expand(obj_alpha.size(0), -1, -1, -1)
-    if remove_obj:
-        obj_alpha = 0 * obj_alpha - 1
-    if freeze_obj:
-        obj_alpha = 0 * obj_alpha + 1
-    if obj_alpha_mask is not None:
-        obj_alpha = obj_alpha_mask * obj_alpha + (1 - obj_alpha_mask) * (-1.0)
+    if remove_obj or freeze_obj or obj_alpha_mask is not None:
+        ho, wo = obj_alpha.shape[-2:]
+        mask = obj_alpha_mask.expand(1, 1, 1, ho, wo).reshape(ho, wo) if torch.is_tensor(obj_alpha_mask) else None
+        obj_alpha = WF.alpha_head(obj_alpha.reshape(-1, 1, ho, wo), mask=mask, has_alpha=False,
+                                  remove=remove_obj, freeze=freeze_obj).view(obj_alpha.shape)
     grid = warper(obj_pose, bg_pose)
     return compute_occ(occ_score), obj_alpha, bg_alpha, grid
 
