@@ -70,6 +70,13 @@ def all_gather_frames(local, frames, group=None):
     if local.shape[0] < per:
         pad = local.new_zeros(per - local.shape[0], *local.shape[1:])
         local = torch.cat([local, pad], dim=0)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory (smoke tests of the multi-rank path on a box with fewer GPUs than
+        # ranks); RCCL ("nccl") gathers device buffers directly over xGMI
+        host = local.cpu().contiguous()
+        out = host.new_empty(world * per, *host.shape[1:])
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out[:frames].to(local.device)
     out = local.new_empty(world * per, *local.shape[1:])
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out[:frames]
