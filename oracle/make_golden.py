@@ -307,6 +307,29 @@ def gen_producers(ns):
              grad_raw=raw.grad if raw.grad is not None else torch.zeros_like(raw), grad_score=score.grad)
 
 
+def gen_demo_clip():
+    """BASELINE config C1: six frames of the in-tree demo clip (datasets/demo_cityscapes, munster),
+    reduced 4x with PIL so that the fixture stays small -- frames bilinear (as the loader's own
+    resize), class maps nearest -- in the demo set's directory layout, plus the matching flow file
+    names' first flow (already under tests/golden/demo_flow.flo).  Data files, not code."""
+    import PIL.Image
+    src = os.path.join(R.REF_ROOT, "datasets", "demo_cityscapes")
+    dst = os.path.join(OUT, "demo_clip")
+    city = os.path.join("val", "munster")
+    names = sorted(os.listdir(os.path.join(src, "leftImg8bit_sequence_512", city)))[:6]
+    for sub, mode, resample in (("leftImg8bit_sequence_512", "RGB", PIL.Image.BILINEAR),
+                                ("leftImg8bit_sequence_deeplabv3_512", None, PIL.Image.NEAREST)):
+        os.makedirs(os.path.join(dst, sub, city), exist_ok=True)
+        for n in names:
+            img = PIL.Image.open(os.path.join(src, sub, city, n))
+            if mode:
+                img = img.convert(mode)
+            img = img.resize((256, 128), resample)
+            img.save(os.path.join(dst, sub, city, n), optimize=True)
+    total = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(dst) for f in fs)
+    print(f"demo_clip: {len(names)} frames + layouts, {total / 1024:.1f} KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
@@ -318,6 +341,7 @@ def main():
     gen_warper(ns)
     gen_inpaint(ns)
     gen_producers(ns)
+    gen_demo_clip()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,104 @@
+"""BASELINE config C1 (demo_cityscapes clip, 128x128, 4 layers): the plumbing driver
+waldo_amd/tools/demo.py -- the call order of Synthesizer.predict (models/synthesizer.py:434-480) on
+the committed six-frame clip -- on the HIP path against the SAME chain restated with the CPU oracle,
+stage by stage.  Grid inversion rounds positions to cells, so fp32-level differences upstream flip
+a few cells: the inverted grids and everything downstream are compared with a
+robust measure (share of deviating pixels + mean error), the stages before them tightly."""
+import os
+
+import pytest
+import torch
+
+from oracle import producers_oracle as PO
+from oracle import warper_oracle as WO
+from oracle import wif_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLIP = os.path.join(HERE, "golden", "demo_clip", "leftImg8bit_sequence_512", "val", "munster")
+
+
+def robust(a, b, what, tol=2e-3, share=0.02, mean_tol=1e-3):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    d = (a - b).abs()
+    bad = (d > tol).double().mean().item()
+    print(f"[demo] {what}: max {d.max().item():.3e} mean {d.mean().item():.3e} share>{tol:g}: {bad:.4f}")
+    assert bad <= share and d.mean().item() <= mean_tol, (what, bad, d.mean().item())
+
+
+def oracle_predict(opt, vid, lyt, net, ctx_len):
+    """demo.predict restated with oracle functions only (CPU)."""
+    from waldo_amd.tools import demo
+    cfg = WO.WarperCfg.from_opt(opt)
+    b, t = vid.shape[:2]
+    no = opt.num_obj
+    lo, lb = opt.obj_shape[0] * opt.obj_shape[1], opt.latent_shape[0] * opt.latent_shape[1]
+    buf = demo.pose_buffers(opt, "cpu")
+    mask = demo.obj_alpha_mask(opt, "cpu")
+    bg_alpha = torch.ones(b, 1, *cfg.src_shape)
+
+    def stage(pop, pbp, score, nt):
+        obj_pose = PO.pose_affine(pop, buf["mul_obj"], buf["bias_obj"], buf["tgt_pts_obj"].view(lo, 2))
+        bg_pose = PO.pose_affine(pbp, torch.ones(6), buf["bias_bg"], buf["tgt_pts_bg"].view(lb, 2))
+        oa = PO.decoder_tail(net["raw"], None, 0.0, opt.scale_factor)
+        oa = PO.alpha_arithmetic(oa.view(b, no, 1, *oa.shape[-2:]), mask)
+        grid = WO.warper_grids(cfg, obj_pose.view(b, nt, no, lo, 2), bg_pose.view(b, nt, 1, lb, 2))
+        return obj_pose, oa, O.compute_occ(score), grid
+
+    out = {}
+    obj_pose, oa, occ, grid = stage(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
+    out["obj_pose"], out["obj_alpha"], out["occ"], out["grid"] = obj_pose, oa, occ, grid
+    ctx_ts = torch.arange(ctx_len).view(1, -1, 1).expand(b, -1, t).contiguous()
+    inp = torch.cat([vid, lyt], 2)
+    dec = WO.decode_output(cfg, inp, grid, occ, oa, bg_alpha, net["cls"], ctx_ts, torch.arange(t), True, False)
+    out["rec_vid"] = dec[0][:, :, :3]
+    raw = dec[5]
+    vt = raw.permute(0, 2, 1, 3, 4, 5)
+    out["inp_rec_vid"] = WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:]), ab=True)
+    tp = t - ctx_len
+    oa2, occ2, grid2 = oa, occ, grid  # full-length "predicted" pose sequences: the same synthetic poses
+    ctx_ts = torch.arange(ctx_len).view(1, -1, 1).expand(b, -1, tp).contiguous()
+    dec = WO.decode_output(cfg, inp, grid2, occ2, oa2, bg_alpha, net["cls"], ctx_ts, torch.arange(ctx_len, t), True, False)
+    out["pred_vid"] = torch.cat([vid[:, :ctx_len], dec[0][:, :, :3]], 1)
+    vt = dec[5].permute(0, 2, 1, 3, 4, 5)
+    out["inp_pred_vid"] = torch.cat([vid[:, :ctx_len], WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:]), True)], 1)
+    return out
+
+
+def test_demo_clip_predict_chain(dev, tmp_path):
+    from waldo_amd.nets import flp
+    from waldo_amd.nets.lvd import Warper
+    from waldo_amd.nets.wif import WIF
+    from waldo_amd.tools import demo, io as wio
+    opt = demo.demo_opt(dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20)
+    clip = wio.load_clip(CLIP, (128, 128), 20, max_frames=6)
+    vid, lyt = clip["vid"].unsqueeze(0), clip["lyt"].unsqueeze(0)
+    ctx_len = 4
+    net = demo.synthetic_network_outputs(opt, 1, 6, ctx_len, seed=0)
+    ref = oracle_predict(opt, vid, lyt, net, ctx_len)
+
+    warper = Warper(opt).to(dev)
+    wif = WIF(opt, unet=demo.UniformFusionUNet()).to(dev)
+    netd = {k: v.to(dev) for k, v in net.items()}
+    got = demo.predict(opt, warper, wif, vid.to(dev), lyt.to(dev), netd, ctx_len)
+    # the stages in front of the grid inversion: tight
+    buf = demo.pose_buffers(opt, dev)
+    pts = flp.obj_pose_to_points(netd["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+    assert (pts.cpu() - ref["obj_pose"]).abs().max() <= 1e-6
+    grid = warper(pts.view(1, 6, 3, 4, 2), flp.bg_pose_to_points(netd["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"]).view(1, 6, 1, 16, 2))
+    assert (grid[0].cpu() - ref["grid"][0]).abs().max() <= 1e-4
+    robust(grid[1], ref["grid"][1], "inverted object grids", tol=1e-3, share=0.02, mean_tol=5e-2)
+    # the frames predict produces
+    for key in ("rec_vid", "inp_rec_vid", "pred_vid", "inp_pred_vid"):
+        assert torch.isfinite(got[key]).all()
+        robust(got[key], ref[key], key)
+    assert got["rec_vid"].shape == (1, 6, 3, 128, 128) and got["pred_vid"].shape == (1, 6, 3, 128, 128)
+    assert torch.equal(got["pred_vid"][:, :ctx_len].cpu(), vid[:, :ctx_len])
+    # reconstruction from 4 context frames of a real clip: not a blank image
+    assert got["inp_rec_vid"].std() > 0.1
+    # and the command-line driver writes its results
+    res = demo.run(CLIP, str(tmp_path / "out"), frames=6, ctx_len=4)
+    names = set(os.listdir(tmp_path / "out"))
+    assert {"rec_vid.gif", "inp_pred_vid.gif", "pred_vid_last.png", "pred_flow_last.flo"} <= names
+    assert torch.equal(res["rec_vid"], got["rec_vid"])

@@ -90,9 +90,55 @@ def test_formats_against_reference_loader():
         ref_lyt = ds.load_layout_path(p)
         ids = torch.from_numpy(np.asarray(PIL.Image.open(p)).copy()).long()
         assert torch.equal(wio.layout_to_logits(ids, 20), ref_lyt)
+        assert torch.equal(wio.read_layout(p, 20), ref_lyt)
+        # frames: load_rgb_path + the inference transform of get_transform (Resize on the PIL image,
+        # ToTensor, Normalize(0.5, 0.5)) with stand-ins for the three torchvision classes it composes
+        tv = stubs["torchvision.transforms"]
+        tv.Resize = lambda size, method: (lambda img: img.resize((size[1], size[0]), method))
+        tv.Normalize = lambda mean, std: (lambda x: (x - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1))
+
+        class Compose:
+            def __init__(self, ts):
+                self.ts = ts
+
+            def __call__(self, x):
+                for t in self.ts:
+                    x = t(x)
+                return x
+
+        tv.Compose = Compose
+        img_dir = lyt_dir.replace("_deeplabv3_512", "_512")
+        pi = os.path.join(img_dir, sorted(os.listdir(img_dir))[0])
+        for dim, ar in ((128, 1.0), (128, 2.0), (512, 2.0)):
+            ref_img = ds.load_rgb_path(pi, mod.get_transform(dim, aspect_ratio=ar))
+            assert torch.equal(wio.read_rgb(pi, (dim, int(dim * ar))), ref_img), (dim, ar)
     finally:
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+CLIP = os.path.join(HERE, "golden", "demo_clip", "leftImg8bit_sequence_512", "val", "munster")
+
+
+def test_load_clip_and_dumps(tmp_path):
+    """The committed six-frame demo clip (C1) through load_clip, and the result writers."""
+    import PIL.Image
+    clip = wio.load_clip(CLIP, (64, 128), 20, max_frames=5)
+    assert clip["vid"].shape == (5, 3, 64, 128) and clip["lyt"].shape == (5, 20, 64, 128)
+    assert clip["flow"] is None and clip["names"][0].endswith("000001_leftImg8bit.png")
+    assert clip["vid"].min() >= -1 and clip["vid"].max() <= 1 and clip["vid"].std() > 0.1
+    assert torch.equal((clip["lyt"] > 0).sum(1), torch.ones(5, 64, 128, dtype=torch.long))
+    wio.dump_image(clip["vid"][0], tmp_path / "f.png")
+    back = wio.read_rgb(tmp_path / "f.png")
+    assert (back - clip["vid"][0]).abs().max() <= 1.0 / 255 + 1e-6
+    wio.dump_video(clip["vid"], str(tmp_path / "v.gif"))
+    assert PIL.Image.open(tmp_path / "v.gif").n_frames == 5
+    wio.dump_video(clip["vid"], str(tmp_path / "frames"))
+    assert sorted(os.listdir(tmp_path / "frames")) == [f"{i:04d}.png" for i in range(5)]
+    with pytest.raises(ValueError):
+        wio.dump_video(clip["vid"], str(tmp_path / "v.mp4"))
+    with pytest.raises(ValueError):
+        wio.read_layout(os.path.join(CLIP.replace("_512", "_deeplabv3_512"), clip["names"][0]), 5)

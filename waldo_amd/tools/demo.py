@@ -1,0 +1,205 @@
+"""BASELINE config C1 plumbing: WIF inference on a demo clip, reproducing the call order of the
+reference's ``Synthesizer.predict`` (models/synthesizer.py:425-480) around the hot path.
+
+    python -m waldo_amd.tools.demo --clip <dir of frame PNGs> --out <dir> [--dim 128 --num-obj 3]
+
+What is real: the frames and layout maps of the clip (``waldo_amd.tools.io.load_clip``), every
+warp / composite / fusion step (the HIP kernels behind ``nets.lvd`` / ``nets.flp`` / ``nets.wif``),
+the tensor plumbing between them (``ctx_ts`` / ``pred_ts`` construction, the ``last_n_ctx``
+window, the disocclusion bookkeeping, the future-prediction branch).  What is synthetic: the
+outputs of the networks that are outside this path (layer / pose estimators,
+object decoder conv stack, pose generator, UNet) -- seeded stand-ins with the right shapes:
+smooth object blobs for the decoder's raw image, small smooth motions for the pose heads, and a
+UNet stand-in that predicts a zero residual and uniform scores.  The same stand-ins feed the CPU
+oracle in tests/test_demo.py, so the chain is checked end to end, not just exercised.
+"""
+import argparse
+import os
+import types
+
+import torch
+import torch.nn as nn
+
+from ..nets import flp
+from ..nets.lvd import Warper, decode_output, decoder_tail, estimate_alpha_grid_occ
+from ..nets.wif import WIF
+from . import io as wio
+from .utils import get_grid
+
+
+def demo_opt(dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20, **over):
+    """The option fields the path reads (Warper: models/nets/lvd.py:472-499; WIF: ii_score, ii_ab),
+    at the C1 size: 128 x 128, 4 layers (3 objects + background)."""
+    d = dict(latent_shape=[4, 4], obj_shape=[2, 2], time_dropout=0.0, num_obj=num_obj, patch_size=8,
+             scale_factor=2, dim=dim, aspect_ratio=aspect_ratio, load_dim=0, num_perm_grid=1,
+             normalize_alpha=False, use_lyt_filtering=True, use_lyt_opacity=False, weight_cls=True,
+             min_cls=0.05, include_self=False, no_filter=False, allow_ghost=False, num_lyt=num_lyt,
+             ii_score=True, ii_ab=True, last_n_ctx=0, no_future=False, pad_obj_alpha=2)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+class UniformFusionUNet(nn.Module):
+    """UNet stand-in: zero colour residual (channels 0-2), equal scores (channel 3) -- the fusion of
+    wif.py:49-54 then averages the warped context frames with their sigmoid(alpha + 5) weights."""
+
+    def forward(self, x):
+        return x.new_zeros(x.shape[0], 4, *x.shape[-2:])
+
+
+def synthetic_network_outputs(opt, b, t, ctx_len, seed=0, device="cpu"):
+    """Seeded stand-ins for what the networks outside the path would hand over, on ``device``."""
+    g = torch.Generator().manual_seed(seed)
+    no, nl = opt.num_obj, opt.num_lyt
+    lo = opt.obj_shape[0] * opt.obj_shape[1]
+    lb = opt.latent_shape[0] * opt.latent_shape[1]
+    ho, wo = opt.obj_shape[0] * opt.patch_size, opt.obj_shape[1] * opt.patch_size
+    # object decoder raw image: one soft blob per object (positive inside -> alpha ~ +1 after tanh)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, ho), torch.linspace(-1, 1, wo), indexing="ij")
+    rad = 0.5 + 0.3 * torch.rand(b * no, 1, 1, 1, generator=g)
+    raw = 4.0 * (rad - (xx ** 2 + yy ** 2).sqrt().view(1, 1, ho, wo) / 1.0)
+    # pose heads (after tanh): per-object placement + a slow drift over time, small point deltas
+    base = 0.6 * (torch.rand(b, 1, no, 6 + 2 * lo, generator=g) * 2 - 1)
+    drift = 0.05 * torch.randn(b, 1, no, 6 + 2 * lo, generator=g) * torch.arange(t).view(1, t, 1, 1)
+    obj = base + drift
+    obj[..., 6:] = 0.1 * obj[..., 6:]
+    obj[..., [0, 3]] = -0.2 + 0.2 * obj[..., [0, 3]]  # scales around bias_obj - 0.2
+    obj[..., [1, 2]] = 0.2 * obj[..., [1, 2]]        # small shear
+    bg = 0.02 * torch.randn(b, 1, 1, 6 + 2 * lb, generator=g) * torch.arange(t).view(1, t, 1, 1)
+    occ_score = torch.randn(b, t, no, generator=g)
+    cls = torch.softmax(2.0 * torch.randn(b, no, nl, generator=g), dim=-1)
+    out = dict(raw=raw, pred_obj_pose=obj.reshape(b * t, no, -1), pred_bg_pose=bg.reshape(b * t, 1, -1),
+               occ_score=occ_score, cls=cls)
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def pose_buffers(opt, device):
+    """Buffers of the pose heads (models/nets/flp.py:119-123) at the demo's option values."""
+    lo = opt.obj_shape[0] * opt.obj_shape[1]
+    lb = opt.latent_shape[0] * opt.latent_shape[1]
+    return dict(
+        tgt_pts_obj=get_grid(*opt.obj_shape).view(1, 1, lo, 2).to(device),
+        tgt_pts_bg=get_grid(*opt.latent_shape).view(1, 1, lb, 2).to(device),
+        bias_obj=torch.tensor([[[0.5, 0.0, 0.0, opt.aspect_ratio * 0.5, 0.0, 0.0]]], device=device),
+        mul_obj=torch.tensor([[[0.5, 0.5, 0.5, 0.5, 1.0, 1.0]]], device=device),
+        bias_bg=torch.tensor([[[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]]], device=device))
+
+
+def obj_alpha_mask(opt, device):
+    """lvd.py:27-34: zero border of ``pad_obj_alpha`` decoder pixels around the object canvas."""
+    ho = opt.obj_shape[0] * opt.patch_size * opt.scale_factor
+    wo = opt.obj_shape[1] * opt.patch_size * opt.scale_factor
+    po = opt.pad_obj_alpha * opt.scale_factor
+    m = torch.ones(ho, wo, device=device)
+    if po > 0:
+        m[:po] = 0
+        m[:, :po] = 0
+        m[-po:] = 0
+        m[:, -po:] = 0
+    return m.view(1, 1, 1, ho, wo)
+
+
+@torch.no_grad()
+def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
+    """The hot-path part of Synthesizer.predict (models/synthesizer.py:434-480).  real_vid
+    (B, T, 3, H, W), real_lyt (B, T, Nl, H, W); ``net`` = synthetic_network_outputs(...).
+    Returns a dict of the tensors predict produces."""
+    b, t = real_vid.shape[:2]
+    no = opt.num_obj
+    lo = opt.obj_shape[0] * opt.obj_shape[1]
+    lb = opt.latent_shape[0] * opt.latent_shape[1]
+    dev = real_vid.device
+    buf = pose_buffers(opt, dev)
+    mask = obj_alpha_mask(opt, dev)
+    bg_alpha = torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev)
+
+    def alpha_grid_occ(pred_obj_pose, pred_bg_pose, occ_score, nt):
+        # pose heads' affine (flp.py:259-273), decoder tail (lvd.py:245-254), then
+        # LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135)
+        obj_pose = flp.obj_pose_to_points(pred_obj_pose, buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+        bg_pose = flp.bg_pose_to_points(pred_bg_pose, buf["tgt_pts_bg"], buf["bias_bg"])
+        obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
+        obj_alpha = obj_alpha.view(b, no, 1, *obj_alpha.shape[-2:])
+        return estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(b, nt, no, lo, 2),
+                                       bg_pose.view(b, nt, 1, lb, 2), occ_score, obj_alpha_mask=mask)
+
+    def disocc(alpha_ctx):  # synthesizer.py:447-450
+        mx = alpha_ctx.max(dim=3)[0]
+        dmax, dmin = mx.max(dim=1)[0], mx.min(dim=1)[0]
+        dmax = dmax.clone()
+        dmax[dmax - dmin > 1] = 0
+        return dmax.unsqueeze(2)
+
+    out = {}
+    occ, obj_alpha, bga, grid = alpha_grid_occ(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
+    # reconstruct video (synthesizer.py:436-445)
+    ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(b, -1, t)
+    if opt.last_n_ctx > 0:
+        ctx_ts = ctx_ts[:, -opt.last_n_ctx:].contiguous()
+    pred_ts = torch.arange(t, device=dev, dtype=torch.int64)
+    real_input = torch.cat([real_vid, real_lyt], dim=2)
+    rec_output, _, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
+                                                                  net["cls"], ctx_ts.contiguous(), pred_ts)
+    out["rec_vid"] = rec_output[:, :, :3]
+    out["rec_disocc"] = disocc(alpha_ctx)
+    out["inp_rec_vid"] = wif(raw_output)  # synthesizer.py:460
+    if not opt.no_future:
+        # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
+        # poses as they came in, the future ones predicted (flp.py:275-290) -- here the synthetic poses
+        # of all T frames stand for them (synthesizer.py:464-472)
+        tp = t - ctx_len
+        pred_ts = torch.arange(ctx_len, t, device=dev, dtype=torch.int64)
+        ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(b, -1, tp)
+        occ, obj_alpha, bga, grid = alpha_grid_occ(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
+        pred_output, pred_flow, _, alpha, _, raw_output, alpha_ctx = decode_output(
+            warper, real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_ts.contiguous(), pred_ts)
+        out["pred_disocc"] = disocc(alpha_ctx)
+        out["pred_flow"] = pred_flow
+        out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred_output[:, :, :3]], dim=1)
+        out["inp_pred_vid"] = torch.cat([real_vid[:, :ctx_len], wif(raw_output)], dim=1)
+    return out
+
+
+def run(clip_dir, out_dir=None, dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20, frames=6, ctx_len=4, seed=0,
+        device="cuda:0"):
+    opt = demo_opt(dim, aspect_ratio, num_obj, num_lyt)
+    size = (dim, int(dim * aspect_ratio))
+    clip = wio.load_clip(clip_dir, size, num_lyt, max_frames=frames)
+    dev = torch.device(device)
+    vid, lyt = clip["vid"].unsqueeze(0).to(dev), clip["lyt"].unsqueeze(0).to(dev)
+    warper = Warper(opt).to(dev)
+    wif = WIF(opt, unet=UniformFusionUNet()).to(dev)
+    net = synthetic_network_outputs(opt, 1, vid.shape[1], ctx_len, seed=seed, device=dev)
+    res = predict(opt, warper, wif, vid, lyt, net, ctx_len)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        for key in ("rec_vid", "inp_rec_vid", "pred_vid", "inp_pred_vid"):
+            if key in res:
+                wio.dump_video(res[key][0], os.path.join(out_dir, key + ".gif"))
+                wio.dump_image(res[key][0, -1], os.path.join(out_dir, key + "_last.png"))
+        if "pred_flow" in res:
+            fl = res["pred_flow"][0, -1, 0]
+            wio.write_flo(os.path.join(out_dir, "pred_flow_last.flo"), fl)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--clip", required=True, help="directory with the clip's frame PNGs (demo dataset layout)")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--aspect-ratio", type=float, default=1.0)
+    ap.add_argument("--num-obj", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--ctx-len", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    res = run(args.clip, args.out, args.dim, args.aspect_ratio, args.num_obj, frames=args.frames,
+              ctx_len=args.ctx_len, seed=args.seed)
+    for k, v in res.items():
+        print(f"{k}: {tuple(v.shape)} range [{v.min().item():.3f}, {v.max().item():.3f}] "
+              f"finite={bool(torch.isfinite(v).all())}")
+
+
+if __name__ == "__main__":
+    main()
