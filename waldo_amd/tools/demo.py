@@ -11,7 +11,7 @@ outputs of the networks that are outside this path (layer /
 object decoder conv stack, pose generator, UNet) -- seeded stand-ins with the right shapes:
 smooth object blobs for the decoder's raw image, small smooth motions for the pose heads, and a
 UNet stand-in that predicts a zero residual and uniform scores.  The same stand-ins feed the CPU
-oracle in tests/test_demo.py, so the chain is checked end to end, not just exercised.
+restatement of the chain in tests/test_demo.py, so it is checked end to end, not just exercised.
 """
 import argparse
 import os
