@@ -161,7 +161,7 @@ int waldo_pose_affine_bwd(const float* pose, const float* mul6, const float* bia
 
 /* ---------------------------------------------------------------------------------------
  * A9: the two full-resolution passes of Warper.grid_to_flow_ctx / grid_to_flow
- * (models/nets/lvd.py:707-828, 602-705), forward only (the inference path).  The low-resolution
+ * (models/nets/lvd.py:707-828, 602-705); their backward entry points follow A10.  The low-resolution
  * inputs come from waldo_grid_sample2d_fwd (lvd.py:723-728, 784-796); Hd = H*scale, Wd = W*scale.
  *
  * waldo_flow_ctx_alpha_fwd (lvd.py:731-766): bilinear x`scale` upsampling (F.interpolate,
@@ -189,7 +189,7 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
                             int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward only: warp of the context frames
+ * A10: Warper.input_to_output (models/nets/lvd.py:830-853): warp of the context frames
  * by the composited flow and temporal fusion, incl. the include_self branch (lvd.py:842-845).
  *   input (B,T,C,Hd,Wd); flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1];
  *   ctx_ts (B,Tc,Tp) int64; Tc' = Tc + (include_self ? 1 : 0) <= 8; include_self needs Tp == T
@@ -199,6 +199,41 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
 int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
                               const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
                               int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+                              waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Backward of A9 / A10 (csrc/flow_ctx_bwd.hip): the reference's live backward path in LVD training
+ * (models/synthesizer.py:841 through models/nets/lvd.py:602-853).  Shapes as the forward entry points.
+ *
+ * waldo_flow_ctx_alpha_bwd:  grad_a01 (B*Tw,L,Hd,Wd) = d loss / d a01 (a caller that also holds a
+ *   gradient of alpha_out = 2 a01 - 1 adds twice that);  grad_alpha_lr (B*Tw,L,H,W) OVERWRITTEN;
+ *   grad_dist (B,L-1,Nl) and grad_occ (B,T,L,L) must be ZERO-FILLED (one float atomic per workgroup
+ *   and entry; either may be NULL);  workspace: B*Tw*L*Hd*Wd floats when scale > 1 (the gradient at
+ *   the HD raster, transposed-upsampled by a gather pass), unused at scale 1.
+ * waldo_flow_ctx_warp_bwd:  grad_flow (M,2,Hd,Wd), grad_alpha_ctx (M,L,Hd,Wd), grad_disocc (M,Hd,Wd),
+ *   any may be NULL (zero);  grad_flow_lr (M,L,2,H,W) OVERWRITTEN;  grad_a01 (B*Tw,L,Hd,Wd) must be
+ *   ZERO-FILLED (bilinear splat with float atomics, as F.grid_sample's backward; NULL to skip);
+ *   grad_occ as above;  workspace: M*L*2*Hd*Wd floats when scale > 1.  The ghost mask (isobj_lr > 0.9)
+ *   and the frame indices carry no gradient.
+ * waldo_frame_warp_fuse_bwd:  grad_out (B,Tp,C+1,Hd,Wd), grad_raw (B,Tc',Tp,C+L,Hd,Wd), either may be
+ *   NULL;  grad_flow (B,Tc,Tp,2,Hd,Wd) and grad_alpha (B,Tc,Tp,L,Hd,Wd) OVERWRITTEN.  The frames
+ *   (`input`) are data: no gradient is produced for them.
+ * ------------------------------------------------------------------------------------- */
+int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* input, const float* dist,
+                             const float* occ, const float* grad_a01, float* grad_alpha_lr,
+                             float* grad_dist, float* grad_occ, float* workspace, int B, int T, int Tw,
+                             int L, int Nl, int C, int chan_off, int H, int W, int scale,
+                             waldo_stream_t stream);
+int waldo_flow_ctx_warp_bwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                            const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
+                            const float* grad_flow, const float* grad_alpha_ctx,
+                            const float* grad_disocc, float* grad_flow_lr, float* grad_a01,
+                            float* grad_occ, float* workspace, int B, int T, int Tw, int Tc, int Tp,
+                            int L, int H, int W, int scale, waldo_stream_t stream);
+int waldo_frame_warp_fuse_bwd(const float* input, const float* flow, const float* alpha,
+                              const int64_t* ctx_ts, const float* grad_out, const float* grad_raw,
+                              float* grad_flow, float* grad_alpha, int B, int T, int Tc, int Tp, int C,
+                              int L, int Hd, int Wd, int include_self, float eps,
                               waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -237,6 +237,65 @@ def test_flow_ctx_fused_passes(dev, over, ctx_only):
         close(x, z, what="fused vs unfused:" + name)
 
 
+@pytest.mark.parametrize("over,ctx_only,include_self", [
+    (dict(num_obj=3, dim=16, load_dim=0), False, True),                       # the LVD recipe's shape: x1, ctx "prev"
+    (dict(num_obj=16, obj_shape=[2, 2], dim=8, load_dim=32), True, False),   # L = 17, x4, ghost mask
+    (dict(num_obj=5, dim=16, load_dim=48, allow_ghost=True), True, False),   # x3
+    (dict(num_obj=3, dim=16, load_dim=32, no_filter=True), False, False),    # no layout filter
+    (dict(num_obj=4, dim=16, load_dim=16, weight_cls=True, min_cls=0.05), False, True),
+])
+def test_fused_hd_backward(dev, over, ctx_only, include_self):
+    """Backward of the fused full-resolution passes (csrc/flow_ctx_bwd.hip) against the CPU oracle's
+    autograd AND against the per-op HIP path, for every differentiable input of the chain
+    grid_to_flow[_ctx] -> input_to_output: the four grids, the object alphas, the occlusion matrix
+    and the class distributions; loss over every output (flow, both alphas, disocc, fused frames,
+    raw frames)."""
+    from waldo_amd.nets import Warper
+    opt = opt_ns(include_self=include_self, **over)
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    b, t, nl = 2, 3, 6
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=17)
+    if include_self:  # ctx_mode "prev" of synthesizer.py:826-828
+        ctx_ts = torch.roll(torch.arange(t), 1).view(1, 1, t).expand(b, -1, -1).contiguous()
+        pred_ts = torch.arange(t)
+    else:
+        ctx_ts = torch.tensor([[[0], [1]], [[1], [1]]])
+        pred_ts = torch.tensor([2])
+    with torch.no_grad():
+        grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
+    names = ("tgo", "sgo", "tgb", "sgb", "obj_alpha", "occ", "cls")
+
+    def run(fn_flow, fn_out, to, leaves):
+        g4, oa, oc, cl = leaves[:4], leaves[4], leaves[5], leaves[6]
+        r = fn_flow(inp.to(to), g4, oc, oa, bg_alpha.to(to), cl, ctx_ts.to(to), pred_ts.to(to))
+        out, raw = fn_out(inp.to(to), r[3], r[0], ctx_ts.to(to))
+        torch.manual_seed(2)
+        loss = 0
+        for x in (r[0], r[2], r[3], r[4], out, raw):
+            loss = loss + (x * torch.randn(x.shape).to(to)).sum()
+        loss.backward()
+        return [x.grad for x in leaves], (r, out, raw)
+
+    base = [*grid_o, obj_alpha, occ, cls]
+    lo = [x.clone().requires_grad_() for x in base]
+    fo = WO.grid_to_flow_ctx if ctx_only else WO.grid_to_flow
+    g_o, _ = run(lambda *a: fo(cfg, *a), lambda *a: WO.input_to_output(cfg, *a), "cpu", lo)
+    grads = {}
+    for fused in (True, False):
+        wp.fuse_hd = fused
+        lh = [x.clone().to(dev).requires_grad_() for x in base]
+        fh = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
+        grads[fused], _ = run(fh, wp.input_to_output, dev, lh)
+    wp.fuse_hd = True
+    for i, name in enumerate(names):
+        if g_o[i] is None:
+            assert grads[True][i] is None or grads[True][i].abs().max() == 0, name
+            continue
+        close(grads[True][i], g_o[i], tol=2e-3, rel=True, what=f"fused vs oracle: grad {name}")
+        close(grads[True][i], grads[False][i], tol=2e-3, rel=True, what=f"fused vs per-op: grad {name}")
+
+
 def test_fused_hd_passes_at_recipe_size(dev):
     """The reference's real Cityscapes recipe R (scripts/cityscapes/train_wif.sh:12-14,28): L = 17
     layers, Nl = 20 classes, 128x256 -> 512x1024, B = 1, Tc = 4, Tp = 1 -- the fused passes of

@@ -43,6 +43,9 @@ SIGNATURES = {
     "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_fwd": [_c_f] * 9 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
+    "waldo_flow_ctx_alpha_bwd": [_c_f] * 9 + [_int] * 10 + [_stream],
+    "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],
+    "waldo_frame_warp_fuse_bwd": [_c_f] * 8 + [_int] * 9 + [_flt, _stream],
     "waldo_wif_fuse_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _stream],
     "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
                            _stream],

@@ -21,55 +21,9 @@
 //
 // Both are HBM streaming passes: A reads Nl + (L taps from the 16x smaller LR planes) and writes
 // 2L floats per HD pixel; B reads ~L gathered alphas and writes L + 3.
-#include "waldo_common.hip.h"
+#include "flow_ctx_common.hip.h"
 
 namespace waldo {
-
-// source taps of F.interpolate(mode="bilinear", align_corners=False, scale_factor=s):
-// src = max((dst + 0.5) / s - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, size - 1)
-struct UpTap {
-  int i0, i1;
-  float l0, l1;
-};
-
-__device__ __forceinline__ UpTap up_tap(int dst, float rscale, int size) {
-  const float src = fmaxf(((float)dst + 0.5f) * rscale - 0.5f, 0.0f);
-  UpTap t;
-  t.i0 = min((int)src, size - 1);
-  t.i1 = min(t.i0 + 1, size - 1);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.0f - t.l1;
-  return t;
-}
-
-// the four taps of one HD pixel inside ANY low-resolution plane: byte offsets + weights, computed
-// once per thread and shared by all the planes it upsamples (uniform plane base + 32-bit offset)
-struct UpTaps {
-  uint32_t o00, o01, o10, o11;
-  float lx0, lx1, ly0, ly1;
-};
-
-__device__ __forceinline__ UpTaps up_taps(int y, int x, float rscale, int H, int W) {
-  const UpTap ty = up_tap(y, rscale, H), tx = up_tap(x, rscale, W);
-  UpTaps t;
-  t.o00 = (uint32_t)(__mul24(ty.i0, W) + tx.i0) * 4u;
-  t.o01 = (uint32_t)(__mul24(ty.i0, W) + tx.i1) * 4u;
-  t.o10 = (uint32_t)(__mul24(ty.i1, W) + tx.i0) * 4u;
-  t.o11 = (uint32_t)(__mul24(ty.i1, W) + tx.i1) * 4u;
-  t.lx0 = tx.l0;
-  t.lx1 = tx.l1;
-  t.ly0 = ty.l0;
-  t.ly1 = ty.l1;
-  return t;
-}
-
-__device__ __forceinline__ float up_sample(const float* __restrict__ plane, const UpTaps& t) {
-  const float top = t.lx0 * ldb(plane, t.o00) + t.lx1 * ldb(plane, t.o01);
-  const float bot = t.lx0 * ldb(plane, t.o10) + t.lx1 * ldb(plane, t.o11);
-  return t.ly0 * top + t.ly1 * bot;
-}
-
-constexpr int kMaxCls = 32;
 
 template <int LP>
 __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
@@ -162,15 +116,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   // frame of the context alpha (clamped: the index comes from device memory) and of the order
   const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1));
   const int tpred = (int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1));
-  // texel centre of the HD identity grid exactly as get_grid() builds it: torch.linspace(start, end,
-  // n) with start / end rounded from double, step = (end - start) / (n - 1) in float, and the
-  // upper half counted down from the end
-  const float sx = (float)(-1.0 + 1.0 / (double)Wd), ex = (float)(1.0 - 1.0 / (double)Wd);
-  const float sy = (float)(-1.0 + 1.0 / (double)Hd), ey = (float)(1.0 - 1.0 / (double)Hd);
-  const float stepx = (Wd > 1) ? (ex - sx) / (float)(Wd - 1) : 0.0f;
-  const float stepy = (Hd > 1) ? (ey - sy) / (float)(Hd - 1) : 0.0f;
-  const float gx0 = (x < Wd / 2) ? sx + stepx * (float)x : ex - stepx * (float)(Wd - 1 - x);
-  const float gy0 = (y < Hd / 2) ? sy + stepy * (float)y : ey - stepy * (float)(Hd - 1 - y);
+  float gx0, gy0;  // texel centre of the HD identity grid exactly as get_grid() builds it
+  identity_grid(x, y, Wd, Hd, gx0, gy0);
 
   // branch-free over the padded layer count (a padding layer re-reads layer L-1 and is zeroed):
   // conditional writes to the per-layer arrays would keep them out of registers
@@ -224,7 +171,6 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 // the normalised weights as (B,Tc,Tp,.,Hd,Wd) tensors; here the taps and scores of the Tc contexts
 // of a pixel stay in registers and every input channel is sampled, written to `raw` and fused
 // into `out` in one pass.
-constexpr int kFwMaxCtx = 8;
 
 template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
@@ -237,12 +183,8 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
   const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   if (p >= HWd) return;
   const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
-  const float sx = (float)(-1.0 + 1.0 / (double)Wd), ex = (float)(1.0 - 1.0 / (double)Wd);
-  const float sy = (float)(-1.0 + 1.0 / (double)Hd), ey = (float)(1.0 - 1.0 / (double)Hd);
-  const float stepx = (Wd > 1) ? (ex - sx) / (float)(Wd - 1) : 0.0f;
-  const float stepy = (Hd > 1) ? (ey - sy) / (float)(Hd - 1) : 0.0f;
-  const float gx0 = (x < Wd / 2) ? sx + stepx * (float)x : ex - stepx * (float)(Wd - 1 - x);
-  const float gy0 = (y < Hd / 2) ? sy + stepy * (float)y : ey - stepy * (float)(Hd - 1 - y);
+  float gx0, gy0;
+  identity_grid(x, y, Wd, Hd, gx0, gy0);
 
   // taps, score and source frame of every context of this pixel, in registers (branch-free over the
   // padded context count: a padding context repeats context Tc-1 and is never stored or summed)
@@ -317,15 +259,6 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
   obase[(int64_t)C * HWd] = acc;
 }
 
-static int pad_l(int L) {
-  if (L <= 4) return 4;
-  if (L <= 8) return 8;
-  if (L <= 12) return 12;
-  if (L <= 17) return 17;
-  if (L <= 24) return 24;
-  return 32;
-}
-
 static int check_flow_ctx(const char* fn, int64_t N, int L, int H, int W, int scale) {
   if (N < 0 || L < 1 || L > 32 || H < 1 || W < 1 || scale < 1 || scale > 64 ||
       (int64_t)H * scale > 32767 || (int64_t)W * scale > 32767) {
@@ -371,7 +304,7 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
-  switch (pad_l(L)) {
+  switch (flow_ctx_pad_l(L)) {
     WALDO_FC_CASE(4, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
     WALDO_FC_CASE(8, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
     WALDO_FC_CASE(12, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
@@ -401,7 +334,7 @@ extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_
   }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
-  switch (pad_l(L)) {
+  switch (flow_ctx_pad_l(L)) {
     WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
     WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
     WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)

@@ -400,33 +400,109 @@ def wif_fuse(vid, net_out, ab=True):
 # --------------------------------------------------------------------------------------
 # A9: the two HD passes of Warper.grid_to_flow_ctx / grid_to_flow (forward only)
 # --------------------------------------------------------------------------------------
+class _FlowCtxAlpha(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha_lr, input, dist, occ, tw, chan_off, scale):
+        n, nl, h, w = alpha_lr.shape
+        b, t, c, hd, wd = input.shape
+        ncls = dist.shape[2] if dist is not None else 0
+        a01 = alpha_lr.new_empty(n, nl, hd, wd)
+        out = alpha_lr.new_empty(n, nl, hd, wd)
+        with torch.cuda.device(alpha_lr.device):
+            _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
+                      _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), b, t, tw, nl, ncls, c, chan_off, h, w,
+                      scale, _lib.current_stream(alpha_lr.device))
+        ctx.save_for_backward(alpha_lr, input, dist, occ)
+        ctx.cfg = (tw, chan_off, scale)
+        return a01, out
+
+    @staticmethod
+    def backward(ctx, g_a01, g_out):
+        alpha_lr, input, dist, occ = ctx.saved_tensors
+        tw, chan_off, scale = ctx.cfg
+        n, nl, h, w = alpha_lr.shape
+        b, t, c, hd, wd = input.shape
+        ncls = dist.shape[2] if dist is not None else 0
+        # alpha_out = 2 a01 - 1
+        if g_a01 is None:
+            g = 2.0 * g_out
+        elif g_out is None:
+            g = g_a01
+        else:
+            g = g_a01 + 2.0 * g_out
+        g = _c(g)
+        g_lr = torch.empty_like(alpha_lr)
+        g_dist = torch.zeros_like(dist) if (dist is not None and ctx.needs_input_grad[2]) else None
+        g_occ = torch.zeros_like(occ) if ctx.needs_input_grad[3] else None
+        ws = alpha_lr.new_empty(n, nl, hd, wd) if scale > 1 else None
+        with torch.cuda.device(alpha_lr.device):
+            _lib.call("waldo_flow_ctx_alpha_bwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
+                      _lib.ptr(occ), _lib.ptr(g), _lib.ptr(g_lr), _lib.ptr(g_dist), _lib.ptr(g_occ),
+                      _lib.ptr(ws), b, t, tw, nl, ncls, c, chan_off, h, w, scale,
+                      _lib.current_stream(alpha_lr.device))
+        return g_lr, None, g_dist, g_occ, None, None, None
+
+
 def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale):
     """Upsampling + layout filter + first occlusion product (models/nets/lvd.py:731-766).
     alpha_lr (B*Tw, L, H, W) in [0, 1]; input (B, T, C, Hd, Wd) with the layout logits in channels
     [chan_off, chan_off + Nl); dist (B, L-1, Nl) or None (no filter); occ (B, T, L, L).
     Returns (a01, alpha) of shape (B*Tw, L, Hd, Wd): the composited alpha in [0, 1] and 2a - 1.
-    Inference path: no autograd graph is recorded."""
+    Differentiable w.r.t. alpha_lr, dist and occ (the frames / layouts in ``input`` are data)."""
     _lib.check_cuda(alpha_lr, input, occ)
-    alpha_lr, input, occ = _c(alpha_lr.detach()), _c(input.detach()), _c(occ.detach())
+    alpha_lr, input, occ = _c(alpha_lr), _c(input.detach()), _c(occ)
     n, nl, h, w = alpha_lr.shape
     b, t, c, hd, wd = input.shape
     if n != b * tw or tuple(occ.shape) != (b, t, nl, nl) or hd != h * scale or wd != w * scale:
         raise _lib.WaldoHipError(
             f"flow_ctx_alpha: inconsistent shapes alpha_lr={tuple(alpha_lr.shape)} input={tuple(input.shape)} "
             f"occ={tuple(occ.shape)} tw={tw} scale={scale}")
-    ncls = 0
     if dist is not None:
-        dist = _c(dist.detach())
-        ncls = dist.shape[2]
+        dist = _c(dist)
         if tuple(dist.shape[:2]) != (b, nl - 1):
             raise _lib.WaldoHipError(f"flow_ctx_alpha: dist {tuple(dist.shape)} is not (B, L-1, Nl)")
-    a01 = alpha_lr.new_empty(n, nl, hd, wd)
-    out = alpha_lr.new_empty(n, nl, hd, wd)
-    with torch.cuda.device(alpha_lr.device):
-        _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
-                  _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), b, t, tw, nl, ncls, c, chan_off, h, w,
-                  scale, _lib.current_stream(alpha_lr.device))
-    return a01, out
+    return _FlowCtxAlpha.apply(alpha_lr, input, dist, occ, tw, chan_off, scale)
+
+
+class _FlowCtxWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
+        m, nl, _, h, w = flow_lr.shape
+        b, tc, tp = ctx_ts.shape
+        t = occ.shape[1]
+        hd, wd = a01.shape[-2:]
+        flow = flow_lr.new_empty(m, 2, hd, wd)
+        alpha_ctx = flow_lr.new_empty(m, nl, hd, wd)
+        disocc = flow_lr.new_empty(m, hd, wd)
+        with torch.cuda.device(flow_lr.device):
+            _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
+                      _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
+                      _lib.ptr(disocc), b, t, tw, tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
+        ctx.save_for_backward(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ)
+        ctx.cfg = (tw, scale)
+        return flow, alpha_ctx, disocc
+
+    @staticmethod
+    def backward(ctx, g_flow, g_actx, g_dis):
+        flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = ctx.saved_tensors
+        tw, scale = ctx.cfg
+        m, nl, _, h, w = flow_lr.shape
+        b, tc, tp = ctx_ts.shape
+        t = occ.shape[1]
+        hd, wd = a01.shape[-2:]
+        g_flow = _c(g_flow) if g_flow is not None else None
+        g_actx = _c(g_actx) if g_actx is not None else None
+        g_dis = _c(g_dis) if g_dis is not None else None
+        g_lr = torch.empty_like(flow_lr)
+        g_a01 = torch.zeros_like(a01) if ctx.needs_input_grad[2] else None
+        g_occ = torch.zeros_like(occ) if ctx.needs_input_grad[5] else None
+        ws = flow_lr.new_empty(m, nl, 2, hd, wd) if scale > 1 else None
+        with torch.cuda.device(flow_lr.device):
+            _lib.call("waldo_flow_ctx_warp_bwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
+                      _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(g_flow), _lib.ptr(g_actx),
+                      _lib.ptr(g_dis), _lib.ptr(g_lr), _lib.ptr(g_a01), _lib.ptr(g_occ), _lib.ptr(ws), b, t, tw,
+                      tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
+        return g_lr, None, g_a01, None, None, g_occ, None, None
 
 
 def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
@@ -434,16 +510,16 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
     (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
     a01 (B*Tw, L, Hd, Wd) from flow_ctx_alpha; ctx_ts (B, Tc, Tp) long; pred_ts (Tp) long;
     occ (B, T, L, L).  Returns flow (M, 2, Hd, Wd), alpha_ctx (M, L, Hd, Wd) in [-1, 1],
-    disocc (M, Hd, Wd)."""
+    disocc (M, Hd, Wd).  Differentiable w.r.t. flow_lr, a01 and occ (the thresholded ghost mask
+    carries no gradient, as in the reference)."""
     _lib.check_cuda(flow_lr, a01, occ)
     if not (ctx_ts.is_cuda and pred_ts.is_cuda):
         raise _lib.WaldoHipError("flow_ctx_warp: ctx_ts / pred_ts must be on the GPU")
-    flow_lr, a01, occ = _c(flow_lr.detach()), _c(a01), _c(occ.detach())
+    flow_lr, a01, occ = _c(flow_lr), _c(a01), _c(occ)
     ctx_ts, pred_ts = _c(ctx_ts.long()), _c(pred_ts.long())
     m, nl, _, h, w = flow_lr.shape
     b, tc, tp = ctx_ts.shape
     t = occ.shape[1]
-    hd, wd = a01.shape[-2:]
     if m != b * tc * tp or pred_ts.numel() != tp or tuple(a01.shape) != (b * tw, nl, h * scale, w * scale) \
             or tuple(occ.shape) != (b, t, nl, nl):
         raise _lib.WaldoHipError(
@@ -454,27 +530,54 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
         isobj_lr = _c(isobj_lr.detach())
         if tuple(isobj_lr.shape) != (m, nl - 1, h, w):
             raise _lib.WaldoHipError(f"flow_ctx_warp: isobj_lr {tuple(isobj_lr.shape)} is not (M, L-1, H, W)")
-    flow = flow_lr.new_empty(m, 2, hd, wd)
-    alpha_ctx = flow_lr.new_empty(m, nl, hd, wd)
-    disocc = flow_lr.new_empty(m, hd, wd)
-    with torch.cuda.device(flow_lr.device):
-        _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
-                  _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
-                  _lib.ptr(disocc), b, t, tw, tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
-    return flow, alpha_ctx, disocc
+    return _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale)
 
 
 MAX_FUSE_CTX = 8
 
 
+class _FrameWarpFuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, flow, alpha, ctx_ts, include_self, eps):
+        b, t, c, hd, wd = input.shape
+        _, tc, tp, nl = alpha.shape[:4]
+        tcx = tc + (1 if include_self else 0)
+        out = input.new_empty(b, tp, c + 1, hd, wd)
+        raw = input.new_empty(b, tcx, tp, c + nl, hd, wd)
+        with torch.cuda.device(input.device):
+            _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
+                      _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
+                      1 if include_self else 0, float(eps), _lib.current_stream(input.device))
+        ctx.save_for_backward(input, flow, alpha, ctx_ts)
+        ctx.cfg = (bool(include_self), float(eps))
+        return out, raw
+
+    @staticmethod
+    def backward(ctx, g_out, g_raw):
+        input, flow, alpha, ctx_ts = ctx.saved_tensors
+        include_self, eps = ctx.cfg
+        b, t, c, hd, wd = input.shape
+        _, tc, tp, nl = alpha.shape[:4]
+        g_out = _c(g_out) if g_out is not None else None
+        g_raw = _c(g_raw) if g_raw is not None else None
+        g_flow = torch.empty_like(flow)
+        g_alpha = torch.empty_like(alpha)
+        with torch.cuda.device(input.device):
+            _lib.call("waldo_frame_warp_fuse_bwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
+                      _lib.ptr(ctx_ts), _lib.ptr(g_out), _lib.ptr(g_raw), _lib.ptr(g_flow), _lib.ptr(g_alpha), b, t,
+                      tc, tp, c, nl, hd, wd, 1 if include_self else 0, eps, _lib.current_stream(input.device))
+        return None, g_flow, g_alpha, None, None, None
+
+
 def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
-    """Warper.input_to_output (models/nets/lvd.py:830-853), forward only.  input (B,T,C,Hd,Wd);
+    """Warper.input_to_output (models/nets/lvd.py:830-853).  input (B,T,C,Hd,Wd);
     flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1]; ctx_ts (B,Tc,Tp) long.
-    Returns (out (B,Tp,C+1,Hd,Wd), raw (B,Tc',Tp,C+L,Hd,Wd))."""
+    Returns (out (B,Tp,C+1,Hd,Wd), raw (B,Tc',Tp,C+L,Hd,Wd)).  Differentiable w.r.t. flow and alpha;
+    the frames in ``input`` are data (no gradient is produced for them)."""
     _lib.check_cuda(input, flow, alpha)
     if not ctx_ts.is_cuda:
         raise _lib.WaldoHipError("frame_warp_fuse: ctx_ts must be on the GPU")
-    input, flow, alpha = _c(input.detach()), _c(flow.detach()), _c(alpha.detach())
+    input, flow, alpha = _c(input.detach()), _c(flow), _c(alpha)
     ctx_ts = _c(ctx_ts.long())
     b, t, c, hd, wd = input.shape
     _, tc, tp, nl = alpha.shape[:4]
@@ -483,14 +586,7 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
         raise _lib.WaldoHipError(
             f"frame_warp_fuse: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
             f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
-    tcx = tc + (1 if include_self else 0)
-    out = input.new_empty(b, tp, c + 1, hd, wd)
-    raw = input.new_empty(b, tcx, tp, c + nl, hd, wd)
-    with torch.cuda.device(input.device):
-        _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
-                  _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
-                  1 if include_self else 0, float(eps), _lib.current_stream(input.device))
-    return out, raw
+    return _FrameWarpFuse.apply(input, flow, alpha, ctx_ts, bool(include_self), eps)
 
 
 # --------------------------------------------------------------------------------------

@@ -8,9 +8,11 @@ are.  Every resampling (``F.grid_sample`` in the reference), every occlusion pro
 (``(1 - alpha * occ).prod(dim)``), the TPS grids and the grid inversion run in the hand-written
 gfx950 kernels of ``waldo_amd.functional``; what is left in PyTorch is indexing, concatenation,
 the small low-resolution softmax / mean of the layout filter and the bilinear ``F.interpolate``
-rescale.  When no autograd graph is needed (inference), the full-resolution passes of
-``grid_to_flow[_ctx]`` and ``input_to_output`` run fused (csrc/flow_ctx.hip; row f1 of SURVEY.md
-section 8).  No CPU path: tensors must live on the GPU.
+rescale of the layouts.  The full-resolution passes of ``grid_to_flow[_ctx]`` and
+``input_to_output`` run fused, forward (csrc/flow_ctx.hip; row f1 of SURVEY.md section 8) and
+backward (csrc/flow_ctx_bwd.hip: the reference's live backward path in LVD training); the per-op
+composition stays as the fallback for non-integer scales and for frames that require a gradient.
+No CPU path: tensors must live on the GPU.
 
 The occlusion products never materialise the reference's (L, L, h, w) broadcast, so the
 ``fast`` / ``restrict_to_ctx`` memory switches of the reference only change WHAT is returned
@@ -116,7 +118,7 @@ class Warper(nn.Module):
         self.invert_bg = InverseWarp(*self.src_shape, *self.src_shape, num_perm=opt.num_perm_grid)
         self.no_filter = opt.no_filter
         self.allow_ghost = opt.allow_ghost
-        self.fuse_hd = True  # inference: run the two full-resolution passes of grid_to_flow[_ctx] fused
+        self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused
 
     # ------------------------------------------------------------------ image -> layer space
     def layer_from_input(self, input, grid):
@@ -244,9 +246,10 @@ class Warper(nn.Module):
         return torch.stack(out, dim=2)
 
     def _fused_ok(self, tensors, nl, ncls):
-        """The fused HD passes are forward-only kernels with an integer upsampling factor."""
+        """The fused HD passes (forward and backward kernels) need an integer upsampling factor and
+        frames that are data: ``tensors[0]`` (the input video / layout) must not require a gradient."""
         s = self.scale_hd
-        return (not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+        return (not (torch.is_grad_enabled() and tensors[0] is not None and tensors[0].requires_grad)
                 and float(s) == int(s) and int(s) >= 1 and nl <= 32 and 1 <= ncls <= 32
                 and self.src_shape_hd[0] == self.src_shape[0] * int(s)
                 and self.src_shape_hd[1] == self.src_shape[1] * int(s))
@@ -362,7 +365,7 @@ class Warper(nn.Module):
         b, tc, tp = flow.shape[:3]
         self_slot = self.include_self and tp == input.size(1)
         if self.fuse_hd and tc + int(self_slot) <= WF.MAX_FUSE_CTX and \
-                not (torch.is_grad_enabled() and any(x.requires_grad for x in (input, alpha, flow))):
+                not (torch.is_grad_enabled() and input.requires_grad):
             return WF.frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=self_slot, eps=eps)
         hd, wd = self.src_shape_hd
         c = input.size(-3)
