@@ -230,6 +230,42 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[N], int lane) 
   return TransposeReduce<N, 32>::run(v, lane);
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming 16-byte stores / loads for data that is written once and read once by ANOTHER kernel
+// (the records between K1 and K2, the gradient planes K2 writes): the cache policy is a compile-time
+// choice so that variants can be measured against each other (tools_dev/ab_bench.py).
+//   policy 0: plain store (line stays in the XCD's L2)   1: sc1, write-through (line dropped)
+//          2: nt
+// ---------------------------------------------------------------------------------------
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
+
+template <int POLICY>
+__device__ __forceinline__ void stream_store16(float* uniform_base, uint32_t byte_off, int64_t bytes, f32x4_s v) {
+  if constexpr (POLICY == 1) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_base, 0, (int)bytes, 0x00020000);
+    u32x4_s u;
+    __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)byte_off, 0, 16);
+  } else if constexpr (POLICY == 2) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_s*>(reinterpret_cast<char*>(uniform_base) + byte_off));
+  } else {
+    *reinterpret_cast<f32x4_s*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
+  }
+}
+
+// measured at the headline shape (backward 2.247 ms with plain stores): records nt 2.210, sc1 2.236;
+// gradient planes nt 2.218; both nt 2.193; nt LOADS of the records in K2 2.267 (worse)
+#ifndef WALDO_REC_STORE_POLICY
+#define WALDO_REC_STORE_POLICY 2
+#endif
+#ifndef WALDO_REC_LOAD_NT
+#define WALDO_REC_LOAD_NT 0
+#endif
+#ifndef WALDO_GRAD_STORE_POLICY
+#define WALDO_GRAD_STORE_POLICY 2
+#endif
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic but NOT for its outstanding global
 // loads / stores (__syncthreads() also emits s_waitcnt vmcnt(0), which would serialise a prefetch
 // that is meant to stay in flight across the barrier)

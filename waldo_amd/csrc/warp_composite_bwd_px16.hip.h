@@ -452,7 +452,9 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
       for (int l = 0; l < LP; ++l)
         if (EXL || l < L)
-          rec[((int64_t)f * L + l) * HW + p] = make_float4(gxs[l], gys[l], ap[l], l >= 1 ? 0.5f * ga[l] : 0.0f);
+          stream_store16<WALDO_REC_STORE_POLICY>(reinterpret_cast<float*>(rec + ((int64_t)f * L + l) * HW),
+                                                 (uint32_t)p * 16u, HW * 16,
+                                                 (f32x4){gxs[l], gys[l], ap[l], l >= 1 ? 0.5f * ga[l] : 0.0f});
     }
     if constexpr (!kPark) lds_barrier();  // every wave is done sampling: gg overlays the staged image
     {

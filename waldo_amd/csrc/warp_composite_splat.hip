@@ -228,7 +228,15 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         k.livep = i < total && py < H && px < W;
         k.p = (unsigned)(__mul24(min(py, H - 1), W) + min(px, W - 1));
         // 32-bit byte offsets from uniform bases (HW * 8 < 2^32 is implied by the launcher's check)
+#if WALDO_REC_LOAD_NT
+        {
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(rcp) + k.p * 16u));
+          k.rc = make_float4(r[0], r[1], r[2], r[3]);
+        }
+#else
         k.rc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(rcp) + k.p * 16u);
+#endif
         k.g0 = ldb(gplane, k.p * 4u);
         k.g1 = ldb(gplane + HW, k.p * 4u);
         k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
@@ -310,8 +318,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         for (int c = 0; c < 4; ++c) {
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
           const float inv = c < 3 ? inv_rgb : inv_a;
-          *reinterpret_cast<f32x4*>(gbase + c * HW + doff) =
-              (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv};
+          stream_store16<WALDO_GRAD_STORE_POLICY>(gbase + c * HW, doff * 4u, HW * 4,
+                                                  (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv});
         }
       }
     }
