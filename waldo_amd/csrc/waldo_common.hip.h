@@ -212,9 +212,23 @@ struct TransposeReduce {
     for (int m = 0; m < M; ++m) {
       float a = v[2 * m];
       float b = (2 * m + 1 < N) ? v[2 * m + 1] : 0.0f;
-      float keep = hi ? b : a;
-      float send = hi ? a : b;
-      w[m] = keep + __shfl_xor(send, D, kWave);
+      if constexpr (D == 32 || D == 16) {
+        // lanes with bit D clear keep a, the others b, each plus its partner's copy of the same:
+        // exactly what the row / half swap of (a, b) lays side by side -- one VALU swap and one add
+        // instead of two selects, a ds_bpermute and its wait (3/4 of this function's exchanges)
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        if constexpr (D == 32) {
+          const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+          w[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        } else {
+          const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+          w[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+      } else {
+        float keep = hi ? b : a;
+        float send = hi ? a : b;
+        w[m] = keep + __shfl_xor(send, D, kWave);
+      }
     }
     if constexpr (D == 1) {
       return w[0];
@@ -266,6 +280,38 @@ __device__ __forceinline__ void stream_store16(float* uniform_base, uint32_t byt
 #define WALDO_GRAD_STORE_POLICY 2
 #endif
 
+// ---------------------------------------------------------------------------------------
+// Exchanges between the four 16-lane ROWS of a wavefront without the LDS crossbar: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange odd rows of one register with even rows of another
+// (halves for the 32 form).  Fed the same value twice they return (A, B) with, in every lane, the
+// lane's own value in one and its xor-16 (xor-32) partner's in the other -- for a commutative op
+// that is all a butterfly step needs: one VALU instruction instead of a ds_bpermute and its wait.
+// ---------------------------------------------------------------------------------------
+template <class Op>
+__device__ __forceinline__ unsigned rows_combine_u(unsigned v, Op op) {
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = op(r[0], r[1]);
+  r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return op(r[0], r[1]);
+}
+
+// min / max of a float over the lanes {l, l ^ 16, l ^ 32, l ^ 48} (the same column of the 4 rows)
+__device__ __forceinline__ float rows_min(float v) {
+  return __uint_as_float(rows_combine_u(__float_as_uint(v), [](unsigned a, unsigned b) {
+    return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b)));
+  }));
+}
+__device__ __forceinline__ float rows_max(float v) {
+  return __uint_as_float(rows_combine_u(__float_as_uint(v), [](unsigned a, unsigned b) {
+    return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
+  }));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  return __uint_as_float(rows_combine_u(__float_as_uint(v), [](unsigned a, unsigned b) {
+    return __float_as_uint(__uint_as_float(a) + __uint_as_float(b));
+  }));
+}
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic but NOT for its outstanding global
 // loads / stores (__syncthreads() also emits s_waitcnt vmcnt(0), which would serialise a prefetch
 // that is meant to stay in flight across the barrier)
@@ -275,8 +321,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
-  return v;
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return rows_sum(v);
 }
 
 __device__ __forceinline__ int wave_min_i(int v) {

@@ -104,3 +104,9 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
                 grad_layers, grad_mapping, grad_occ, workspace, (int)F, L, H, W, K3, st);
   return launch_status("waldo_warp_composite_bwd");
 }
+
+#ifdef WALDO_K1_STAMPS
+// diagnostic builds only: copies the stamp buffer of the LP = 8 translation unit to the host
+namespace waldo { int k1_stamps_read(unsigned long long* dst, int n); }
+extern "C" int waldo_debug_k1_stamps(unsigned long long* dst, int n) { return waldo::k1_stamps_read(dst, n); }
+#endif

@@ -74,6 +74,21 @@ struct Px16Cfg {
   static constexpr int kWavesPerSimd = LP <= 8 ? 3 : 2;
 };
 
+// Diagnostic build only (-DWALDO_K1_STAMPS): s_memtime stamps of wave 0 at the phase boundaries of
+// the LAST frame of a workgroup's chunk, into a buffer of the code object that no kernel reads
+// (tools_dev/k1_stamps.py); never compiled into the product library.
+#ifdef WALDO_K1_STAMPS
+constexpr int kStampSlots = 24, kStampBlocks = 8192;
+__device__ unsigned long long waldo_k1_stamps[kStampBlocks * kStampSlots];
+#define WALDO_STAMP(i)                                                                            \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && f == f1 - 1 && blockIdx.x < kStampBlocks)                             \
+      waldo_k1_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#else
+#define WALDO_STAMP(i) do { } while (0)
+#endif
+
 template <int LP, bool EXL, bool GOCC>
 __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) void warp_composite_bwd_px16_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
   const int f1 = min(F, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
     const float* oc = occ + (int64_t)f * L * L;
+    WALDO_STAMP(0);
     // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (see
     // warp_composite_fwd_lds_kernel):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
@@ -178,10 +194,8 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           mn = fminf(mn, acc[g][nt][r]);
           mx = fmaxf(mx, acc[g][nt][r]);
         }
-      mn = fminf(mn, __shfl_xor(mn, 16, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-      mn = fminf(mn, __shfl_xor(mn, 32, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      mn = rows_min(mn);
+      mx = rows_max(mx);
       if (kk == 0) {
         boxred[(wave * GGC + nt * 16 + arow) * 2 + 0] = mn;
         boxred[(wave * GGC + nt * 16 + arow) * 2 + 1] = mx;
@@ -206,6 +220,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       }
     }
     __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
+    WALDO_STAMP(1);
     // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 turn the range of "their" column
     // (layer, xy) into block origins -- per cell of the footprint table (this tile owns its cells:
     // plain stores in the splat kernel's format (min x, -max x, min y, -max y)) and for the whole
@@ -288,6 +303,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
+    WALDO_STAMP(2);
     {
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
@@ -309,6 +325,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
+        if (l < 8) WALDO_STAMP(3 + l);
         const TapCore tc = tap_core_px(gxs[l], gys[l], H, W);
         const float* b0 = img + (l & 1) * kImgBufFloats;
         float sv[4], sx[4], sy[4];
@@ -379,6 +396,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       }
     }
 
+    WALDO_STAMP(11);
     // ---- (F) composite backward (lvd.py:100-114): a'_j = a_j prod_i (1 - a_i occ[i][j]).
     // Two layers j per step on the packed-fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of
     // work per VALU issue slot -- this kernel is issue bound); the contributions of even and odd j
@@ -445,6 +463,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
       for (int l = 0; l < LP; ++l) ga[l] += ga2[l][0] + ga2[l][1];
     }
+    WALDO_STAMP(12);
     // ---- (G) a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Records, contribution bounds
     // and the grid gradient of every layer.  The records go out FIRST: the stores get the rest of
     // this phase to drain.
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     if constexpr (!kPark) lds_barrier();  // every wave is done sampling: gg overlays the staged image
     {
       float ggx[LP], ggy[LP];
+      int eb[LP];
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
         const bool pad = !EXL && l >= L;
@@ -488,9 +508,12 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         v = pk_max_u16(v, row_ror_i<4>(v));
         v = pk_max_u16(v, row_ror_i<2>(v));
         v = pk_max_u16(v, row_ror_i<1>(v));
-        v = pk_max_u16(v, __shfl_xor(v, 16, kWave));
-        v = pk_max_u16(v, __shfl_xor(v, 32, kWave));
-        if (lane == 0) wbound[wave * LP + l] = v;
+        eb[l] = (int)rows_combine_u((unsigned)v, [](unsigned x, unsigned y) { return (unsigned)pk_max_u16((int)x, (int)y); });
+      }
+      // every lane now holds every layer's bound: one masked store region for all of them
+      if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < LP; ++l) wbound[wave * LP + l] = eb[l];
       }
       // this thread's column of gg: with parking it overwrites the thread's own parked values
 #pragma unroll
@@ -502,6 +525,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       for (int c = 2 * LP; c < GGC; ++c) gg[c * PP1 + pix] = 0.0f;
     }
     __syncthreads();  // gg rows and the waves' bounds are complete
+    WALDO_STAMP(13);
     {
       constexpr int kCellsPerTile = kLdsTile / kCellRows, kWavesPerCell = 4 / kCellsPerTile;
       if (threadIdx.x < kCellsPerTile * LP) {
@@ -552,6 +576,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             macc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bv, macc[mt][nt], 0, 0, 0);
         }
       }
+      WALDO_STAMP(14);
       __syncthreads();  // every wave is done reading gg: reuse its bytes for the accumulators
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -574,6 +599,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       }
     }
     __syncthreads();  // the stage region, boxred and wbound are re-used by the next frame
+    WALDO_STAMP(15);
   }
 }
 

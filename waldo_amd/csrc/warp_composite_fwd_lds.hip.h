@@ -38,7 +38,8 @@
 namespace waldo {
 
 #ifndef WALDO_STAGE_AHEAD
-#define WALDO_STAGE_AHEAD 4  // layers whose box loads are in flight at a time
+#define WALDO_STAGE_AHEAD 2  // layers whose box loads are in flight at a time (measured 2 / 3 / 4 / 6 / 8:
+                             // fwd 0.726 / 0.728 / 0.736 / 0.836 / 0.990 ms, bwd 2.222 / 2.225 / 2.242 / 2.58 / 2.59)
 #endif
 
 struct BoxTaps {
@@ -230,10 +231,8 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
           mn = fminf(mn, acc[g][nt][r]);
           mx = fmaxf(mx, acc[g][nt][r]);
         }
-      mn = fminf(mn, __shfl_xor(mn, 16, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-      mn = fminf(mn, __shfl_xor(mn, 32, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      mn = rows_min(mn);
+      mx = rows_max(mx);
       if (kk == 0) {
         boxred[(wave * GGC + nt * 16 + arow) * 2 + 0] = mn;
         boxred[(wave * GGC + nt * 16 + arow) * 2 + 1] = mx;

@@ -1,2 +1,10 @@
 #define WALDO_LP 8
 #include "warp_composite_inst.hip.h"
+
+#ifdef WALDO_K1_STAMPS
+namespace waldo {
+int k1_stamps_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(waldo_k1_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+}  // namespace waldo
+#endif
