@@ -23,6 +23,9 @@
 namespace waldo {
 
 constexpr int kAccTilesMax = 16;  // pixel tiles a workgroup walks before it flushes its LDS tables
+// The two flow_ctx backward kernels are compiled for >= 3 waves per SIMD (168 VGPRs): at L = 17 they
+// want 210 / 300+ registers and would run one or two waves per SIMD; with the cap they spill ~100 /
+// ~1000 bytes per lane to scratch and the LVD-recipe step is 5 % faster (3.85 -> 3.67 ms).
 
 __device__ __forceinline__ float sgnf(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
 
@@ -73,7 +76,7 @@ __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float 
 }
 
 template <int LP>
-__global__ __launch_bounds__(kBlock) void flow_ctx_alpha_bwd_kernel(
+__global__ __launch_bounds__(kBlock, 3) void flow_ctx_alpha_bwd_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, const float* __restrict__ g_a01,
     float* __restrict__ g_up, float* __restrict__ g_dist, float* __restrict__ g_occ, int T, int Tw,
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_bwd_kernel(
 }
 
 template <int LP>
-__global__ __launch_bounds__(kBlock) void flow_ctx_warp_bwd_kernel(
+__global__ __launch_bounds__(kBlock, 3) void flow_ctx_warp_bwd_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ,
