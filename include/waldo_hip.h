@@ -83,6 +83,18 @@ int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id, const flo
                            float* field_a, float* field_b, unsigned char* fill_iter, float* denom,
                            unsigned char* mask_a, unsigned char* mask_b, int64_t B, int Hs, int Ws,
                            int H, int W, int niter, int erode, waldo_stream_t stream);
+/* The same with the tie-break order given (InverseWarp with num_perm > 1, warp.py:91-111, one
+ * call per permutation; the results are averaged by the caller -- the fill, the erosion and the
+ * final grid are linear in the elected field for a fixed set of occupied cells, and that set does
+ * not depend on the order):  order (H*W) i32 a permutation of the samples (one row of the
+ * reference buffer `perm`), rank (H*W) i32 its inverse.  Among the samples landing on one cell
+ * the one standing first in `order` wins.  waldo_inverse_warp_bwd serves both. */
+int waldo_inverse_warp_order_fwd(const float* src_grid, const float* src_id, const float* tgt_id,
+                                 const float* gauss3x3, const int* rank, const int* order,
+                                 float* out, float* dxy, int* cell, int* winner, float* field_a,
+                                 float* field_b, unsigned char* fill_iter, float* denom,
+                                 unsigned char* mask_a, unsigned char* mask_b, int64_t B, int Hs,
+                                 int Ws, int H, int W, int niter, int erode, waldo_stream_t stream);
 int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3, const int* cell,
                            const int* winner, const unsigned char* fill_iter, const float* denom,
                            const unsigned char* mask, float* gfield, float* grad_src_grid,

@@ -141,6 +141,25 @@ def gen_inverse_warp(ns):
              hs=hs, ws=ws, ht=ht, wt=wt, erode=erode)
 
 
+def gen_inverse_warp_perm(ns):
+    """num_perm > 1 (warp.py:91-111): the module's own randperm buffer goes into the fixture."""
+    g = torch.Generator().manual_seed(15)
+    ctrl = ns.get_grid(4, 4).view(-1, 2)
+    for tag, (hs, ws, ht, wt, erode, shrink, sigma, nperm) in {
+            "perm3": (8, 8, 16, 32, True, 0.5, 0.12, 3), "perm4": (12, 20, 24, 40, False, 0.45, 0.15, 4)}.items():
+        torch.manual_seed(31)  # the perm buffer draws from the global generator
+        inv = ns.InverseWarp(hs, ws, ht, wt, num_perm=nperm)
+        tps = ns.TPSWarp(hs, ws, ctrl)
+        pts = ctrl.view(1, 16, 2) * shrink + sigma * torch.randn(3, 16, 2, generator=g)
+        src_grid = tps(pts).detach().requires_grad_()
+        with R.stable_sort():
+            out = inv(src_grid, erode=erode)
+        wgt = torch.randn(out.shape, generator=g)
+        (out * wgt).sum().backward()
+        save(f"inverse_warp_{tag}", src_grid=src_grid, out=out, wgt=wgt, grad_src_grid=src_grid.grad,
+             perm=inv.perm.to(torch.int32), hs=hs, ws=ws, ht=ht, wt=wt, erode=erode)
+
+
 def gen_warper(ns):
     """Warper.forward -> grid_to_flow_ctx -> input_to_output (the inference chain of
     LVD decode_output, lvd.py:141-153) and grid_to_flow (training), plus WIF.forward's fusion."""
@@ -333,15 +352,13 @@ def gen_demo_clip():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
-    gen_tps(ns)
-    gen_grid_sample(ns)
-    gen_occ_comp(ns)
-    gen_warp_composite(ns)
-    gen_inverse_warp(ns)
-    gen_warper(ns)
-    gen_inpaint(ns)
-    gen_producers(ns)
-    gen_demo_clip()
+    only = set(sys.argv[1:])  # e.g. `make_golden.py inverse_warp_perm`; none = all
+    for fn in (gen_tps, gen_grid_sample, gen_occ_comp, gen_warp_composite, gen_inverse_warp,
+               gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers):
+        if not only or fn.__name__[4:] in only:
+            fn(ns)
+    if not only or "demo_clip" in only:
+        gen_demo_clip()
 
 
 if __name__ == "__main__":

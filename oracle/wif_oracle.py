@@ -239,8 +239,8 @@ def make_synthetic(frames, nl, h, w, k_side=4, seed=0, sigma=0.05, smooth=0):
 # --------------------------------------------------------------------------------------
 
 
-def inverse_warp(src_grid, tgt_shape, niter=5, pad=True, erode=True, kernel_size=3):
-    """InverseWarp.forward with num_perm == 1, models/modules/warp.py:71-174.
+def inverse_warp(src_grid, tgt_shape, niter=5, pad=True, erode=True, kernel_size=3, perm=None):
+    """InverseWarp.forward, models/modules/warp.py:71-174 (perm None: num_perm == 1).
 
     src_grid (B, Hs, Ws, 2) maps layer space -> image space; the result (B, H, W, 2) maps image
     space -> layer space.  Restated as: (1) displacement, bilinearly resized to the target
@@ -250,6 +250,9 @@ def inverse_warp(src_grid, tgt_shape, niter=5, pad=True, erode=True, kernel_size
     passes: the 4-neighbour ring of the filled set takes the Gaussian-weighted mean of the
     filled 3x3 neighbours (warp.py:135-151); (4) optional erosion (warp.py:153-162);
     (5) unfilled cells get the offset (2W, 2H) px, i.e. sample out of range (warp.py:164-167).
+    With perm (P, H*W), P > 1 (warp.py:91-111): step (2) runs once per row with the samples taken
+    in that order -- the one standing first in perm[p] wins -- and the P elected fields are
+    averaged; the set of occupied cells is the same for every row (the reference takes row 0's).
     Differentiable w.r.t. the displacement values (not the integer cell indices)."""
     b, hs, ws, _ = src_grid.shape
     h, w = tgt_shape
@@ -267,13 +270,24 @@ def inverse_warp(src_grid, tgt_shape, niter=5, pad=True, erode=True, kernel_size
     # lowest source index wins: process sources in DEcreasing index order so that the last
     # write (lowest index) survives.  index_put_ with accumulate=False is not ordered, so do
     # the winner selection explicitly with a scatter-min over source indices.
-    src_idx = torch.arange(h * w).view(1, -1).expand(b, -1)
-    winner = torch.full((b, h * w + 1), h * w, dtype=torch.long)
-    winner = winner.scatter_reduce(1, cell, src_idx, reduce="amin", include_self=True)[:, :h * w]
-    mask = winner < h * w
-    wsafe = winner.clamp(max=h * w - 1)
-    inv_dx = torch.where(mask, -torch.gather(dx, 1, wsafe), torch.zeros_like(dx)).view(b, h, w)
-    inv_dy = torch.where(mask, -torch.gather(dy, 1, wsafe), torch.zeros_like(dy)).view(b, h, w)
+    orders = [None] if perm is None else [row.long() for row in perm]
+    inv_dx = inv_dy = 0
+    for order in orders:
+        # position of each sample in the tie-break order (its own index for num_perm == 1)
+        pos = torch.arange(h * w)
+        if order is not None:
+            pos = torch.empty(h * w, dtype=torch.long).scatter_(0, order, torch.arange(h * w))
+        first = torch.full((b, h * w + 1), h * w, dtype=torch.long)
+        first = first.scatter_reduce(1, cell, pos.view(1, -1).expand(b, -1), reduce="amin",
+                                     include_self=True)[:, :h * w]
+        mask = first < h * w
+        wsafe = first.clamp(max=h * w - 1)
+        if order is not None:
+            wsafe = order[wsafe]
+        inv_dx = inv_dx + torch.where(mask, -torch.gather(dx, 1, wsafe), torch.zeros_like(dx))
+        inv_dy = inv_dy + torch.where(mask, -torch.gather(dy, 1, wsafe), torch.zeros_like(dy))
+    inv_dx = (inv_dx / len(orders)).view(b, h, w)
+    inv_dy = (inv_dy / len(orders)).view(b, h, w)
     mask = mask.view(b, h, w)
     if pad:
         p = n + 1

@@ -46,6 +46,45 @@ def test_inverse_warp_golden(dev, golden, tag):
     close(sg.grad, g["grad_src_grid"], rel=True, what="grad_src_grid")
 
 
+@pytest.mark.parametrize("tag", ["perm3", "perm4"])
+def test_inverse_warp_num_perm_golden(dev, golden, tag):
+    """num_perm > 1 (warp.py:91-111) against the reference's own output for its own perm buffer:
+    the first sample in perm[p] order wins each contested cell, the P fields are averaged."""
+    import waldo_amd
+    g = golden(f"inverse_warp_{tag}")
+    perm = g["perm"]
+    mod = waldo_amd.InverseWarp(int(g["hs"]), int(g["ws"]), int(g["ht"]), int(g["wt"]),
+                                num_perm=perm.shape[0]).to(dev)
+    mod.perm.copy_(perm)
+    sg = g["src_grid"].to(dev).requires_grad_()
+    out = mod(sg, erode=bool(g["erode"]))
+    close(out, g["out"], what="out")
+    (out * g["wgt"].to(dev)).sum().backward()
+    close(sg.grad, g["grad_src_grid"], rel=True, what="grad_src_grid")
+    # the tie-break matters in these cases: sample-index order gives a different field
+    one = waldo_amd.InverseWarp(int(g["hs"]), int(g["ws"]), int(g["ht"]), int(g["wt"])).to(dev)
+    assert (one(sg.detach(), erode=bool(g["erode"])).cpu() - g["out"]).abs().max() > 1e-3
+
+
+def test_inverse_warp_num_perm_random(dev):
+    """Recipe-sized object map, 3 random orders, against the oracle."""
+    import waldo_amd
+    torch.manual_seed(77)
+    ctrl = O.get_grid(4, 4).view(-1, 2)
+    inv, rep = O.tps_init(64, 64, ctrl)
+    pts = ctrl.view(1, 16, 2) * 0.55 + 0.12 * torch.randn(2, 16, 2)
+    sg = O.tps_grid(inv, rep, pts, 64, 64).requires_grad_()
+    mod = waldo_amd.InverseWarp(64, 64, 128, 256, num_perm=3).to(dev)
+    ref = O.inverse_warp(sg, (128, 256), perm=mod.perm.cpu())
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    s2 = sg.detach().to(dev).requires_grad_()
+    out = mod(s2)
+    close(out, ref, what="out")
+    (out * wgt.to(dev)).sum().backward()
+    close(s2.grad, sg.grad, rel=True, what="grad")
+
+
 @pytest.mark.parametrize("cfg", [(8, 8, 16, 32, 5, True), (16, 32, 16, 32, 5, False), (64, 64, 128, 256, 5, True),
                                  (7, 9, 13, 21, 3, True), (8, 8, 8, 8, 0, False), (4, 4, 40, 40, 8, True)])
 def test_inverse_warp_random(dev, cfg):
@@ -78,7 +117,9 @@ def test_inverse_warp_identity_and_errors(dev):
     with pytest.raises(ValueError):
         mod(ident, pad=False)
     with pytest.raises(NotImplementedError):
-        waldo_amd.InverseWarp(8, 8, 8, 8, num_perm=2).to(dev)(O.get_grid(8, 8).to(dev))
+        waldo_amd.InverseWarp(8, 8, 8, 8, kernel_size=5).to(dev)(O.get_grid(8, 8).to(dev))
+    two = waldo_amd.InverseWarp(12, 20, 12, 20, num_perm=2).to(dev)  # no collisions: order is moot
+    close(two(ident, erode=False), ident.cpu(), 1e-6, what="identity, num_perm=2")
     assert mod(torch.zeros(0, 12, 20, 2, device=dev)).shape == (0, 12, 20, 2)
 
 

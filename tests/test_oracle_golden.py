@@ -94,6 +94,19 @@ def test_inverse_warp(golden, tag):
     close(sg.grad, g["grad_src_grid"], 1e-5)
 
 
+@pytest.mark.parametrize("tag", ["perm3", "perm4"])
+def test_inverse_warp_num_perm(golden, tag):
+    """num_perm > 1: the reference's output for its own randperm buffer (stable sort)."""
+    g = golden(f"inverse_warp_{tag}")
+    sg = g["src_grid"].clone().requires_grad_()
+    out = O.inverse_warp(sg, (int(g["ht"]), int(g["wt"])), erode=bool(g["erode"]), perm=g["perm"])
+    close(out, g["out"], 1e-6)
+    (out * g["wgt"]).sum().backward()
+    close(sg.grad, g["grad_src_grid"], 1e-5)
+    plain = O.inverse_warp(sg.detach(), (int(g["ht"]), int(g["wt"])), erode=bool(g["erode"]))
+    assert (plain - g["out"]).abs().max() > 1e-3  # the order matters in these cases
+
+
 def test_inverse_warp_identity():
     """InverseWarp(identity) = identity, fully filled (SURVEY.md section 4 invariant)."""
     ident = O.get_grid(12, 20)

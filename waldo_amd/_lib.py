@@ -27,6 +27,7 @@ SIGNATURES = {
     "waldo_tps_grid_fwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
     "waldo_tps_grid_bwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
     "waldo_inverse_warp_fwd": [_c_f] * 14 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
+    "waldo_inverse_warp_order_fwd": [_c_f] * 16 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
     "waldo_inverse_warp_bwd": [_c_f] * 9 + [_i64, _int, _int, _int, _int, _int, _stream],
     "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
                                 _i64, _stream],

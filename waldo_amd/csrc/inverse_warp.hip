@@ -25,7 +25,8 @@ constexpr int kNoWinner = 0x7f7f7f7f;  // hipMemsetAsync(0x7f)
 // ---- step 1+2: resized displacement, target cell, winner election
 __global__ __launch_bounds__(kBlock) void iw_splat_kernel(
     const float* __restrict__ src_grid, const float* __restrict__ src_id, float* __restrict__ dxy,
-    int* __restrict__ cell, int* __restrict__ winner, int Hs, int Ws, int H, int W) {
+    int* __restrict__ cell, int* __restrict__ winner, const int* __restrict__ rank, int Hs, int Ws,
+    int H, int W) {
   const int64_t b = blockIdx.y;
   const int s = blockIdx.x * kBlock + threadIdx.x;
   const int HW = H * W;
@@ -56,9 +57,20 @@ __global__ __launch_bounds__(kBlock) void iw_splat_kernel(
   int c = -1;
   if (txf >= 0.0f && tyf >= 0.0f && txf <= (float)(W - 1) && tyf <= (float)(H - 1)) {
     c = (int)tyf * W + (int)txf;
-    atomicMin(winner + b * HW + c, s);
+    // priority of a sample among those landing on one cell: its position in the tie-break order
+    atomicMin(winner + b * HW + c, rank ? rank[s] : s);
   }
   cell[b * HW + s] = c;
+}
+
+// ---- step 2b (tie-break order given): the elected position -> the sample standing there
+__global__ __launch_bounds__(kBlock) void iw_unrank_kernel(int* __restrict__ winner,
+                                                           const int* __restrict__ order, int64_t n,
+                                                           int HW) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int w = winner[i];
+  if (w >= 0 && w < HW) winner[i] = order[w];
 }
 
 // ---- step 3a: padded field of the winners
@@ -433,6 +445,16 @@ static int check_iw(const char* fn, int64_t B, int Hs, int Ws, int H, int W, int
 
 using namespace waldo;
 
+namespace waldo {
+static int inverse_warp_fwd_impl(const char* fn, const float* src_grid, const float* src_id,
+                                 const float* tgt_id, const float* gauss3x3, float* out, float* dxy,
+                                 int* cell, int* winner, float* field_a, float* field_b,
+                                 unsigned char* fill_iter, float* denom, unsigned char* mask_a,
+                                 unsigned char* mask_b, const int* rank, const int* order, int64_t B,
+                                 int Hs, int Ws, int H, int W, int niter, int erode,
+                                 waldo_stream_t stream);
+}
+
 extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id,
                                       const float* tgt_id, const float* gauss3x3, float* out,
                                       float* dxy, int* cell, int* winner, float* field_a,
@@ -440,12 +462,41 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
                                       unsigned char* mask_a, unsigned char* mask_b, int64_t B,
                                       int Hs, int Ws, int H, int W, int niter, int erode,
                                       waldo_stream_t stream) {
-  int rc = check_iw("waldo_inverse_warp_fwd", B, Hs, Ws, H, W, niter);
+  return inverse_warp_fwd_impl("waldo_inverse_warp_fwd", src_grid, src_id, tgt_id, gauss3x3, out,
+                               dxy, cell, winner, field_a, field_b, fill_iter, denom, mask_a, mask_b,
+                               nullptr, nullptr, B, Hs, Ws, H, W, niter, erode, stream);
+}
+
+extern "C" int waldo_inverse_warp_order_fwd(const float* src_grid, const float* src_id,
+                                            const float* tgt_id, const float* gauss3x3,
+                                            const int* rank, const int* order, float* out,
+                                            float* dxy, int* cell, int* winner, float* field_a,
+                                            float* field_b, unsigned char* fill_iter, float* denom,
+                                            unsigned char* mask_a, unsigned char* mask_b, int64_t B,
+                                            int Hs, int Ws, int H, int W, int niter, int erode,
+                                            waldo_stream_t stream) {
+  if (B > 0 && (!rank || !order)) {
+    set_error("waldo_inverse_warp_order_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  return inverse_warp_fwd_impl("waldo_inverse_warp_order_fwd", src_grid, src_id, tgt_id, gauss3x3,
+                               out, dxy, cell, winner, field_a, field_b, fill_iter, denom, mask_a,
+                               mask_b, rank, order, B, Hs, Ws, H, W, niter, erode, stream);
+}
+
+int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const float* src_id,
+                                        const float* tgt_id, const float* gauss3x3, float* out,
+                                        float* dxy, int* cell, int* winner, float* field_a,
+                                        float* field_b, unsigned char* fill_iter, float* denom,
+                                        unsigned char* mask_a, unsigned char* mask_b,
+                                        const int* rank, const int* order, int64_t B, int Hs, int Ws,
+                                        int H, int W, int niter, int erode, waldo_stream_t stream) {
+  int rc = check_iw(fn, B, Hs, Ws, H, W, niter);
   if (rc) return rc;
   if (B == 0) return WALDO_OK;
   if (!src_grid || !src_id || !tgt_id || !gauss3x3 || !out || !dxy || !cell || !winner ||
       !field_a || !field_b || !fill_iter || !denom || !mask_a || !mask_b) {
-    set_error("waldo_inverse_warp_fwd: null pointer");
+    set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -455,7 +506,12 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
   dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
   (void)hipMemsetAsync(winner, 0x7f, sizeof(int) * (size_t)B * HW, st);
   hipLaunchKernelGGL(iw_splat_kernel, gs, dim3(kBlock), 0, st, src_grid, src_id, dxy, cell, winner,
-                     Hs, Ws, H, W);
+                     rank, Hs, Ws, H, W);
+  if (order) {
+    const int64_t nw = (int64_t)B * HW;
+    hipLaunchKernelGGL(iw_unrank_kernel, dim3((unsigned)((nw + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       st, winner, order, nw, HW);
+  }
   const bool passes = debug_option(WALDO_DEBUG_IW_PASSES);
   const int tiles_x = (Wp + kFusedTW - 1) / kFusedTW, tiles_y = (Hp + kFusedTH - 1) / kFusedTH;
   const size_t lds = (size_t)(kFusedTH + 4 * niter + 2) * (kFusedTW + 4 * niter + 2) * (2 * sizeof(float) + 3);
@@ -463,7 +519,7 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
     hipLaunchKernelGGL(iw_fused_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(kBlock), lds, st, dxy,
                        winner, gauss3x3, tgt_id, out, fill_iter, denom, mask_a, H, W, niter, erode, tiles_x,
                        tiles_x * tiles_y);
-    return launch_status("waldo_inverse_warp_fwd");
+    return launch_status(fn);
   }
   hipLaunchKernelGGL(iw_gather_kernel, gp, dim3(kBlock), 0, st, dxy, winner, field_a, fill_iter, H,
                      W, pad);
@@ -495,7 +551,7 @@ extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id
     (void)hipMemcpyAsync(mask_a, mi, (size_t)n, hipMemcpyDeviceToDevice, st);
   hipLaunchKernelGGL(iw_finalize_kernel, gs, dim3(kBlock), 0, st, fin, mask_a, tgt_id, out, H, W,
                      pad);
-  return launch_status("waldo_inverse_warp_fwd");
+  return launch_status(fn);
 }
 
 extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3,

@@ -92,7 +92,7 @@ def tps_grid(inverse_kernel, basis_t, src_pts, height, width):
 # --------------------------------------------------------------------------------------
 class _InverseWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src_grid, src_id, tgt_id, gauss, niter, erode):
+    def forward(ctx, src_grid, src_id, tgt_id, gauss, niter, erode, rank, order):
         _lib.check_cuda(src_grid, src_id, tgt_id, gauss)
         src_grid, src_id, tgt_id, gauss = _c(src_grid), _c(src_id), _c(tgt_id), _c(gauss)
         b, hs, ws, _ = src_grid.shape
@@ -110,12 +110,23 @@ class _InverseWarp(torch.autograd.Function):
         denom = src_grid.new_empty(b, hwp)
         mask_a = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
         mask_b = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
+        work = (_lib.ptr(out), _lib.ptr(dxy), _lib.ptr(cell), _lib.ptr(winner), _lib.ptr(field_a),
+                _lib.ptr(field_b), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask_a),
+                _lib.ptr(mask_b), b, hs, ws, h, w, niter, int(bool(erode)))
         with torch.cuda.device(dev):
-            _lib.call("waldo_inverse_warp_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
-                      _lib.ptr(tgt_id), _lib.ptr(gauss), _lib.ptr(out), _lib.ptr(dxy),
-                      _lib.ptr(cell), _lib.ptr(winner), _lib.ptr(field_a), _lib.ptr(field_b),
-                      _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask_a), _lib.ptr(mask_b), b,
-                      hs, ws, h, w, niter, int(bool(erode)), _lib.current_stream(dev))
+            if order is None:
+                _lib.call("waldo_inverse_warp_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
+                          _lib.ptr(tgt_id), _lib.ptr(gauss), *work, _lib.current_stream(dev))
+            else:
+                if not (rank.is_cuda and order.is_cuda):
+                    raise _lib.WaldoHipError("inverse_warp: rank / order must be on the GPU")
+                if (rank.dtype != torch.int32 or order.dtype != torch.int32
+                        or rank.numel() != h * w or order.numel() != h * w):
+                    raise _lib.WaldoHipError("inverse_warp: rank / order must be int32 of H*W elements")
+                rank, order = rank.contiguous(), order.contiguous()
+                _lib.call("waldo_inverse_warp_order_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
+                          _lib.ptr(tgt_id), _lib.ptr(gauss), _lib.ptr(rank), _lib.ptr(order), *work,
+                          _lib.current_stream(dev))
         ctx.save_for_backward(gauss, cell, winner, fill_iter, denom, mask_a)
         ctx.cfg = (b, hs, ws, h, w, niter)
         return out
@@ -132,14 +143,32 @@ class _InverseWarp(torch.autograd.Function):
                       _lib.ptr(winner), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask),
                       _lib.ptr(gfield), _lib.ptr(gsrc), b, hs, ws, h, w, niter,
                       _lib.current_stream(grad_out.device))
-        return gsrc, None, None, None, None, None
+        return gsrc, None, None, None, None, None, None, None
 
 
-def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True):
-    """InverseWarp.forward (models/modules/warp.py:71-174; num_perm == 1, 3x3 kernel, pad).
+def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True, perm=None):
+    """InverseWarp.forward (models/modules/warp.py:71-174; 3x3 kernel, pad).
     src_grid (B, Hs, Ws, 2) -> (B, H, W, 2); src_id / tgt_id are the identity grids of the two
-    rasters, gauss3x3 the normalised Gaussian (the reference module's buffers)."""
-    return _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode))
+    rasters, gauss3x3 the normalised Gaussian (the reference module's buffers).
+
+    perm None: num_perm == 1 (the lowest sample index wins a contested cell, warp.py:113-123).
+    perm (P, H*W) integer, P > 1: the reference's tie-break averaging (warp.py:91-111): for each
+    row the sample standing first in that order wins, and the P elected fields are averaged.  The
+    fill / erosion / crop are linear in the elected field for a fixed set of occupied cells (which
+    does not depend on the order), so the average is taken over the P results instead."""
+    if perm is None:
+        return _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode), None,
+                                  None)
+    order = perm.to(torch.int32)
+    rank = torch.empty_like(order)
+    pos = torch.arange(order.shape[1], dtype=torch.int32, device=order.device)
+    rank.scatter_(1, order.long(), pos.expand_as(order))
+    out = None
+    for p in range(order.shape[0]):
+        o = _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode), rank[p],
+                               order[p])
+        out = o if out is None else out + o
+    return out / order.shape[0]
 
 
 # --------------------------------------------------------------------------------------

@@ -72,10 +72,12 @@ class InverseWarp(nn.Module):
     atomicMin instead of the reference's two sorts; Jacobi fill passes; erosion; crop), with an
     exact backward w.r.t. the displacement values.  Buffers keep the reference's names.
 
-    Differences from the reference, on purpose: among colliding samples the lowest sample index
-    wins (the reference's result under a stable sort; its own depends on torch.sort's
-    implementation); ``num_perm > 1`` (random tie-break averaging, unused by every script) and
-    ``pad=False`` (which fails with a shape error in the reference) raise."""
+    Differences from the reference, on purpose: among colliding samples the first in tie-break
+    order wins (sample index for ``num_perm == 1``, position in ``perm[p]`` for ``num_perm > 1``;
+    the reference's result under a stable sort -- its own depends on torch.sort's implementation);
+    ``pad=False`` (which fails with a shape error in the reference) raises.  ``num_perm > 1``
+    (warp.py:91-111, unused by every script) runs one inversion per permutation and averages the
+    results, which equals averaging the elected fields first (see ``WF.inverse_warp``)."""
 
     def __init__(self, src_height, src_width, tgt_height, tgt_width, kernel_size=3, num_perm=1):
         super().__init__()
@@ -91,11 +93,11 @@ class InverseWarp(nn.Module):
         self.register_buffer("perm", torch.stack([torch.randperm(tgt_height * tgt_width) for _ in range(num_perm)]))
 
     def forward(self, src_grid, niter=5, pad=True, erode=True):
-        if self.num_perm != 1 or self.kernel_size != 3:
-            raise NotImplementedError("InverseWarp: only num_perm == 1, kernel_size == 3 (what the "
-                                      "reference's scripts use) is implemented")
+        if self.kernel_size != 3:
+            raise NotImplementedError("InverseWarp: only kernel_size == 3 (what the reference's "
+                                      "scripts use) is implemented")
         if not pad:
             raise ValueError("InverseWarp: pad=False fails with a shape error in the reference "
                              "(warp.py:169-173); not supported")
         return WF.inverse_warp(src_grid, self.src_grid[0], self.tgt_grid[0], self.kernel.view(9),
-                               niter=niter, erode=erode)
+                               niter=niter, erode=erode, perm=self.perm if self.num_perm > 1 else None)
