@@ -249,6 +249,37 @@ int waldo_frame_warp_fuse_bwd(const float* input, const float* flow, const float
                               waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A9, low-resolution part: the class distribution of every object for the layout filter
+ * (models/nets/lvd.py:624-634 and 731-746; csrc/lyt_dist.hip).  Per batch item, with x running over
+ * the Tw frames and H x W pixels:
+ *   win[o][x]  = (alpha[o][x] + 1e-6) * sum_n (cls[o][n] + min_cls) * softmax_n(lyt[.][x])[n]
+ *                (the sum is 1 when cls is NULL: the reference's `cls is None` / no weight_cls case)
+ *   mean[o][n] = sum_x win[o][x] lyt[n][x] / sum_x win[o][x];   dist[o][.] = softmax_n(mean[o][.])
+ *   alpha  (B,Tw,layers,H,W)   projected alpha in [0,1]; the objects are layers first_obj ..
+ *                              first_obj + No - 1 = layers - 1 (layer 0 is the background)
+ *   lyt    layout logits at the alpha's raster: plane n of frame t of item b starts at
+ *          lyt + b * lyt_batch_stride + t * lyt_frame_stride + n * H * W (elements), so a channel
+ *          slice of the (B,T,3+Nl,H,W) input is passed without a copy
+ *   cls    (B,No,Nl) or NULL;   dist, mean (B,No,Nl) and total (B,No) out (mean / total are what the
+ *          backward needs);   workspace: waldo_lyt_dist_workspace_bytes(), shared by both directions
+ * Backward: grad_dist (B,No,Nl) -> grad_alpha (B,Tw,layers,H,W) OVERWRITTEN (zero for the layers in
+ * front of the objects) and grad_cls (B,No,Nl) OVERWRITTEN (NULL exactly when cls is).  The layout
+ * logits are data (no gradient).  No atomics: per-workgroup partial sums added in workgroup order.
+ * No, Nl <= 32.
+ * ------------------------------------------------------------------------------------- */
+int64_t waldo_lyt_dist_workspace_bytes(int64_t B, int Tw, int No, int Nl, int H, int W);
+int waldo_lyt_dist_fwd(const float* alpha, const float* lyt, int64_t lyt_batch_stride,
+                       int64_t lyt_frame_stride, const float* cls, float min_cls, float* dist,
+                       float* mean, float* total, float* workspace, int64_t B, int Tw, int layers,
+                       int first_obj, int No, int Nl, int H, int W, waldo_stream_t stream);
+int waldo_lyt_dist_bwd(const float* grad_dist, const float* alpha, const float* lyt,
+                       int64_t lyt_batch_stride, int64_t lyt_frame_stride, const float* cls,
+                       float min_cls, const float* dist, const float* mean, const float* total,
+                       float* grad_alpha, float* grad_cls, float* workspace, int64_t B, int Tw,
+                       int layers, int first_obj, int No, int Nl, int H, int W,
+                       waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused hot path (BASELINE.json metric): TPS grid (A2) -> bilinear warp of every 4-channel
  * layer (A4) -> LVD.reduce_comp (A6, lvd.py:100-114) in ONE launch.
  *   layers   (F,L,4,H,W) in [-1,1]   channel 3 = alpha; the alpha of layer 0 is taken as +1

@@ -208,22 +208,29 @@ def grid_to_bg_flow_from_ctx_to_ref(cfg, grid, ctx_len, ref):
 # --------------------------------------------------------------------------------------
 # A9: flow / alpha synthesis
 # --------------------------------------------------------------------------------------
+def lyt_dist(alpha_obj, lyt, cls, weight_cls, min_cls):
+    """Class distribution of every object (lvd.py:627-634 / 737-744): the layout logits averaged
+    over the object's alpha window (optionally weighted by how well each pixel's class agrees with
+    the predicted class vector), then a softmax.
+    alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W), cls (B,No,Nl) or None -> (B,No,Nl)."""
+    win = alpha_obj + 1e-6                                              # B Tw No 1 H W
+    if weight_cls:
+        prob = lyt.softmax(dim=2)                                       # B Tw Nl H W
+        wcls = torch.einsum("bon,btnhw->btohw", cls + min_cls, prob).unsqueeze(3)
+        win = win * wcls
+    total = win.sum(dim=(1, 4, 5))                                      # B No 1
+    mean = torch.einsum("btohw,btnhw->bon", win.squeeze(3), lyt) / total  # B No Nl
+    return mean.softmax(dim=2)                                          # B No Nl
+
+
 def _lyt_alpha(cfg, alpha_obj, lyt, hd_lyt, cls):
     """Layout filter (lvd.py:624-639 / 731-751): per object, 1 - 0.5 * L1 distance between the
     object's class distribution and the per-pixel class distribution at HD.
     alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W), hd_lyt (B,Tw,Nl,Hd,Wd) -> (B,Tw,No,1,Hd,Wd)."""
-    b, tw, no = alpha_obj.shape[:3]
-    nl = lyt.shape[2]
+    no = alpha_obj.shape[2]
     hd_prob = hd_lyt.softmax(dim=2)                                     # B Tw Nl Hd Wd
     if cls is None or cfg.weight_cls:
-        win = alpha_obj + 1e-6                                          # B Tw No 1 H W
-        if cfg.weight_cls:
-            prob = lyt.softmax(dim=2)                                   # B Tw Nl H W
-            wcls = torch.einsum("bon,btnhw->btohw", cls + cfg.min_cls, prob).unsqueeze(3)
-            win = win * wcls
-        total = win.sum(dim=(1, 4, 5))                                  # B No 1
-        mean = torch.einsum("btohw,btnhw->bon", win.squeeze(3), lyt) / total  # B No Nl
-        dist = mean.softmax(dim=2)                                      # B No Nl
+        dist = lyt_dist(alpha_obj, lyt, cls, cfg.weight_cls, cfg.min_cls)
     else:
         dist = cls                                                      # B No Nl
     out = []

@@ -47,6 +47,8 @@ SIGNATURES = {
     "waldo_flow_ctx_alpha_bwd": [_c_f] * 9 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_bwd": [_c_f] * 8 + [_int] * 9 + [_flt, _stream],
+    "waldo_lyt_dist_fwd": [_c_f, _c_f, _i64, _i64, _c_f, _flt] + [_c_f] * 4 + [_i64] + [_int] * 7 + [_stream],
+    "waldo_lyt_dist_bwd": [_c_f] * 3 + [_i64, _i64, _c_f, _flt] + [_c_f] * 6 + [_i64] + [_int] * 7 + [_stream],
     "waldo_wif_fuse_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _stream],
     "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
                            _stream],
@@ -57,6 +59,7 @@ SIGNATURES = {
 }
 PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
          "waldo_warp_composite_bwd_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int]),
+         "waldo_lyt_dist_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
          "waldo_last_error_string": (ctypes.c_char_p, []),
          "waldo_set_debug_option": (_int, [_int, _int])}
 

@@ -429,6 +429,70 @@ def wif_fuse(vid, net_out, ab=True):
 # --------------------------------------------------------------------------------------
 # A9: the two HD passes of Warper.grid_to_flow_ctx / grid_to_flow (forward only)
 # --------------------------------------------------------------------------------------
+class _LytDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha, lyt, cls, min_cls, first_obj):
+        b, tw, la, h, w = alpha.shape
+        nl = lyt.shape[2]
+        no = la - first_obj
+        dev = alpha.device
+        dist = alpha.new_empty(b, no, nl)
+        mean = alpha.new_empty(b, no, nl)
+        total = alpha.new_empty(b, no)
+        wsb = _lib.load().waldo_lyt_dist_workspace_bytes(b, tw, no, nl, h, w)
+        ws = alpha.new_empty(max(wsb, 4) // 4)
+        with torch.cuda.device(dev):
+            _lib.call("waldo_lyt_dist_fwd", _lib.ptr(alpha), _lib.ptr(lyt), lyt.stride(0), lyt.stride(1),
+                      _lib.ptr(cls), float(min_cls), _lib.ptr(dist), _lib.ptr(mean), _lib.ptr(total),
+                      _lib.ptr(ws), b, tw, la, first_obj, no, nl, h, w, _lib.current_stream(dev))
+        ctx.save_for_backward(alpha, lyt, cls, dist, mean, total)
+        ctx.cfg = (float(min_cls), first_obj)
+        ctx.mark_non_differentiable(mean, total)
+        return dist, mean, total
+
+    @staticmethod
+    def backward(ctx, g_dist, _g_mean, _g_total):
+        alpha, lyt, cls, dist, mean, total = ctx.saved_tensors
+        min_cls, first_obj = ctx.cfg
+        b, tw, la, h, w = alpha.shape
+        nl = lyt.shape[2]
+        no = la - first_obj
+        dev = alpha.device
+        g_dist = _c(g_dist)
+        g_alpha = torch.empty_like(alpha)
+        g_cls = torch.empty_like(cls) if cls is not None else None
+        wsb = _lib.load().waldo_lyt_dist_workspace_bytes(b, tw, no, nl, h, w)
+        ws = alpha.new_empty(max(wsb, 4) // 4)
+        with torch.cuda.device(dev):
+            _lib.call("waldo_lyt_dist_bwd", _lib.ptr(g_dist), _lib.ptr(alpha), _lib.ptr(lyt), lyt.stride(0),
+                      lyt.stride(1), _lib.ptr(cls), min_cls, _lib.ptr(dist), _lib.ptr(mean),
+                      _lib.ptr(total), _lib.ptr(g_alpha), _lib.ptr(g_cls), _lib.ptr(ws), b, tw, la,
+                      first_obj, no, nl, h, w, _lib.current_stream(dev))
+        return g_alpha, None, g_cls, None, None
+
+
+def lyt_dist(alpha, lyt, cls=None, min_cls=0.0, first_obj=1):
+    """Class distribution of every object for the layout filter (models/nets/lvd.py:624-634 /
+    731-746).  alpha (B, Tw, L, H, W) projected alpha in [0, 1], objects = layers first_obj .. L-1;
+    lyt (B, Tw, Nl, H, W) layout logits at the same raster (any batch / frame strides: a channel
+    slice of the input works without a copy); cls (B, No, Nl) = the reference's ``cls`` when
+    ``weight_cls`` is set, else None.  Returns dist (B, No, Nl).  Differentiable w.r.t. alpha and
+    cls; the layout is data."""
+    _lib.check_cuda(alpha, lyt, cls)
+    alpha = _c(alpha)
+    lyt = lyt.detach()
+    b, tw, la, h, w = alpha.shape
+    if lyt.dim() != 5 or tuple(lyt.shape[:2]) != (b, tw) or tuple(lyt.shape[3:]) != (h, w):
+        raise _lib.WaldoHipError(f"lyt_dist: lyt {tuple(lyt.shape)} does not match alpha {tuple(alpha.shape)}")
+    if lyt.stride(4) != 1 or lyt.stride(3) != w or lyt.stride(2) != h * w:
+        lyt = lyt.contiguous()
+    if cls is not None:
+        cls = _c(cls)
+        if tuple(cls.shape) != (b, la - first_obj, lyt.shape[2]):
+            raise _lib.WaldoHipError(f"lyt_dist: cls {tuple(cls.shape)} is not (B, No, Nl)")
+    return _LytDist.apply(alpha, lyt, cls, float(min_cls), int(first_obj))[0]
+
+
 class _FlowCtxAlpha(torch.autograd.Function):
     @staticmethod
     def forward(ctx, alpha_lr, input, dist, occ, tw, chan_off, scale):

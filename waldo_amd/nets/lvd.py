@@ -222,25 +222,32 @@ class Warper(nn.Module):
         return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
 
     # ------------------------------------------------------------------ flow / alpha synthesis
-    def _lyt_dist(self, alpha_obj, lyt, cls):
+    def _lyt_dist(self, alpha, lyt, cls):
         """Class distribution of every object for the layout filter (lvd.py:624-634 / 731-746).
-        alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W), cls (B,No,Nl) or None -> (B,No,Nl)."""
-        if cls is None or self.weight_cls:
-            win = alpha_obj.squeeze(3) + 1e-6                                   # B Tw No H W
-            if self.weight_cls:
-                win = win * torch.einsum("bon,btnhw->btohw", cls + self.min_cls, lyt.softmax(dim=2))
-            total = win.sum(dim=(1, 3, 4))                                      # B No
-            mean = torch.einsum("btohw,btnhw->bon", win, lyt) / total.unsqueeze(2)
-            return mean.softmax(dim=2)                                          # B No Nl
-        return cls
+        alpha (B,Tw,L,1,H,W) with the background at layer 0, lyt (B,Tw,Nl,H,W), cls (B,No,Nl) or
+        None -> (B,No,Nl).  One pass of csrc/lyt_dist.hip; a layout that requires a gradient (no
+        script has one) takes the framework expression."""
+        if not (cls is None or self.weight_cls):
+            return cls
+        if torch.is_grad_enabled() and lyt.requires_grad:
+            return self._lyt_dist_torch(alpha[:, :, 1:], lyt, cls)
+        return WF.lyt_dist(alpha.squeeze(3), lyt, cls if self.weight_cls else None, self.min_cls, first_obj=1)
 
-    def _lyt_alpha(self, alpha_obj, lyt, hd_lyt, cls):
-        """Layout filter (lvd.py:624-639 / 731-751).  alpha_obj (B,Tw,No,1,H,W), lyt (B,Tw,Nl,H,W),
+    def _lyt_dist_torch(self, alpha_obj, lyt, cls):
+        win = alpha_obj.squeeze(3) + 1e-6                                       # B Tw No H W
+        if self.weight_cls:
+            win = win * torch.einsum("bon,btnhw->btohw", cls + self.min_cls, lyt.softmax(dim=2))
+        total = win.sum(dim=(1, 3, 4))                                          # B No
+        mean = torch.einsum("btohw,btnhw->bon", win, lyt) / total.unsqueeze(2)
+        return mean.softmax(dim=2)                                              # B No Nl
+
+    def _lyt_alpha(self, alpha, lyt, hd_lyt, cls):
+        """Layout filter (lvd.py:624-639 / 731-751).  alpha (B,Tw,L,1,H,W), lyt (B,Tw,Nl,H,W),
         hd_lyt (B,Tw,Nl,Hd,Wd), cls (B,No,Nl) or None -> (B,Tw,No,1,Hd,Wd).  The reference builds a
         (B,Tw,No,Nl,Hd,Wd) tensor; this loops over the objects instead."""
-        no = alpha_obj.shape[2]
+        no = alpha.shape[2] - 1
         hd_prob = hd_lyt.softmax(dim=2)
-        dist = self._lyt_dist(alpha_obj, lyt, cls)
+        dist = self._lyt_dist(alpha, lyt, cls)
         out = [1 - (dist[:, None, o, :, None, None] - hd_prob).abs().sum(dim=2, keepdim=True) / 2
                for o in range(no)]
         return torch.stack(out, dim=2)
@@ -271,7 +278,7 @@ class Warper(nn.Module):
         dist = None
         if ctx_only or not self.no_filter:
             lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
-            dist = self._lyt_dist(alpha[:, :, 1:], lyt, cls)
+            dist = self._lyt_dist(alpha, lyt, cls)
         occ = occ.reshape(b, t, nl, nl)
         a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ, tw, 3, s)
 
@@ -313,7 +320,7 @@ class Warper(nn.Module):
         alpha = alpha[:, win]                                                   # B Tw L 1 H W
         filt = ctx_only or not self.no_filter
         if filt:
-            lyt_alpha = self._lyt_alpha(alpha[:, :, 1:], input[:, win, 3:], hd_input[:, win, 3:], cls)
+            lyt_alpha = self._lyt_alpha(alpha, input[:, win, 3:], hd_input[:, win, 3:], cls)
         alpha = scale(alpha, self.scale_hd)
         if filt:
             alpha = torch.cat([alpha[:, :, :1], alpha[:, :, 1:] * lyt_alpha], dim=2)
