@@ -289,17 +289,18 @@ int waldo_lyt_dist_bwd(const float* grad_dist, const float* alpha, const float* 
  *   rgb      (F,3,H,W)  out, in [-1,1]
  *   alpha    (F,L,H,W)  out, composited alpha in [-1,1]; may be NULL (not written)
  * K3 <= 32, L <= waldo_max_layers().
- * Padding: taps outside a layer contribute 0 (grid_sample's zeros padding on the raw values, i.e.
- * delta = 0 in the notation of A4: alpha 0.5 / grey after the (x + 1) / 2 of reduce_comp).  The
- * reference's layer_to_output shifts by delta = 1 so that out-of-range taps read -1 (alpha 0): a
- * caller that needs that behaviour at the image border composes waldo_grid_sample2d (delta = 1)
- * with waldo_occ_composite instead of this entry point.
+ * Padding: every layer is sampled as grid_sample(x + delta, grid) - delta (A4; lvd.py:548,559).
+ * delta = 0: taps outside a layer contribute 0 (zeros padding on the raw values: alpha 0.5 / grey
+ * after the (x + 1) / 2 of reduce_comp) -- the BASELINE pipeline.  delta = 1 is the default of the
+ * reference's layer_to_output: out-of-range taps read -1 (alpha 0 / black).  The shift only acts
+ * where a footprint leaves the layer; with delta = 0 the results have the same bits as before the
+ * parameter existed.
  * Coordinates: the grid is evaluated directly in pixel units (the mapping column scaled by W/2 or
  * H/2 inside the kernels), which moves a sample position by rounding only (~1e-5 px at 512 px).
  * ------------------------------------------------------------------------------------- */
 int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const float* mapping,
                              const float* occ, float* rgb, float* alpha, int64_t F, int L, int H,
-                             int W, int K3, waldo_stream_t stream);
+                             int W, int K3, float delta, waldo_stream_t stream);
 /* Backward of the above.
  *   grad_rgb (F,3,H,W); grad_alpha (F,L,H,W) or NULL;
  *   workspace: scratch of at least waldo_warp_composite_bwd_workspace_bytes() bytes (256-byte
@@ -325,7 +326,7 @@ int waldo_warp_composite_bwd(const float* layers, const float* basis_t, const fl
                              const float* occ, const float* grad_rgb, const float* grad_alpha,
                              float* grad_layers, float* grad_mapping, float* grad_occ,
                              void* workspace, int64_t workspace_bytes, int64_t F, int L, int H,
-                             int W, int K3, waldo_stream_t stream);
+                             int W, int K3, float delta, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A12. Fusion epilogue of WIF.forward with ii_score (models/nets/wif.py:49-54).

@@ -22,7 +22,7 @@ def load():
         _lib = ctypes.CDLL(_SO)
         fp, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
         _lib.waldo_oracle_fused.restype = ctypes.c_int
-        _lib.waldo_oracle_fused.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 5 + [fp, fp, ctypes.c_int] + [dp] * 5
+        _lib.waldo_oracle_fused.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 5 + [fp, fp, ctypes.c_int, ctypes.c_double] + [dp] * 5
     return _lib
 
 
@@ -34,9 +34,10 @@ def _ptr(a, t):
     return None if a is None else a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def fused(layers, pts, occ, ctrl, w_rgb=None, w_alpha=None, loss_sq=False, backward=True):
+def fused(layers, pts, occ, ctrl, w_rgb=None, w_alpha=None, loss_sq=False, backward=True, delta=0.0):
     """layers (F,L,4,H,W), pts (F*L,N,2), occ (F,L,L), ctrl (N,2).  Loss: sum(rgb*w_rgb) +
-    sum(alpha*w_alpha), or mean(rgb^2) with ``loss_sq``.  Returns a dict of float64 arrays."""
+    sum(alpha*w_alpha), or mean(rgb^2) with ``loss_sq``.  delta: grid_sample(x + delta) - delta
+    (lvd.py:548,559).  Returns a dict of float64 arrays."""
     layers, pts, occ, ctrl, w_rgb, w_alpha = map(_f32, (layers, pts, occ, ctrl, w_rgb, w_alpha))
     f, nl, _, h, w = layers.shape
     n = ctrl.shape[0]
@@ -48,7 +49,7 @@ def fused(layers, pts, occ, ctrl, w_rgb=None, w_alpha=None, loss_sq=False, backw
     rc = load().waldo_oracle_fused(
         _ptr(layers, ctypes.c_float), _ptr(pts, ctypes.c_float), _ptr(occ, ctypes.c_float),
         _ptr(ctrl, ctypes.c_float), f, nl, h, w, n, _ptr(w_rgb, ctypes.c_float), _ptr(w_alpha, ctypes.c_float),
-        int(bool(loss_sq)), _ptr(out["rgb"], d), _ptr(out["alpha"], d), _ptr(out.get("grad_layers"), d),
+        int(bool(loss_sq)), float(delta), _ptr(out["rgb"], d), _ptr(out["alpha"], d), _ptr(out.get("grad_layers"), d),
         _ptr(out.get("grad_pts"), d), _ptr(out.get("grad_occ"), d))
     if rc != 0:
         raise RuntimeError(f"waldo_oracle_fused failed with code {rc}")

@@ -122,6 +122,31 @@ def gen_warp_composite(ns):
              grad_score=both["grad_score"], grad_layers_sq=layers.grad, grad_pts_sq=pts.grad)
 
 
+def gen_warp_composite_delta(ns):
+    """The same path with the reference's "-delta" padding (Warper.obj_to_output / bg_to_output,
+    lvd.py:548,559: F.grid_sample(x + delta, grid) - delta; layer_to_output's default is 1)."""
+    g = torch.Generator().manual_seed(44)
+    for tag, (f, nl, h, w, sigma, delta) in {"delta1": (3, 5, 16, 24, 0.15, 1.0),
+                                             "delta1_big": (2, 3, 20, 28, 0.5, 1.0),
+                                             "delta_half": (2, 8, 32, 32, 0.2, 0.5)}.items():
+        ctrl = ns.get_grid(4, 4).view(-1, 2)
+        tps = ns.TPSWarp(h, w, ctrl)
+        lvd = lvd_stub(ns, nl - 1)
+        layers = (torch.rand(f, nl, 4, h, w, generator=g) * 2 - 1).requires_grad_()
+        pts = (ctrl.view(1, 16, 2) + sigma * torch.randn(f * nl, 16, 2, generator=g)).requires_grad_()
+        score = torch.randn(f, 1, nl - 1, generator=g, requires_grad=True)
+        occ = lvd.compute_occ(score)
+        grid = tps(pts)
+        warped = (F.grid_sample(layers.view(f * nl, 4, h, w) + delta, grid) - delta).view(f, 1, nl, 4, h, w)
+        rgb, alpha, _ = lvd.reduce_comp(warped, occ, torch.zeros(f, 0, nl, 2, h, w))
+        w1 = torch.randn(rgb.shape, generator=g)
+        w2 = torch.randn(alpha.shape, generator=g)
+        ((rgb * w1).sum() + (alpha * w2).sum()).backward()
+        save(f"warp_composite_{tag}", layers=layers, pts=pts, score=score, occ=occ[:, 0], ctrl=ctrl,
+             delta=delta, rgb=rgb[:, 0], alpha=alpha[:, 0], w1=w1[:, 0], w2=w2[:, 0],
+             grad_layers=layers.grad, grad_pts=pts.grad, grad_score=score.grad)
+
+
 def gen_inverse_warp(ns):
     g = torch.Generator().manual_seed(5)
     ctrl = ns.get_grid(4, 4).view(-1, 2)
@@ -353,7 +378,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load()
     only = set(sys.argv[1:])  # e.g. `make_golden.py inverse_warp_perm`; none = all
-    for fn in (gen_tps, gen_grid_sample, gen_occ_comp, gen_warp_composite, gen_inverse_warp,
+    for fn in (gen_tps, gen_grid_sample, gen_occ_comp, gen_warp_composite, gen_warp_composite_delta, gen_inverse_warp,
                gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers):
         if not only or fn.__name__[4:] in only:
             fn(ns)

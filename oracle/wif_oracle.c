@@ -92,12 +92,14 @@ static void make_taps(double gx, double gy, int H, int W, taps_t* t) {
 
 /* loss: weights mode  sum(rgb * w_rgb) + sum(alpha * w_alpha)   (either may be NULL)
  *       square mode   mean(rgb^2)                                (loss_sq != 0)
+ * delta: every layer is sampled as grid_sample(x + delta) - delta (Warper.obj_to_output /
+ *       bg_to_output, lvd.py:548,559); 0 is plain F.grid_sample.
  * outputs (all double, caller-allocated, grad_* may be NULL to skip the backward):
  *   rgb (F,3,HW)  alpha (F,L,HW)  grad_layers (F,L,4,HW)  grad_pts (F*L,N,2)  grad_occ (F,L,L) */
 int waldo_oracle_fused(const float* layers, const float* pts, const float* occ, const float* ctrl,
                        int F, int L, int H, int W, int N, const float* w_rgb, const float* w_alpha,
-                       int loss_sq, double* rgb, double* alpha, double* grad_layers, double* grad_pts,
-                       double* grad_occ) {
+                       int loss_sq, double delta, double* rgb, double* alpha, double* grad_layers,
+                       double* grad_pts, double* grad_occ) {
   const int K3 = N + 3, HW = H * W;
   if (F < 0 || L < 1 || L > 64 || H < 1 || W < 1 || N < 1 || N > 64) return -1;
   double* kinv = (double*)calloc((size_t)K3 * K3, sizeof(double));
@@ -157,7 +159,8 @@ int waldo_oracle_fused(const float* layers, const float* pts, const float* occ, 
           const float* plane = layers + ((size_t)(f * L + l) * 4 + c) * HW;
           double s = 0.0;
           for (int k = 0; k < 4; ++k)
-            if (tp[l].in[k]) s += tp[l].w[k] * plane[tp[l].idx[k]];
+            if (tp[l].in[k]) s += tp[l].w[k] * (plane[tp[l].idx[k]] + delta);
+          s -= delta;
           v[l][c] = (s + 1.0) / 2.0; /* reduce_comp, lvd.py:103 */
         }
         a[l] = l == 0 ? 1.0 : v[l][3]; /* lvd.py:105 */
@@ -205,7 +208,7 @@ int waldo_oracle_fused(const float* layers, const float* pts, const float* occ, 
           const float* plane = layers + ((size_t)(f * L + l) * 4 + c) * HW;
           double tex[4];
           for (int k = 0; k < 4; ++k) {
-            tex[k] = t->in[k] ? (double)plane[t->idx[k]] : 0.0;
+            tex[k] = t->in[k] ? (double)plane[t->idx[k]] + delta : 0.0;
             if (t->in[k] && grad_layers) grad_layers[((size_t)(f * L + l) * 4 + c) * HW + t->idx[k]] += gs[c] * t->w[k];
           }
           /* d s / d ix, d s / d iy of the bilinear interpolant (zero-padded texels) */

@@ -203,14 +203,15 @@ def reduce_comp(vid, occ, flow=None):
 # --------------------------------------------------------------------------------------
 
 
-def warp_composite(layers, src_pts, occ, inverse_kernel, tgt_grid_repr, explicit=False):
+def warp_composite(layers, src_pts, occ, inverse_kernel, tgt_grid_repr, explicit=False, delta=0.0):
     """TPS grid (A2) -> grid_sample of each 4-channel layer (A4) -> reduce_comp (A6).
+    delta: grid_sample(x + delta) - delta as Warper.obj_to_output / bg_to_output (lvd.py:548,559).
 
     layers (F, L, 4, H, W) in [-1, 1]; src_pts (F*L, K, 2); occ (F, L, L);
     returns rgb (F, 3, H, W), alpha' (F, L, H, W) -- both in [-1, 1]."""
     f, nl, c, h, w = layers.shape
     grid = tps_grid(inverse_kernel, tgt_grid_repr, src_pts, h, w)
-    warped = grid_sample(layers.reshape(f * nl, c, h, w), grid, explicit).view(f, 1, nl, c, h, w)
+    warped = grid_sample_delta(layers.reshape(f * nl, c, h, w), grid, delta, explicit).view(f, 1, nl, c, h, w)
     rgb, alpha, _ = reduce_comp(warped, occ.view(f, 1, nl, nl))
     return rgb[:, 0], alpha[:, 0]
 

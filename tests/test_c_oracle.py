@@ -45,6 +45,18 @@ def test_c_oracle_vs_reference_golden(golden, tag):
     assert rel(q["grad_pts"], g["grad_pts_sq"]) < 2e-3
 
 
+@pytest.mark.parametrize("tag", ["delta1", "delta1_big", "delta_half"])
+def test_c_oracle_delta_vs_reference_golden(golden, tag):
+    """grid_sample(x + delta) - delta (lvd.py:548,559) in the C restatement vs the reference."""
+    g = {k: v.numpy() for k, v in golden(f"warp_composite_{tag}").items()}
+    r = C.fused(g["layers"], g["pts"], g["occ"], g["ctrl"], g["w1"], g["w2"], delta=float(g["delta"]))
+    # the reference's fp32 grid under a sigma = 0.5 warp of white noise moves values by ~1e-4
+    assert np.abs(r["rgb"] - g["rgb"]).max() < 2e-4
+    assert np.abs(r["alpha"] - g["alpha"]).max() < 2e-4
+    assert rel(r["grad_layers"], g["grad_layers"]) < 2e-4
+    assert rel(r["grad_pts"], g["grad_pts"]) < 2e-3
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 9, 13), (1, 8, 16, 24), (2, 1, 5, 7)])
 def test_c_oracle_vs_torch_fp64(shape):
     f, nl, h, w = shape

@@ -203,14 +203,14 @@ def test_occ_composite_golden(dev, golden):
 
 
 # ----------------------------------------------------------------------------- fused path
-def _oracle_fused(layers, pts, occ, ctrl, w1, w2, dtype, loss="weights"):
+def _oracle_fused(layers, pts, occ, ctrl, w1, w2, dtype, loss="weights", delta=0.0):
     """Oracle outputs and autograd gradients in `dtype` from the same fp32 inputs/buffers."""
     f, nl, _, h, w = layers.shape
     inv, rep = O.tps_init(h, w, ctrl)
     l = layers.detach().to(dtype).requires_grad_()
     p = pts.detach().to(dtype).requires_grad_()
     o = occ.detach().to(dtype).requires_grad_()
-    rgb, alpha = O.warp_composite(l, p, o, inv.to(dtype), rep.to(dtype))
+    rgb, alpha = O.warp_composite(l, p, o, inv.to(dtype), rep.to(dtype), delta=delta)
     if loss == "weights":
         ((rgb * w1.to(dtype)).sum() + (alpha * w2.to(dtype)).sum()).backward()
     else:
@@ -218,7 +218,7 @@ def _oracle_fused(layers, pts, occ, ctrl, w1, w2, dtype, loss="weights"):
     return rgb.detach(), alpha.detach(), l.grad, p.grad, o.grad
 
 
-def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None, generic=False):
+def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None, generic=False, delta=0.0):
     from waldo_amd import functional as WF
     import waldo_amd
     WF._FORCE_GENERIC_BWD = generic  # False: tiled backward where it applies (L <= 8, K3 == 19)
@@ -231,7 +231,7 @@ def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None
     p2 = pts.detach().to(dev).requires_grad_()
     o2 = occ.detach().to(dev).requires_grad_()
     try:
-        rgb, alpha = WF.warp_composite(l2, p2, o2, tps.inverse_kernel, tps.basis_t, return_alpha=True)
+        rgb, alpha = WF.warp_composite(l2, p2, o2, tps.inverse_kernel, tps.basis_t, return_alpha=True, delta=delta)
         if loss == "weights":
             ((rgb * w1.to(dev)).sum() + (alpha * w2.to(dev)).sum()).backward()
         else:
@@ -266,6 +266,40 @@ def test_warp_composite_golden(dev, golden, tag):
     ref32 = (g["rgb"], g["alpha"], g["grad_layers"], g["grad_pts"], None)
     _compare_fused(hip, ref32, ref64)
     close(score.grad, g["grad_score"], rel=True, what="grad_score", exact=s64.grad)
+
+
+@pytest.mark.parametrize("tag", ["delta1", "delta1_big", "delta_half"])
+def test_warp_composite_delta_golden(dev, golden, tag):
+    """The "-delta" padding of Warper.obj_to_output / bg_to_output (lvd.py:548,559) on the fused path
+    vs the REFERENCE's F.grid_sample(x + delta) - delta -> reduce_comp (outputs and autograd)."""
+    g = golden(f"warp_composite_{tag}")
+    delta = float(g["delta"])
+    ref64 = _oracle_fused(g["layers"], g["pts"], g["occ"], g["ctrl"], g["w1"], g["w2"], torch.float64, delta=delta)
+    hip = _hip_fused(dev, g["layers"], g["pts"], g["occ"], g["ctrl"], g["w1"], g["w2"], delta=delta)
+    ref32 = (g["rgb"], g["alpha"], g["grad_layers"], g["grad_pts"], None)
+    _compare_fused(hip, ref32, ref64)
+    # and the padding matters here: delta = 0 gives another picture
+    plain = _hip_fused(dev, g["layers"], g["pts"], g["occ"], g["ctrl"], g["w1"], g["w2"])
+    assert (plain[0].cpu() - g["rgb"]).abs().max() > 1e-2
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(f=2, nl=8, h=64, w=96, sigma=0.15), dict(f=2, nl=8, h=32, w=48, sigma=0.6),   # staged; boxes too large
+    dict(f=2, nl=5, h=17, w=33, sigma=0.2), dict(f=1, nl=17, h=32, w=64, sigma=0.2),     # plain forward; LP = 17
+    dict(f=2, nl=8, h=32, w=48, sigma=0.2, generic=True), dict(f=1, nl=24, h=16, w=32, sigma=0.2),
+])
+def test_warp_composite_delta_random(dev, cfg):
+    """delta = 1 through every kernel variant (LDS-staged border path, oversize-box fallback, plain
+    forward, two-kernel and generic backward) against the oracle in fp32 and fp64."""
+    f, nl, h, w = cfg["f"], cfg["nl"], cfg["h"], cfg["w"]
+    ctrl = O.get_grid(4, 4).view(-1, 2)
+    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=nl + 50, sigma=cfg["sigma"])
+    torch.manual_seed(f * 10 + nl)
+    w1, w2 = torch.randn(f, 3, h, w), torch.randn(f, nl, h, w)
+    ref32 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float32, delta=1.0)
+    ref64 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float64, delta=1.0)
+    hip = _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, generic=cfg.get("generic", False), delta=1.0)
+    _compare_fused(hip, ref32, ref64)
 
 
 def test_warp_composite_golden_bench_loss(dev, golden):

@@ -84,6 +84,30 @@ def test_warp_composite(golden, tag, explicit):
     close(score.grad, g["grad_score"], 1e-3)
 
 
+@pytest.mark.parametrize("tag", ["delta1", "delta1_big", "delta_half"])
+@pytest.mark.parametrize("explicit", [False, True])
+def test_warp_composite_delta(golden, tag, explicit):
+    """The "-delta" padding of Warper.obj_to_output / bg_to_output (lvd.py:548,559) on the fused path:
+    the reference's F.grid_sample(x + delta) - delta -> reduce_comp, forward and autograd."""
+    g = golden(f"warp_composite_{tag}")
+    layers = g["layers"].clone().requires_grad_()
+    pts = g["pts"].clone().requires_grad_()
+    score = g["score"].clone().requires_grad_()
+    f, nl, _, h, w = layers.shape
+    inv, rep = O.tps_init(h, w, g["ctrl"])
+    occ = O.compute_occ(score)[:, 0]
+    rgb, alpha = O.warp_composite(layers, pts, occ, inv, rep, explicit=explicit, delta=float(g["delta"]))
+    close(rgb, g["rgb"], 2e-6)
+    close(alpha, g["alpha"], 2e-6)
+    ((rgb * g["w1"]).sum() + (alpha * g["w2"]).sum()).backward()
+    close(layers.grad, g["grad_layers"], 1e-5)
+    close(pts.grad, g["grad_pts"], 2e-3 * max(1.0, g["grad_pts"].abs().max().item()))
+    close(score.grad, g["grad_score"], 1e-3)
+    # the padding matters in these cases
+    plain, _ = O.warp_composite(g["layers"], g["pts"], g["occ"], inv, rep)
+    assert (plain - g["rgb"]).abs().max() > 1e-2
+
+
 @pytest.mark.parametrize("tag", ["obj", "bg", "obj2"])
 def test_inverse_warp(golden, tag):
     g = golden(f"inverse_warp_{tag}")

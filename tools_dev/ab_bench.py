@@ -2,8 +2,8 @@
 
     python tools_dev/ab_bench.py [--shape F,L,H,W] [--iters 20] [--rounds 3] lib1.so lib2.so ...
 
-Calls waldo_warp_composite_fwd / _bwd through ctypes directly (their ABI has not changed since
-round 1), events on the current stream around each call."""
+Calls waldo_warp_composite_fwd / _bwd through ctypes directly (libraries older than version 1002
+have no `delta` argument), events on the current stream around each call."""
 import argparse
 import ctypes
 import os
@@ -54,8 +54,11 @@ for path in args.libs:
     lib = ctypes.CDLL(os.path.abspath(path), mode=ctypes.RTLD_LOCAL)
     lib.waldo_warp_composite_bwd_workspace_bytes.restype = i64
     lib.waldo_warp_composite_bwd_workspace_bytes.argtypes = [i64, i32, i32, i32, i32]
-    lib.waldo_warp_composite_fwd.argtypes = [P] * 6 + [i64, i32, i32, i32, i32, P]
-    lib.waldo_warp_composite_bwd.argtypes = [P] * 10 + [i64, i64, i32, i32, i32, i32, P]
+    lib.waldo_version.restype = i32
+    lib.extra = (ctypes.c_float(0.0),) if lib.waldo_version() >= 1002 else ()
+    tail = [ctypes.c_float] * len(lib.extra) + [P]
+    lib.waldo_warp_composite_fwd.argtypes = [P] * 6 + [i64, i32, i32, i32, i32] + tail
+    lib.waldo_warp_composite_bwd.argtypes = [P] * 10 + [i64, i64, i32, i32, i32, i32] + tail
     wsb = lib.waldo_warp_composite_bwd_workspace_bytes(F, L, H, W, 19)
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.int32, device=dev)
     libs.append((os.path.basename(path), lib, ws, wsb))
@@ -63,7 +66,7 @@ st = P(torch.cuda.current_stream().cuda_stream)
 
 
 def fwd(lib):
-    rc = lib.waldo_warp_composite_fwd(ptr(layers), ptr(basis_t), ptr(mapping), ptr(occ), ptr(rgb), None, F, L, H, W, 19, st)
+    rc = lib.waldo_warp_composite_fwd(ptr(layers), ptr(basis_t), ptr(mapping), ptr(occ), ptr(rgb), None, F, L, H, W, 19, *lib.extra, st)
     assert rc == 0
 
 
@@ -71,7 +74,7 @@ def bwd(lib, ws, wsb):
     if wsb == 0:
         gl.zero_()
     rc = lib.waldo_warp_composite_bwd(ptr(layers), ptr(basis_t), ptr(mapping), ptr(occ), ptr(grad_rgb), None, ptr(gl),
-                                      ptr(gm), None, ptr(ws) if wsb else None, wsb, F, L, H, W, 19, st)
+                                      ptr(gm), None, ptr(ws) if wsb else None, wsb, F, L, H, W, 19, *lib.extra, st)
     assert rc == 0
 
 

@@ -53,9 +53,9 @@ SIGNATURES = {
     "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
                            _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
-                                 _stream],
+                                 _flt, _stream],
     "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64,
-                                 _i64, _int, _int, _int, _int, _stream],
+                                 _i64, _int, _int, _int, _int, _flt, _stream],
 }
 PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
          "waldo_warp_composite_bwd_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int]),

@@ -168,28 +168,31 @@ __device__ __forceinline__ float ldb(const float* __restrict__ base, uint32_t by
 // corner values times their validity: the same number as the four-weight sum of grid_sample up to
 // rounding, in 6 operations per channel instead of 8, and the ONE form every kernel of the fused
 // path uses (the LDS-staged kernels evaluate it on packed channel pairs: bit-identical).
-__device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const Taps& t) {
-  const float p00 = ldb(plane, t.o00), p01 = ldb(plane, t.o01);
-  const float p10 = ldb(plane, t.o10), p11 = ldb(plane, t.o11);
+// delta: grid_sample(x + delta) - delta of Warper.obj_to_output / bg_to_output (lvd.py:548,559) --
+// the shift is applied to the corner values before their validity, exactly as the reference does;
+// with delta == 0 the result has the same bits as without.
+__device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const Taps& t, float delta = 0.0f) {
+  const float p00 = ldb(plane, t.o00) + delta, p01 = ldb(plane, t.o01) + delta;
+  const float p10 = ldb(plane, t.o10) + delta, p11 = ldb(plane, t.o11) + delta;
   const float v00 = p00 * (t.vx0 * t.vy0), v01 = p01 * (t.vx1 * t.vy0);
   const float v10 = p10 * (t.vx0 * t.vy1), v11 = p11 * (t.vx1 * t.vy1);
   const float top = fmaf(t.fx, v01 - v00, v00);
   const float bot = fmaf(t.fx, v11 - v10, v10);
-  return fmaf(t.fy, bot - top, top);
+  return fmaf(t.fy, bot - top, top) - delta;
 }
 
 // sample + partial derivatives w.r.t. the UNNORMALISED coordinates (ix, iy)
 __device__ __forceinline__ float tap_sample_d(const float* __restrict__ plane, const Taps& t,
-                                              float& ddx, float& ddy) {
-  const float p00 = ldb(plane, t.o00), p01 = ldb(plane, t.o01);
-  const float p10 = ldb(plane, t.o10), p11 = ldb(plane, t.o11);
+                                              float& ddx, float& ddy, float delta = 0.0f) {
+  const float p00 = ldb(plane, t.o00) + delta, p01 = ldb(plane, t.o01) + delta;
+  const float p10 = ldb(plane, t.o10) + delta, p11 = ldb(plane, t.o11) + delta;
   float v00 = p00 * (t.vx0 * t.vy0), v01 = p01 * (t.vx1 * t.vy0);
   float v10 = p10 * (t.vx0 * t.vy1), v11 = p11 * (t.vx1 * t.vy1);
   float top = fmaf(t.fx, v01 - v00, v00);
   float bot = fmaf(t.fx, v11 - v10, v10);
   ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
   ddy = bot - top;
-  return fmaf(t.fy, ddy, top);
+  return fmaf(t.fy, ddy, top) - delta;
 }
 
 // ---------------------------------------------------------------------------------------

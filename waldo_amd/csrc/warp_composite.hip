@@ -11,11 +11,12 @@ constexpr int kMaxK3 = 32;
 #define WALDO_DECL_LP(LPV)                                                                      \
   void wc_fwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
                       const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,   \
-                      int K3, hipStream_t st);                                                  \
+                      int K3, float delta, hipStream_t st);                                     \
   void wc_bwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
                       const float* occ, const float* grad_rgb, const float* grad_alpha,         \
                       float* grad_layers, float* grad_mapping, float* grad_occ,                 \
-                      void* workspace, int F, int L, int H, int W, int K3, hipStream_t st);
+                      void* workspace, int F, int L, int H, int W, int K3, float delta,         \
+                      hipStream_t st);
 WALDO_DECL_LP(4)
 WALDO_DECL_LP(8)
 WALDO_DECL_LP(12)
@@ -63,7 +64,7 @@ extern "C" int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, in
 extern "C" int waldo_warp_composite_fwd(const float* layers, const float* basis_t,
                                         const float* mapping, const float* occ, float* rgb,
                                         float* alpha, int64_t F, int L, int H, int W, int K3,
-                                        waldo_stream_t stream) {
+                                        float delta, waldo_stream_t stream) {
   int rc = check_common("waldo_warp_composite_fwd", F, L, H, W, K3);
   if (rc) return rc;
   if (F == 0) return WALDO_OK;
@@ -73,7 +74,7 @@ extern "C" int waldo_warp_composite_fwd(const float* layers, const float* basis_
   }
   hipStream_t st = (hipStream_t)stream;
   WALDO_CALL_LP(wc_fwd_lp, K3 == 19, layers, basis_t, mapping, occ, rgb, alpha, (int)F, L, H, W,
-                K3, st);
+                K3, delta, st);
   return launch_status("waldo_warp_composite_fwd");
 }
 
@@ -82,7 +83,8 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
                                         const float* grad_rgb, const float* grad_alpha,
                                         float* grad_layers, float* grad_mapping, float* grad_occ,
                                         void* workspace, int64_t workspace_bytes, int64_t F,
-                                        int L, int H, int W, int K3, waldo_stream_t stream) {
+                                        int L, int H, int W, int K3, float delta,
+                                        waldo_stream_t stream) {
   int rc = check_common("waldo_warp_composite_bwd", F, L, H, W, K3);
   if (rc) return rc;
   if (F == 0) return WALDO_OK;
@@ -101,7 +103,7 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
     workspace = nullptr;  // shape served by the generic kernel, which needs none
   }
   WALDO_CALL_LP(wc_bwd_lp, K3 == 19, layers, basis_t, mapping, occ, grad_rgb, grad_alpha,
-                grad_layers, grad_mapping, grad_occ, workspace, (int)F, L, H, W, K3, st);
+                grad_layers, grad_mapping, grad_occ, workspace, (int)F, L, H, W, K3, delta, st);
   return launch_status("waldo_warp_composite_bwd");
 }
 

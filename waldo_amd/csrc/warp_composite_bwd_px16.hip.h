@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     float4* __restrict__ rec, int* __restrict__ cellbox,
     unsigned* __restrict__ cellbound, float* __restrict__ gmap_partial, float* __restrict__ grad_occ,
     int F, int Lrt, int H, int W, int frames_per_block, int ntx, int ntiles, int nchunks, int ncx,
-    int ncells) {
+    int ncells, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   using C = Px16Cfg<LP>;
   constexpr int K3 = C::K3, KS = C::KS, NT = C::NT, GGC = C::GGC, TP = C::TP, PP1 = C::PP1, BP = C::BP;
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           const Taps tg = finish_taps(tc, H, W);
           const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, tg, sx[c], sy[c]);
+          for (int c = 0; c < 4; ++c) sv[c] = tap_sample_d(base + c * HW, tg, sx[c], sy[c], delta);
         } else {
           PairBlock pb;
-          float fx, fy;
+          float fx, fy, shift = 0.0f;
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1
             const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
@@ -348,12 +348,16 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             // inside the box by construction; the clamp only matters for NaN coordinates
             const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
             pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
+            // delta padding: corner values shifted before their validity (the interior path needs
+            // no shift: with every corner valid the weights sum to 1 and the shift cancels)
+            const f32x2_t d2 = {delta, delta};
+            shift = delta;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-              pb.p00[q] = pb.p00[q] * t.v00;
-              pb.p01[q] = pb.p01[q] * t.v01;
-              pb.p10[q] = pb.p10[q] * t.v10;
-              pb.p11[q] = pb.p11[q] * t.v11;
+              pb.p00[q] = (pb.p00[q] + d2) * t.v00;
+              pb.p01[q] = (pb.p01[q] + d2) * t.v01;
+              pb.p10[q] = (pb.p10[q] + d2) * t.v10;
+              pb.p11[q] = (pb.p11[q] + d2) * t.v11;
             }
             fx = t.fx;
             fy = t.fy;
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             const f32x2_t dy = bot - top;
             const f32x2_t dx = __builtin_elementwise_fma(fy2, d1 - d0, d0);
             const f32x2_t v = __builtin_elementwise_fma(fy2, dy, top);
-            sv[2 * q] = v[0];
-            sv[2 * q + 1] = v[1];
+            sv[2 * q] = v[0] - shift;
+            sv[2 * q + 1] = v[1] - shift;
             sx[2 * q] = dx[0];
             sx[2 * q + 1] = dx[1];
             sy[2 * q] = dy[0];

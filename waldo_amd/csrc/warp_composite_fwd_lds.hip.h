@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int frames_per_block, int ntx,
-    int ntiles, int nchunks) {
+    int ntiles, int nchunks, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
@@ -345,9 +345,12 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
             // inside the box by construction; the clamp only matters for NaN coordinates
             const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
             const PairBlock pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
+            // delta padding (lvd.py:548,559): shift the corner values before their validity
+            const f32x2_t d2 = {delta, delta};
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-              sv[q] = lerp2(pb.p00[q] * t.v00, pb.p01[q] * t.v01, pb.p10[q] * t.v10, pb.p11[q] * t.v11, t.fx, t.fy);
+              sv[q] = lerp2((pb.p00[q] + d2) * t.v00, (pb.p01[q] + d2) * t.v01, (pb.p10[q] + d2) * t.v10,
+                            (pb.p11[q] + d2) * t.v11, t.fx, t.fy) - d2;
           }
           s[l][0] = sv[0][0];
           s[l][1] = sv[0][1];
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
           const Taps t = make_taps_px(gx[l], gy[l], H, W);
           const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t);
+          for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t, delta);
         }
       }
     }

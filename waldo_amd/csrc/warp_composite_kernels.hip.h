@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 17 ? 2 : 1))) void wa
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int K3rt, int frames_per_block,
-    int ntx, int ntiles, int nchunks) {
+    int ntx, int ntiles, int nchunks, float delta) {
   const int L = EXL ? LP : Lrt;
   const int K3 = EXK ? K3P : K3rt;
   const int64_t HW = (int64_t)H * W;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 17 ? 2 : 1))) void wa
       const Taps t = make_taps_px(ix, iy, H, W);
       const float* base = layers + ((int64_t)f * L + lc) * 4 * HW;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t);
+      for (int c = 0; c < 4; ++c) s[l][c] = tap_sample(base + c * HW, t, delta);
       if (!EXL && l >= L) s[l][3] = -1.0f;  // alpha 0 after (x+1)/2: an inert layer
       if ((l % kFwdGroup) == kFwdGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
     const float* __restrict__ mapping, const float* __restrict__ occ,
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
     float* __restrict__ grad_layers, float* __restrict__ grad_mapping,
-    float* __restrict__ grad_occ, int F, int L, int H, int W, int K3) {
+    float* __restrict__ grad_occ, int F, int L, int H, int W, int K3, float delta) {
   const int64_t HW = (int64_t)H * W;
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = p < HW;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
       Taps t = make_taps_px(gxs[l], gys[l], H, W);
       const float* base = layers + ((int64_t)f * L + l) * 4 * HW;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s[l][c] = tap_sample_d(base + c * HW, t, dsx[l][c], dsy[l][c]);
+      for (int c = 0; c < 4; ++c) s[l][c] = tap_sample_d(base + c * HW, t, dsx[l][c], dsy[l][c], delta);
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) s[l][c] = dsx[l][c] = dsy[l][c] = 0.0f;
@@ -438,7 +438,7 @@ static inline TileGeom tile_geom(int H, int W, int rows) {
 template <int LP, int K3P, bool EXK>
 static void launch_fwd(const float* layers, const float* basis_t, const float* mapping,
                        const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,
-                       int K3, hipStream_t st) {
+                       int K3, float delta, hipStream_t st) {
   const TileGeom g = tile_geom(H, W, 4);
   const int fpb = chunk_frames(F, g.ntiles);
   const int nchunks = (F + fpb - 1) / fpb;
@@ -450,34 +450,34 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
       dim3 grid16((unsigned)xcd_grid(nchunks, nt16));
       if (L == LP)
         hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, true>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks);
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, delta);
       else
         hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, false>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks);
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, delta);
       return;
     }
   }
   if (L == LP)
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, true, EXK>), grid, dim3(kBlock), 0, st,
                        layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
-                       nchunks);
+                       nchunks, delta);
   else
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, false, EXK>), grid, dim3(kBlock), 0, st,
                        layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
-                       nchunks);
+                       nchunks, delta);
 }
 
 template <int LP, int K3P>
 static void launch_bwd(const float* layers, const float* basis_t, const float* mapping,
                        const float* occ, const float* grad_rgb, const float* grad_alpha,
                        float* grad_layers, float* grad_mapping, float* grad_occ, int F, int L,
-                       int H, int W, int K3, hipStream_t st) {
+                       int H, int W, int K3, float delta, hipStream_t st) {
   const int64_t HW = (int64_t)H * W;
   const int tiles = (int)((HW + kBlock - 1) / kBlock);
   dim3 grid(tiles, F);
   hipLaunchKernelGGL((warp_composite_bwd_kernel<LP, K3P>), grid, dim3(kBlock), 0, st, layers,
                      basis_t, mapping, occ, grad_rgb, grad_alpha, grad_layers, grad_mapping,
-                     grad_occ, F, L, H, W, K3);
+                     grad_occ, F, L, H, W, K3, delta);
 }
 
 // two-kernel backward; workspace = Bwd2Layout
@@ -485,7 +485,7 @@ template <int LP>
 static void launch_bwd2(const float* layers, const float* basis_t, const float* mapping,
                         const float* occ, const float* grad_rgb, const float* grad_alpha,
                         void* workspace, float* grad_layers, float* grad_mapping, float* grad_occ,
-                        int F, int L, int H, int W, hipStream_t st) {
+                        int F, int L, int H, int W, float delta, hipStream_t st) {
   const Bwd2Layout lo = bwd2_layout(F, L, H, W);
   char* ws = reinterpret_cast<char*>(workspace);
   int* boxes = reinterpret_cast<int*>(ws);
@@ -504,7 +504,7 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
     hipLaunchKernelGGL((warp_composite_bwd_px16_kernel<LP, EXL, GOCC>), grid, dim3(kBlock), 0, st, layers,
                        basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
-                       grad_occ, F, L, H, W, fpb, lo.ntx16, ntiles, nchunks, lo.ncx, lo.ncells);
+                       grad_occ, F, L, H, W, fpb, lo.ntx16, ntiles, nchunks, lo.ncx, lo.ncells, delta);
   };
   if (L == LP) {
     if (grad_occ != nullptr) go(T{}, T{}); else go(T{}, N{});

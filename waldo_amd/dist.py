@@ -82,7 +82,7 @@ def all_gather_frames(local, frames, group=None):
     return out[:frames]
 
 
-def sharded_warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, gather=True):
+def sharded_warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, gather=True, delta=0.0):
     """Inference over all ranks: composite this rank's frames on its GPU (HIP kernels), then
     all-gather the RGB frames.  Inputs are the FULL (F, ...) tensors present on every rank (or
     already this rank's shard with gather=False)."""
@@ -91,5 +91,5 @@ def sharded_warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, gather
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     l, p, o = shard_frames([layers, src_pts, occ], frames, rank, world, layers=nl)
-    rgb = WF.warp_composite(l, p, o, inverse_kernel, basis_t)
+    rgb = WF.warp_composite(l, p, o, inverse_kernel, basis_t, delta=delta)
     return all_gather_frames(rgb, frames) if gather else rgb

@@ -687,7 +687,7 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
 # --------------------------------------------------------------------------------------
 class _WarpComposite(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, layers, mapping, occ, basis_t, want_alpha):
+    def forward(ctx, layers, mapping, occ, basis_t, want_alpha, delta):
         _lib.check_cuda(layers, mapping, occ, basis_t)
         layers, mapping, occ, basis_t = _c(layers), _c(mapping), _c(occ), _c(basis_t)
         f, nl, c, h, w = layers.shape
@@ -704,9 +704,10 @@ class _WarpComposite(torch.autograd.Function):
         with torch.cuda.device(layers.device):
             _lib.call("waldo_warp_composite_fwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(rgb), _lib.ptr(alpha), f, nl, h,
-                      w, k3, _lib.current_stream(layers.device))
+                      w, k3, float(delta), _lib.current_stream(layers.device))
         ctx.save_for_backward(layers, mapping, occ, basis_t)
         ctx.want_alpha = want_alpha
+        ctx.delta = float(delta)
         return rgb, alpha
 
     @staticmethod
@@ -729,11 +730,11 @@ class _WarpComposite(torch.autograd.Function):
             _lib.call("waldo_warp_composite_bwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(grad_rgb), _lib.ptr(grad_alpha),
                       _lib.ptr(gl), _lib.ptr(gm), _lib.ptr(go), _lib.ptr(ws), ws_bytes, f, nl, h,
-                      w, k3, _lib.current_stream(layers.device))
-        return gl, gm, go, None, None
+                      w, k3, ctx.delta, _lib.current_stream(layers.device))
+        return gl, gm, go, None, None, None
 
 
-def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=False):
+def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=False, delta=0.0):
     """Fused TPS grid -> bilinear warp of each 4-channel layer -> LVD.reduce_comp
     (models/modules/warp.py:49-55, F.grid_sample, models/nets/lvd.py:100-114).
 
@@ -741,18 +742,19 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
     inverse_kernel (N+3, N+3); basis_t (N+3, H*W).  Returns rgb (F, 3, H, W) and, if asked,
     the composited alpha (F, L, H, W), both in [-1, 1].
 
-    Taps outside a layer contribute 0 (delta = 0): this is the BASELINE pipeline, not
-    a drop-in for ``Warper.layer_to_output`` (delta = 1: out-of-range taps read -1, i.e. alpha 0)
-    followed by ``reduce_comp`` -- at the image border use ``grid_sample(..., delta=1)`` +
-    ``occ_composite`` for that.  Precision / NaN contract of the backward: include/waldo_hip.h."""
+    delta: the layers are sampled as ``F.grid_sample(x + delta, grid) - delta`` (lvd.py:548,559).
+    0 (default) is the BASELINE pipeline of SURVEY 8d: taps outside a layer contribute 0 (alpha 0.5 /
+    grey after ``reduce_comp``'s ``(x + 1) / 2``); 1 is ``Warper.layer_to_output``'s default:
+    out-of-range taps read -1, i.e. alpha 0 / black.  Precision / NaN contract of the backward:
+    include/waldo_hip.h."""
     mapping = tps_mapping(inverse_kernel, src_pts)
     f, nl = layers.shape[:2]
     chunk = _frames_per_call(f, nl, layers.shape[-2], layers.shape[-1], mapping.shape[1])
     if f <= chunk:
-        rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha))
+        rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha), float(delta))
     else:  # frames are independent: long batches go in pieces (launch limits, bounded workspace)
         outs = [_WarpComposite.apply(layers[i:i + chunk], mapping[i * nl:(i + chunk) * nl], occ[i:i + chunk],
-                                     basis_t, bool(return_alpha)) for i in range(0, f, chunk)]
+                                     basis_t, bool(return_alpha), float(delta)) for i in range(0, f, chunk)]
         rgb = torch.cat([o[0] for o in outs])
         alpha = torch.cat([o[1] for o in outs]) if return_alpha else None
     return (rgb, alpha) if return_alpha else rgb
