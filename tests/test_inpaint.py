@@ -91,3 +91,31 @@ def test_inpaint_hip_vs_oracle_and_reference(dev, golden, tag):
     assert out.shape == ref.shape
     frac = flipped_fraction(out, ref)
     assert frac <= 2e-3, f"{tag}: {frac:.2e} of the values differ from the reference by more than 1e-4"
+    # The two populations separately.  (1) values that did not flip: within 1e-4 by the definition of
+    # `flipped`; the number printed is how close they really are.  (2) values that did flip must be
+    # ones the REFERENCE ALGORITHM itself flips under input noise at the fp32 rounding level: the
+    # oracle is re-run on inputs perturbed by 3e-5 (a few seeds); a HIP value may differ from the
+    # reference only at, or next to, a pixel that such a perturbation moves by more than 1e-4.
+    diff = (out.detach().cpu().double() - ref.double()).abs()
+    flipped = diff > 1e-4
+    print(f"[inpaint {tag}] flipped {frac:.2e}; max error of the other values {diff[~flipped].max().item():.2e}")
+    if flipped.any():
+        cfg = WO.WarperCfg.from_opt(wopt)
+        cgrid = (g["tgo"], g["sgo"], g["tgb"], g["sgb"])
+        unstable = torch.zeros_like(flipped)
+        for seed in range(4):
+            gen = torch.Generator().manual_seed(seed)
+
+            def jig(t):
+                return t + 3e-5 * torch.randn(t.shape, generator=gen)
+            pert = IO.wif_inpaint(opt, cfg, make_forward(g), IO.stub_inpainter, jig(g["raw_output"]),
+                                  jig(g["alpha"]), jig(g["alpha_ctx"]), g["real_vid"], jig(g["pred_flow"]),
+                                  CTX_LEN, cgrid)
+            unstable |= (pert.double() - ref.double()).abs() > 1e-4
+        # a flipped mask pixel changes its 3x3 neighbourhood through the expand / blur steps
+        near = torch.nn.functional.max_pool2d(unstable.any(dim=-3, keepdim=True).float().flatten(0, -4), 5, 1, 2)
+        near = near.view(*unstable.shape[:-3], 1, *unstable.shape[-2:]).bool().expand_as(flipped)
+        inside = (flipped & near).sum().item() / flipped.sum().item()
+        print(f"[inpaint {tag}] {inside:.0%} of the flipped values lie where the oracle flips under 3e-5 input noise "
+              f"({unstable.double().mean().item():.2e} of all values)")
+        assert inside >= 0.9, f"{tag}: only {inside:.0%} of the flipped values are at noise-unstable pixels"

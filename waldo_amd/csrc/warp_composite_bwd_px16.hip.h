@@ -265,6 +265,10 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         by0[l] = ymin;
         bw[l] = ((xmax - bx0[l] + 1) + 3) & ~3;
         bh[l] = ymax - ymin + 1;
+#ifdef WALDO_ABL_NOFALLBACK  // timing-only ablation: oversize boxes are cut to the cap (wrong values)
+        bw[l] = min(bw[l], 128);
+        bh[l] = min(bh[l], kStageCap / bw[l]);
+#endif
         fits[l] = bh[l] * bw[l] <= kStageCap;  // block-uniform
       }
     }

@@ -283,6 +283,10 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
       by0[l] = ymin;
       bw[l] = ((xmax - bx0[l] + 1) + 3) & ~3;
       bh[l] = ymax - ymin + 1;
+#ifdef WALDO_ABL_NOFALLBACK  // timing-only ablation: oversize boxes are cut to the cap (wrong values)
+      bw[l] = min(bw[l], 128);
+      bh[l] = min(bh[l], kStageCap / bw[l]);
+#endif
     }
 
     // ---- (E) staging: waves 2q / 2q + 1 move the two halves of channel pair q of a layer's box,
