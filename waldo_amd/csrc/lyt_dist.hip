@@ -9,23 +9,22 @@
 //
 // The reference materialises (B, T, No, Nl, H, W) tensors for this; torch restated it as two einsums
 // plus softmaxes (0.3 ms of GEMM + elementwise kernels per LVD-recipe step, forward + backward).
-// Here: one pass over the pixels per direction.  A wave owns a group of four objects and 64 pixels
-// per trip; a lane keeps the 4 x Nl running sums of its pixels in registers (the class logits of a
-// pixel are loaded once per wave as Nl coalesced rows), the lanes are combined by a fixed butterfly,
-// and the workgroups' partial sums are added in workgroup order by a second, tiny kernel -- no
-// atomics, bitwise reproducible.  The backward needs the same reduction shape for grad_cls and is
-// elementwise for grad_alpha; the layout logits are data (no gradient: callers whose layout requires
-// one use the framework expression).
+// Here: one pass over the pixels per direction.  A workgroup takes 256 pixel-frames: each thread
+// stages the class logits (and their softmax) of one of them in LDS; then every wave owns a group of
+// four objects over all 256 pixels, a lane keeping the 4 x Nl running sums of its pixels in
+// registers.  The lanes are combined by a fixed butterfly and the workgroups' partial sums are added
+// in a fixed order by a second, small kernel -- no atomics, bitwise reproducible.  The backward has
+// the same reduction shape for grad_cls and is elementwise for grad_alpha; the layout logits are
+// data (no gradient: callers whose layout requires one use the framework expression).
 #include <math.h>
 
 #include "waldo_common.hip.h"
 
 namespace waldo {
 
-constexpr int kLdGroup = 4;        // objects per wave
-constexpr int kLdWaves = kBlock / kWave;
-constexpr int kLdTrips = 16;       // pixel trips per workgroup: 1024 pixel-frames per workgroup
-constexpr int kLdChunk = kLdTrips * kWave;
+constexpr int kLdGroup = 4;                  // objects per wave
+constexpr int kLdWaves = kBlock / kWave;     // 4: the waves of a workgroup = the pixel slices of its chunk
+constexpr int kLdChunk = kBlock;             // pixel-frames per workgroup
 constexpr int kLdMaxObj = 32, kLdMaxCls = 32;
 
 struct LytView {
@@ -33,34 +32,69 @@ struct LytView {
   int64_t batch_stride, frame_stride;  // elements; planes are HW apart, rows contiguous
 };
 
-// softmax of the NLP logits in v (entries >= Nl masked), in place -> probabilities
+// Phase 1 of both pixel kernels: every thread loads the Nl logits of ONE pixel-frame of the chunk
+// (Nl coalesced rows per wave), takes their softmax when the class weighting needs it, and leaves
+// both in LDS, class-major ([n][pixel]: conflict-free for the writer and for the readers below).
+// The four waves then each take a group of objects over ALL 256 pixels: the softmax (the expensive
+// part: ~20 instructions per class) is computed once per pixel instead of once per object group.
 template <int NLP>
-__device__ __forceinline__ void softmax_regs(float (&v)[NLP], int Nl) {
-  float mx = v[0];
+__device__ __forceinline__ void stage_logits(const LytView& lyt, int b, int64_t i, int64_t npx, int HW,
+                                             int Nl, bool want_prob, float* s_lyt, float* s_prob) {
+  const int64_t ic = i < npx ? i : npx - 1;
+  const int t = (int)(ic / HW), p = (int)(ic - (int64_t)t * HW);
+  const float* lp = lyt.base + b * lyt.batch_stride + t * lyt.frame_stride + p;
+  float v[NLP];
 #pragma unroll
-  for (int n = 1; n < NLP; ++n) mx = fmaxf(mx, n < Nl ? v[n] : mx);
-  float den = 0.0f;
+  for (int n = 0; n < NLP; ++n) v[n] = lp[(int64_t)min(n, Nl - 1) * HW];
+#pragma unroll
+  for (int n = 0; n < NLP; ++n) s_lyt[n * kBlock + threadIdx.x] = n < Nl ? v[n] : 0.0f;
+  if (want_prob) {
+    float mx = v[0];
+#pragma unroll
+    for (int n = 1; n < NLP; ++n) mx = fmaxf(mx, n < Nl ? v[n] : mx);
+    float den = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NLP; ++n) {
+      v[n] = n < Nl ? expf(v[n] - mx) : 0.0f;
+      den += v[n];
+    }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int n = 0; n < NLP; ++n) s_prob[n * kBlock + threadIdx.x] = v[n] * inv;
+  }
+}
+
+// q = sum_n (cls[n] + min_cls) prob[n], as sum_n cls[n] prob[n] + min_cls sum_n prob[n]: the class
+// vector stays a scalar operand (cls is wave-uniform), one fma per class
+template <int NLP>
+__device__ __forceinline__ float class_weight(const float* __restrict__ c, const float (&pr)[NLP], int Nl,
+                                              float min_cls) {
+  float q = 0.0f, ps = 0.0f;
 #pragma unroll
   for (int n = 0; n < NLP; ++n) {
-    v[n] = n < Nl ? expf(v[n] - mx) : 0.0f;
-    den += v[n];
+    q = fmaf(n < Nl ? c[n] : 0.0f, pr[n], q);
+    ps += pr[n];
   }
-  const float inv = 1.0f / den;
-#pragma unroll
-  for (int n = 0; n < NLP; ++n) v[n] *= inv;
+  return fmaf(min_cls, ps, q);
 }
 
 // ---- forward, pass 1: partial sums of win * lyt and of win per (workgroup, object)
-// partial: (B, chunks, No, NLP + 1), the last column is the total
+// partial: (B, No, NLP + 1, chunks) -- the chunk index fastest, so that pass 2 reads rows; column
+// NLP is the total
 template <int NLP>
 __global__ __launch_bounds__(kBlock) void lyt_dist_partial_kernel(
     const float* __restrict__ alpha, LytView lyt, const float* __restrict__ cls,
     float* __restrict__ partial, int Tw, int La, int obj0, int No, int Nl, int HW, int chunks,
     float min_cls) {
+  __shared__ float s_lyt[NLP * kBlock];
+  __shared__ float s_prob[NLP * kBlock];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t npx = (int64_t)Tw * HW;
+  const bool weighted = cls != nullptr;
+  stage_logits<NLP>(lyt, b, (int64_t)chunk * kLdChunk + threadIdx.x, npx, HW, Nl, weighted, s_lyt, s_prob);
+  __syncthreads();
   const int ngroups = (No + kLdGroup - 1) / kLdGroup;
   for (int grp = wave; grp < ngroups; grp += kLdWaves) {
     float acc[kLdGroup][NLP], tot[kLdGroup];
@@ -70,31 +104,27 @@ __global__ __launch_bounds__(kBlock) void lyt_dist_partial_kernel(
 #pragma unroll
       for (int n = 0; n < NLP; ++n) acc[j][n] = 0.0f;
     }
-    for (int it = 0; it < kLdTrips; ++it) {
-      const int64_t i = (int64_t)chunk * kLdChunk + it * kWave + lane;
+    for (int sl = 0; sl < kLdWaves; ++sl) {
+      const int px = sl * kWave + lane;
+      const int64_t i = (int64_t)chunk * kLdChunk + px;
       const bool live = i < npx;
       const int64_t ic = live ? i : npx - 1;
       const int t = (int)(ic / HW), p = (int)(ic - (int64_t)t * HW);
-      const float* lp = lyt.base + b * lyt.batch_stride + t * lyt.frame_stride + p;
+      const float* ap = alpha + (((int64_t)b * Tw + t) * La + obj0) * HW + p;
+      float av[kLdGroup];
+#pragma unroll
+      for (int j = 0; j < kLdGroup; ++j) av[j] = ap[(int64_t)min(grp * kLdGroup + j, No - 1) * HW];
       float lv[NLP], pr[NLP];
 #pragma unroll
       for (int n = 0; n < NLP; ++n) {
-        lv[n] = lp[(int64_t)min(n, Nl - 1) * HW];
-        pr[n] = lv[n];
+        lv[n] = s_lyt[n * kBlock + px];
+        pr[n] = weighted ? s_prob[n * kBlock + px] : 0.0f;
       }
-      if (cls != nullptr) softmax_regs<NLP>(pr, Nl);
-      const float* ap = alpha + (((int64_t)b * Tw + t) * La + obj0) * HW + p;
 #pragma unroll
       for (int j = 0; j < kLdGroup; ++j) {
         const int o = min(grp * kLdGroup + j, No - 1);
-        float q = 1.0f;
-        if (cls != nullptr) {
-          const float* c = cls + ((int64_t)b * No + o) * Nl;  // wave-uniform: scalar loads
-          q = 0.0f;
-#pragma unroll
-          for (int n = 0; n < NLP; ++n) q = fmaf(n < Nl ? c[n] + min_cls : 0.0f, pr[n], q);
-        }
-        const float win = live ? (ap[(int64_t)o * HW] + 1e-6f) * q : 0.0f;
+        const float q = weighted ? class_weight<NLP>(cls + ((int64_t)b * No + o) * Nl, pr, Nl, min_cls) : 1.0f;
+        const float win = live ? (av[j] + 1e-6f) * q : 0.0f;
         tot[j] += win;
 #pragma unroll
         for (int n = 0; n < NLP; ++n) acc[j][n] = fmaf(win, lv[n], acc[j][n]);
@@ -103,47 +133,76 @@ __global__ __launch_bounds__(kBlock) void lyt_dist_partial_kernel(
 #pragma unroll
     for (int j = 0; j < kLdGroup; ++j) {
       const int o = grp * kLdGroup + j;
-      float* out = partial + (((int64_t)b * chunks + chunk) * No + min(o, No - 1)) * (NLP + 1);
+      float* out = partial + (((int64_t)b * No + min(o, No - 1)) * (NLP + 1)) * chunks + chunk;
       const float ts = wave_sum(tot[j]);
-#pragma unroll
-      for (int n = 0; n < NLP; ++n) {
-        const float s = wave_sum(acc[j][n]);
-        if (lane == 0 && o < No) out[n] = s;
-      }
-      if (lane == 0 && o < No) out[NLP] = ts;
+      // all NLP sums in ~2 NLP cross-lane steps: lane l ends up with column bitrev6(l)
+      const float cs = wave_transpose_reduce<NLP>(acc[j], lane);
+      const int n = bitrev6(lane);
+      if (n < NLP && o < No) out[(int64_t)n * chunks] = cs;
+      if (lane == 0 && o < No) out[(int64_t)NLP * chunks] = ts;
     }
   }
 }
 
-// ---- forward, pass 2: partial sums in workgroup order -> total, mean, dist.  One workgroup per
-// batch item, one thread per (object, class) pair at a time.
+// Sums of the (up to 33) rows of `chunks` partials of one (batch item, object), the same order
+// whatever the hardware does: thread t adds the elements t, t + 256, ... of every row (coalesced,
+// all loads independent and in flight together), one transpose-reduce joins the lanes, the four
+// waves' sums are added in wave order.  s_rows[0 .. ncols) receives the sums.
+__device__ __forceinline__ void row_sums(const float* __restrict__ rows, int ncols, int chunks,
+                                         float* s_part, float* s_rows) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  float a[kLdMaxCls], last = 0.0f;
+#pragma unroll
+  for (int n = 0; n < kLdMaxCls; ++n) a[n] = 0.0f;
+  for (int c = threadIdx.x; c < chunks; c += kBlock) {
+    // branch-free (rows past the last are re-reads of it, masked): behind a branch per row the
+    // compiler waits for every load before it issues the next (21 us for this loop instead of ~5)
+    float x[kLdMaxCls + 1];
+#pragma unroll
+    for (int n = 0; n <= kLdMaxCls; ++n) x[n] = rows[(int64_t)min(n, ncols - 1) * chunks + c];
+#pragma unroll
+    for (int n = 0; n < kLdMaxCls; ++n) a[n] += n < ncols ? x[n] : 0.0f;
+    last += kLdMaxCls < ncols ? x[kLdMaxCls] : 0.0f;
+  }
+  const float cs = wave_transpose_reduce<kLdMaxCls>(a, lane);
+  last = wave_sum(last);
+  const int n = bitrev6(lane);
+  if (n < kLdMaxCls) s_part[wave * (kLdMaxCls + 1) + n] = cs;
+  if (lane == 0) s_part[wave * (kLdMaxCls + 1) + kLdMaxCls] = last;
+  __syncthreads();
+  if (threadIdx.x < ncols) {
+    const int k = threadIdx.x;
+    s_rows[k] = (s_part[k] + s_part[(kLdMaxCls + 1) + k]) + (s_part[2 * (kLdMaxCls + 1) + k] + s_part[3 * (kLdMaxCls + 1) + k]);
+  }
+  __syncthreads();
+}
+
+// ---- forward, pass 2: partials -> total, mean, dist.  One workgroup per (object, batch item).
 __global__ __launch_bounds__(kBlock) void lyt_dist_finish_kernel(const float* __restrict__ partial,
                                                                  float* __restrict__ dist,
                                                                  float* __restrict__ mean,
                                                                  float* __restrict__ total, int No,
                                                                  int Nl, int NLP, int chunks) {
-  __shared__ float s[kLdMaxObj * (kLdMaxCls + 1)];
-  const int b = blockIdx.x, pitch = NLP + 1;
-  for (int e = threadIdx.x; e < No * pitch; e += kBlock) {
-    const float* p = partial + (int64_t)b * chunks * No * pitch + e;
-    float a = 0.0f;
-    for (int c = 0; c < chunks; ++c) a += p[(int64_t)c * No * pitch];
-    s[e] = a;
-  }
+  __shared__ float s_part[kLdWaves * (kLdMaxCls + 1)];
+  __shared__ float s_rows[kLdMaxCls + 1];
+  const int o = blockIdx.x, b = blockIdx.y;
+  row_sums(partial + (((int64_t)b * No + o) * (NLP + 1)) * chunks, NLP + 1, chunks, s_part, s_rows);
+  const float t = s_rows[NLP];
+  const int n = threadIdx.x;
+  const float m = n < Nl ? s_rows[n] / t : 0.0f;
   __syncthreads();
-  for (int o = threadIdx.x; o < No; o += kBlock) {
-    const float t = s[o * pitch + NLP];
-    float mx = -__builtin_huge_valf();
-    for (int n = 0; n < Nl; ++n) {
-      const float m = s[o * pitch + n] / t;
-      mean[((int64_t)b * No + o) * Nl + n] = m;
-      s[o * pitch + n] = m;
-      mx = fmaxf(mx, m);
-    }
+  if (n < Nl) {
+    s_rows[n] = m;
+    mean[((int64_t)b * No + o) * Nl + n] = m;
+  }
+  if (n == 0) total[(int64_t)b * No + o] = t;
+  __syncthreads();
+  if (n < Nl) {  // every thread walks the row in the same order: one softmax, the same bits in all
+    float mx = s_rows[0];
+    for (int k = 1; k < Nl; ++k) mx = fmaxf(mx, s_rows[k]);
     float den = 0.0f;
-    for (int n = 0; n < Nl; ++n) den += expf(s[o * pitch + n] - mx);
-    for (int n = 0; n < Nl; ++n) dist[((int64_t)b * No + o) * Nl + n] = expf(s[o * pitch + n] - mx) / den;
-    total[(int64_t)b * No + o] = t;
+    for (int k = 0; k < Nl; ++k) den += expf(s_rows[k] - mx);
+    dist[((int64_t)b * No + o) * Nl + n] = expf(m - mx) / den;
   }
 }
 
@@ -183,19 +242,23 @@ __global__ __launch_bounds__(kBlock) void lyt_dist_bwd_kernel(
     const float* __restrict__ alpha, LytView lyt, const float* __restrict__ cls,
     const float* __restrict__ coef, float* __restrict__ grad_alpha, float* __restrict__ partial,
     int Tw, int La, int obj0, int No, int Nl, int HW, int chunks, float min_cls) {
+  __shared__ float s_lyt[NLP * kBlock];
+  __shared__ float s_prob[NLP * kBlock];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t npx = (int64_t)Tw * HW;
-  // layers in front of the objects (the background) take no part: zero gradient
-  for (int l = 0; l < obj0; ++l)
-    for (int k = threadIdx.x; k < kLdChunk; k += kBlock) {
-      const int64_t i = (int64_t)chunk * kLdChunk + k;
-      if (i < npx) {
-        const int t = (int)(i / HW), p = (int)(i - (int64_t)t * HW);
-        grad_alpha[(((int64_t)b * Tw + t) * La + l) * HW + p] = 0.0f;
-      }
+  const bool weighted = cls != nullptr;
+  {
+    const int64_t i = (int64_t)chunk * kLdChunk + threadIdx.x;
+    stage_logits<NLP>(lyt, b, i, npx, HW, Nl, weighted, s_lyt, s_prob);
+    // layers in front of the objects (the background) take no part: zero gradient
+    if (i < npx) {
+      const int t = (int)(i / HW), p = (int)(i - (int64_t)t * HW);
+      for (int l = 0; l < obj0; ++l) grad_alpha[(((int64_t)b * Tw + t) * La + l) * HW + p] = 0.0f;
     }
+  }
+  __syncthreads();
   const int ngroups = (No + kLdGroup - 1) / kLdGroup;
   for (int grp = wave; grp < ngroups; grp += kLdWaves) {
     float acc[kLdGroup][NLP];
@@ -203,71 +266,62 @@ __global__ __launch_bounds__(kBlock) void lyt_dist_bwd_kernel(
     for (int j = 0; j < kLdGroup; ++j)
 #pragma unroll
       for (int n = 0; n < NLP; ++n) acc[j][n] = 0.0f;
-    for (int it = 0; it < kLdTrips; ++it) {
-      const int64_t i = (int64_t)chunk * kLdChunk + it * kWave + lane;
+    for (int sl = 0; sl < kLdWaves; ++sl) {
+      const int px = sl * kWave + lane;
+      const int64_t i = (int64_t)chunk * kLdChunk + px;
       const bool live = i < npx;
       const int64_t ic = live ? i : npx - 1;
       const int t = (int)(ic / HW), p = (int)(ic - (int64_t)t * HW);
-      const float* lp = lyt.base + b * lyt.batch_stride + t * lyt.frame_stride + p;
+      const int64_t aoff = (((int64_t)b * Tw + t) * La + obj0) * HW + p;
+      float av[kLdGroup];
+#pragma unroll
+      for (int j = 0; j < kLdGroup; ++j)
+        av[j] = weighted ? alpha[aoff + (int64_t)min(grp * kLdGroup + j, No - 1) * HW] : 0.0f;
       float lv[NLP], pr[NLP];
 #pragma unroll
       for (int n = 0; n < NLP; ++n) {
-        lv[n] = lp[(int64_t)min(n, Nl - 1) * HW];
-        pr[n] = lv[n];
+        lv[n] = s_lyt[n * kBlock + px];
+        pr[n] = weighted ? s_prob[n * kBlock + px] : 0.0f;
       }
-      if (cls != nullptr) softmax_regs<NLP>(pr, Nl);
-      const int64_t aoff = (((int64_t)b * Tw + t) * La + obj0) * HW + p;
 #pragma unroll
       for (int j = 0; j < kLdGroup; ++j) {
         const int o = min(grp * kLdGroup + j, No - 1);
-        const float* cf = coef + ((int64_t)b * No + o) * (NLP + 1);  // wave-uniform
+        const float* cf = coef + ((int64_t)b * No + o) * (NLP + 1);  // wave-uniform: scalar operands
         float gw = cf[NLP];
 #pragma unroll
-        for (int n = 0; n < NLP; ++n) gw = fmaf(n < Nl ? cf[n] : 0.0f, lv[n], gw);
-        float q = 1.0f;
-        if (cls != nullptr) {
-          const float* c = cls + ((int64_t)b * No + o) * Nl;
-          q = 0.0f;
-#pragma unroll
-          for (int n = 0; n < NLP; ++n) q = fmaf(n < Nl ? c[n] + min_cls : 0.0f, pr[n], q);
-        }
+        for (int n = 0; n < NLP; ++n) gw = fmaf(cf[n], lv[n], gw);  // columns >= Nl of coef are 0
+        const float q = weighted ? class_weight<NLP>(cls + ((int64_t)b * No + o) * Nl, pr, Nl, min_cls) : 1.0f;
         const bool on = live && grp * kLdGroup + j < No;
         if (on) grad_alpha[aoff + (int64_t)o * HW] = gw * q;
-        if (cls != nullptr) {
-          const float gq = on ? gw * (alpha[aoff + (int64_t)o * HW] + 1e-6f) : 0.0f;
+        if (weighted) {
+          const float gq = on ? gw * (av[j] + 1e-6f) : 0.0f;
 #pragma unroll
           for (int n = 0; n < NLP; ++n) acc[j][n] = fmaf(gq, pr[n], acc[j][n]);
         }
       }
     }
-    if (cls != nullptr) {
+    if (weighted) {
 #pragma unroll
       for (int j = 0; j < kLdGroup; ++j) {
         const int o = grp * kLdGroup + j;
-        float* out = partial + (((int64_t)b * chunks + chunk) * No + min(o, No - 1)) * (NLP + 1);
-#pragma unroll
-        for (int n = 0; n < NLP; ++n) {
-          const float s = wave_sum(acc[j][n]);
-          if (lane == 0 && o < No) out[n] = s;
-        }
+        float* out = partial + (((int64_t)b * No + min(o, No - 1)) * (NLP + 1)) * chunks + chunk;
+        const float cs = wave_transpose_reduce<NLP>(acc[j], lane);
+        const int n = bitrev6(lane);
+        if (n < NLP && o < No) out[(int64_t)n * chunks] = cs;
       }
     }
   }
 }
 
-// ---- backward, pass 3: grad_cls = partial sums in workgroup order
+// ---- backward, pass 3: grad_cls = the partials of a row; one workgroup per (object, batch item)
 __global__ __launch_bounds__(kBlock) void lyt_dist_gcls_kernel(const float* __restrict__ partial,
-                                                               float* __restrict__ grad_cls, int64_t B,
-                                                               int No, int Nl, int NLP, int chunks) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= B * No * Nl) return;
-  const int n = (int)(e % Nl), o = (int)((e / Nl) % No);
-  const int64_t b = e / ((int64_t)Nl * No);
-  const int pitch = NLP + 1;
-  const float* p = partial + (b * chunks * No + o) * pitch + n;
-  float a = 0.0f;
-  for (int c = 0; c < chunks; ++c) a += p[(int64_t)c * No * pitch];
-  grad_cls[e] = a;
+                                                               float* __restrict__ grad_cls, int No,
+                                                               int Nl, int NLP, int chunks) {
+  __shared__ float s_part[kLdWaves * (kLdMaxCls + 1)];
+  __shared__ float s_rows[kLdMaxCls + 1];
+  const int o = blockIdx.x, b = blockIdx.y;
+  row_sums(partial + (((int64_t)b * No + o) * (NLP + 1)) * chunks, Nl, chunks, s_part, s_rows);
+  if (threadIdx.x < Nl) grad_cls[((int64_t)b * No + o) * Nl + threadIdx.x] = s_rows[threadIdx.x];
 }
 
 static int check_ld(const char* fn, int64_t B, int Tw, int La, int obj0, int No, int Nl, int H, int W) {
@@ -339,8 +393,8 @@ extern "C" int waldo_lyt_dist_fwd(const float* alpha, const float* lyt, int64_t 
 #define CALL(N) launch_ld_fwd<N>(alpha, lv, cls, workspace, B, Tw, layers, first_obj, No, Nl, H * W, chunks, min_cls, st)
   WALDO_LD_DISPATCH(nlp, CALL)
 #undef CALL
-  hipLaunchKernelGGL(lyt_dist_finish_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, workspace, dist, mean,
-                     total, No, Nl, nlp, chunks);
+  hipLaunchKernelGGL(lyt_dist_finish_kernel, dim3((unsigned)No, (unsigned)B), dim3(kBlock), 0, st, workspace,
+                     dist, mean, total, No, Nl, nlp, chunks);
   return launch_status("waldo_lyt_dist_fwd");
 }
 
@@ -370,10 +424,8 @@ extern "C" int waldo_lyt_dist_bwd(const float* grad_dist, const float* alpha, co
 #define CALL(N) launch_ld_bwd<N>(alpha, lv, cls, coef, grad_alpha, partial, B, Tw, layers, first_obj, No, Nl, H * W, chunks, min_cls, st)
   WALDO_LD_DISPATCH(nlp, CALL)
 #undef CALL
-  if (cls != nullptr) {
-    const int64_t n = B * No * Nl;
-    hipLaunchKernelGGL(lyt_dist_gcls_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       partial, grad_cls, B, No, Nl, nlp, chunks);
-  }
+  if (cls != nullptr)
+    hipLaunchKernelGGL(lyt_dist_gcls_kernel, dim3((unsigned)No, (unsigned)B), dim3(kBlock), 0, st, partial,
+                       grad_cls, No, Nl, nlp, chunks);
   return launch_status("waldo_lyt_dist_bwd");
 }
