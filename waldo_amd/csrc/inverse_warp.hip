@@ -55,12 +55,17 @@ __global__ __launch_bounds__(kBlock) void iw_splat_kernel(
   dxy[(b * 2 + 1) * HW + s] = dy;
   const float txf = rintf((float)x + dx), tyf = rintf((float)y + dy);  // round half to even
   int c = -1;
-  if (txf >= 0.0f && tyf >= 0.0f && txf <= (float)(W - 1) && tyf <= (float)(H - 1)) {
-    c = (int)tyf * W + (int)txf;
-    // priority of a sample among those landing on one cell: its position in the tie-break order
-    atomicMin(winner + b * HW + c, rank ? rank[s] : s);
-  }
+  if (txf >= 0.0f && tyf >= 0.0f && txf <= (float)(W - 1) && tyf <= (float)(H - 1)) c = (int)tyf * W + (int)txf;
   cell[b * HW + s] = c;
+  // Election: the lowest priority (sample index, or position in the tie-break order) wins the cell.
+  // An object map is a minification: runs of neighbouring samples land on one cell, and ~15 per
+  // covered cell overall; the L2 arbitrates them one by one (the atomics are 3/4 of this kernel).
+  // In sample-index order the first lane of a run of equal cells beats the rest of the run, so only
+  // it asks.  (A look at the current winner before the atomic costs what the atomic costs: measured.)
+  const int key = rank ? rank[s] : s;
+  const int left = __shfl_up(c, 1, kWave);
+  const bool run = rank == nullptr && (threadIdx.x & (kWave - 1)) != 0 && left == c;
+  if (c >= 0 && !run) atomicMin(winner + b * HW + c, key);
 }
 
 // ---- step 2b (tie-break order given): the elected position -> the sample standing there
@@ -397,38 +402,60 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fill_kernel(float* __restrict__
   gy[e] += ay;
 }
 
-// d loss / d (dx, dy) of the winners, then the adjoint of the bilinear resize
-__global__ __launch_bounds__(kBlock) void iw_bwd_splat_kernel(
+// d loss / d (dx, dy) of the winners, then the adjoint of the bilinear resize -- as a GATHER: one
+// thread per source texel and component pair sums the samples whose bilinear footprint contains the
+// texel (those with y0 == j or y1 == j, likewise in x: a (2 H / Hs) x (2 W / Ws) window), each with
+// the weight the forward gave it.  No atomics, no zero-fill, bitwise reproducible; the scatter it
+// replaces put 8 float atomics per winner on addresses shared by the 4-8 neighbouring samples
+// (68 us per call at the recipe).
+__global__ __launch_bounds__(kBlock) void iw_bwd_gather_kernel(
     const float* __restrict__ gfield, const int* __restrict__ cell, const int* __restrict__ winner,
     float* __restrict__ gsrc, int Hs, int Ws, int H, int W, int pad) {
   const int64_t b = blockIdx.y;
   const int HW = H * W, Wp = W + 2 * pad, HWp = (H + 2 * pad) * Wp;
-  const int s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= HW) return;
-  const int c = cell[b * HW + s];
-  if (c < 0 || winner[b * HW + c] != s) return;
-  const int cy = c / W, cx = c - cy * W;
-  const int e = (cy + pad) * Wp + (cx + pad);
-  // field = -d(px);  d(px) = d(normalised) * size / 2
-  const float gdx = -gfield[(b * 2 + 0) * HWp + e] * (float)W / 2.0f;
-  const float gdy = -gfield[(b * 2 + 1) * HWp + e] * (float)H / 2.0f;
-  const int y = s / W, x = s - y * W;
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= Hs * Ws) return;
+  const int j = t / Ws, i = t - j * Ws;
   const float sh = (float)Hs / (float)H, sw = (float)Ws / (float)W;
-  const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f);
-  const float fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + ((y0 < Hs - 1) ? 1 : 0), x1 = x0 + ((x0 < Ws - 1) ? 1 : 0);
-  const float ly = fy - (float)y0, lx = fx - (float)x0;
-  const float hy = 1.0f - ly, hx = 1.0f - lx;
-  float* g = gsrc + b * Hs * Ws * 2;
-  atomicAdd(g + (y0 * Ws + x0) * 2 + 0, hy * hx * gdx);
-  atomicAdd(g + (y0 * Ws + x0) * 2 + 1, hy * hx * gdy);
-  atomicAdd(g + (y0 * Ws + x1) * 2 + 0, hy * lx * gdx);
-  atomicAdd(g + (y0 * Ws + x1) * 2 + 1, hy * lx * gdy);
-  atomicAdd(g + (y1 * Ws + x0) * 2 + 0, ly * hx * gdx);
-  atomicAdd(g + (y1 * Ws + x0) * 2 + 1, ly * hx * gdy);
-  atomicAdd(g + (y1 * Ws + x1) * 2 + 0, ly * lx * gdx);
-  atomicAdd(g + (y1 * Ws + x1) * 2 + 1, ly * lx * gdy);
+  // samples whose source row interval [y0, y1] can contain j: fy in (j - 1, j + 1), one sample of
+  // slack on either side for the rounding of the float expressions (the weights below are exact
+  // zeros / skips for a sample that does not touch the texel)
+  const int ya = max((int)floorf(((float)j - 0.5f) / sh - 0.5f) - 1, 0);
+  const int yb = min((int)ceilf(((float)j + 1.5f) / sh - 0.5f) + 1, H - 1);
+  const int xa = max((int)floorf(((float)i - 0.5f) / sw - 0.5f) - 1, 0);
+  const int xb = min((int)ceilf(((float)i + 1.5f) / sw - 0.5f) + 1, W - 1);
+  float ax = 0.0f, ay = 0.0f;
+  // rows / columns of the window that do not touch the texel are skipped before any load (walking
+  // the whole window for winners first and weighting only those measured 2x slower: the loads of
+  // `cell`, 16 bytes apart across the lanes, are what this kernel pays for)
+  for (int y = ya; y <= yb; ++y) {
+    const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)fy, y1 = y0 + ((y0 < Hs - 1) ? 1 : 0);
+    if (y0 != j && y1 != j) continue;
+    const float ly = fy - (float)y0;
+    // weight of row j in this sample (y0 == y1 at the last row: both terms go to it, as in the forward)
+    const float wy = (y0 == j ? 1.0f - ly : 0.0f) + (y1 == j ? ly : 0.0f);
+    for (int x = xa; x <= xb; ++x) {
+      const float fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
+      const int x0 = (int)fx, x1 = x0 + ((x0 < Ws - 1) ? 1 : 0);
+      if (x0 != i && x1 != i) continue;
+      const int s = y * W + x;
+      const int c = cell[b * HW + s];
+      if (c < 0 || winner[b * HW + c] != s) continue;
+      const float lx = fx - (float)x0;
+      const float wx = (x0 == i ? 1.0f - lx : 0.0f) + (x1 == i ? lx : 0.0f);
+      const int cy = c / W, cx = c - cy * W;
+      const int e = (cy + pad) * Wp + (cx + pad);
+      // field = -d(px);  d(px) = d(normalised) * size / 2
+      const float gdx = -gfield[(b * 2 + 0) * HWp + e] * (float)W / 2.0f;
+      const float gdy = -gfield[(b * 2 + 1) * HWp + e] * (float)H / 2.0f;
+      ax = fmaf(wy * wx, gdx, ax);
+      ay = fmaf(wy * wx, gdy, ay);
+    }
+  }
+  float* g = gsrc + (b * Hs * Ws + t) * 2;
+  g[0] = ax;
+  g[1] = ay;
 }
 
 static int check_iw(const char* fn, int64_t B, int Hs, int Ws, int H, int W, int niter) {
@@ -577,8 +604,7 @@ extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3
   for (int it = niter; it >= 1; --it)
     hipLaunchKernelGGL(iw_bwd_fill_kernel, gp, dim3(kBlock), 0, st, gfield, fill_iter, denom,
                        gauss3x3, Hp, Wp, it);
-  (void)hipMemsetAsync(grad_src_grid, 0, sizeof(float) * (size_t)B * Hs * Ws * 2, st);
-  hipLaunchKernelGGL(iw_bwd_splat_kernel, gs, dim3(kBlock), 0, st, gfield, cell, winner,
-                     grad_src_grid, Hs, Ws, H, W, pad);
+  hipLaunchKernelGGL(iw_bwd_gather_kernel, dim3((Hs * Ws + kBlock - 1) / kBlock, (unsigned)B), dim3(kBlock), 0,
+                     st, gfield, cell, winner, grad_src_grid, Hs, Ws, H, W, pad);
   return launch_status("waldo_inverse_warp_bwd");
 }
