@@ -14,4 +14,5 @@ B.CFLAGS = B.CFLAGS + flags
 B.OBJ = os.path.join("/tmp", "waldo_variants", name)  # objects stay out of the tree (gpurun ships the tree)
 B.LIB = os.path.join(B.LIBDIR, "abl", name + ".so")
 os.makedirs(B.OBJ, exist_ok=True)
+os.makedirs(os.path.dirname(B.LIB), exist_ok=True)
 print(B.build(force=False, verbose=True))

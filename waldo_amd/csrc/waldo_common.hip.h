@@ -41,6 +41,30 @@ __device__ __forceinline__ bool xcd_decode(unsigned bid, int nA, int nB, int& a,
   return a < nA;
 }
 
+// Short launches (a few frames: the passes of the two-kernel backward) would leave XCDs idle with
+// one outer unit per frame: a frame's nT tiles are cut into nbands bands of contiguous tiles
+// (whole tile rows when nbands divides the row count) and the unit pinned to an XCD is
+// (frame, band).  nbands = 1 is xcd_decode.
+__host__ __device__ inline int xcd_bands(int nA) {  // smallest band count that makes nA * nbands a multiple of 8
+  int g = nA, b = kXcds;
+  while (b) { const int t = g % b; g = b; b = t; }
+  return kXcds / g;
+}
+__device__ __forceinline__ bool xcd_decode_banded(unsigned bid, int nA, int nbands, int nT, int inner,
+                                                  int& a, int& tile, int& rest) {
+  const int tpb = (nT + nbands - 1) / nbands;
+  int unit, j;
+  if (!xcd_decode(bid, nA * nbands, tpb * inner, unit, j)) return false;
+  a = unit / nbands;
+  const int t = j / inner;
+  rest = j - t * inner;
+  tile = (unit - a * nbands) * tpb + t;
+  return tile < nT;
+}
+__host__ inline int64_t xcd_grid_banded(int64_t nA, int nbands, int64_t nT, int64_t inner) {
+  return xcd_grid(nA * nbands, ((nT + nbands - 1) / nbands) * inner);
+}
+
 // ---------------------------------------------------------------------------------------
 // Bilinear taps of grid_sample(mode=bilinear, padding_mode=zeros, align_corners=False).
 //   ix = ((x + 1) * W - 1) / 2 ; corners (x0,y0) .. (x0+1,y0+1); a corner outside the image
@@ -273,6 +297,13 @@ __device__ __forceinline__ void stream_store16(float* uniform_base, uint32_t byt
 
 // measured at the headline shape (backward 2.247 ms with plain stores): records nt 2.210, sc1 2.236;
 // gradient planes nt 2.218; both nt 2.193; nt LOADS of the records in K2 2.267 (worse)
+// timing-only ablation (-DWALDO_ABL_REC_ALIAS=n, wrong values): every frame's records alias those of
+// frame f % n, i.e. the records stay resident in the Infinity Cache
+#ifdef WALDO_ABL_REC_ALIAS
+#define WALDO_REC_FRAME(f) ((f) % WALDO_ABL_REC_ALIAS)
+#else
+#define WALDO_REC_FRAME(f) (f)
+#endif
 #ifndef WALDO_REC_STORE_POLICY
 #define WALDO_REC_STORE_POLICY 2
 #endif

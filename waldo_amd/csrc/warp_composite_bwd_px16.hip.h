@@ -96,18 +96,18 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
     float4* __restrict__ rec, int* __restrict__ cellbox,
     unsigned* __restrict__ cellbound, float* __restrict__ gmap_partial, float* __restrict__ grad_occ,
-    int F, int Lrt, int H, int W, int frames_per_block, int ntx, int ntiles, int nchunks, int ncx,
-    int ncells, float delta) {
+    int F, int Lrt, int H, int W, int frames_per_block, int ntx, int ntiles, int nchunks, int nbands,
+    int ncx, int ncells, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   using C = Px16Cfg<LP>;
   constexpr int K3 = C::K3, KS = C::KS, NT = C::NT, GGC = C::GGC, TP = C::TP, PP1 = C::PP1, BP = C::BP;
   constexpr bool kPark = C::kPark;
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int arow = lane & 15, kk = lane >> 4;
-  int chunk, tile;  // frame chunk pinned to an XCD
-  if (!xcd_decode(blockIdx.x, nchunks, ntiles, chunk, tile)) return;
+  int chunk, tile, rest_;  // (frame chunk, band of tiles) pinned to an XCD
+  if (!xcd_decode_banded(blockIdx.x, nchunks, nbands, ntiles, 1, chunk, tile, rest_)) return;
 
   // LDS:
   //   park   (parked variant) rows 0 .. 4*LP-1, one column per pixel: the parked tap derivatives;
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       const float rcp = __builtin_amdgcn_rcpf((float)bw4);
       const int item = min(item_l, n - 1);
       const int r = (int)(((float)item + 0.5f) * rcp);
-      const int xg = item - r * bw4;
-      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-      stg[l].a = *reinterpret_cast<const f32x4*>(src + off);
-      stg[l].b = *reinterpret_cast<const f32x4*>(src + HW + off);
+      const int xg = item - __mul24(r, bw4);
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
+      stg[l].a = ld16(src, off);
+      stg[l].b = ld16(src + HW, off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           float fx, fy, shift = 0.0f;
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1
-            const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
+            const int idx = __mul24(tc.y0 - by0[l], bw[l]) + (tc.x0 - bx0[l]);  // inside the box
             pb = read_block(b0, idx, bw[l]);
             fx = tc.fx;
             fy = tc.fy;
           } else {
             const BoxTaps t = make_box_taps(tc, H, W);
             // inside the box by construction; the clamp only matters for NaN coordinates
-            const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+            const int idx = min(max(__mul24(t.yb - by0[l], bw[l]) + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
             pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
             // delta padding: corner values shifted before their validity (the interior path needs
             // no shift: with every corner valid the weights sum to 1 and the shift cancels)
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
       for (int l = 0; l < LP; ++l)
         if (EXL || l < L)
-          stream_store16<WALDO_REC_STORE_POLICY>(reinterpret_cast<float*>(rec + ((int64_t)f * L + l) * HW),
+          stream_store16<WALDO_REC_STORE_POLICY>(reinterpret_cast<float*>(rec + ((int64_t)WALDO_REC_FRAME(f) * L + l) * HW),
                                                  (uint32_t)p * 16u, HW * 16,
                                                  (f32x4){gxs[l], gys[l], ap[l], l >= 1 ? 0.5f * ga[l] : 0.0f});
     }

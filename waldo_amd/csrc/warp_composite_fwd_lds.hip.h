@@ -86,10 +86,39 @@ struct StageRegs {
   f32x4_t a, b;
 };
 
+#ifndef WALDO_STAGE_PKMOV
+#define WALDO_STAGE_PKMOV 1
+#endif
+// (a.lo, b.lo) and (a.hi, b.hi) of two register pairs: v_pk_mov_b32 takes its low result from
+// src0[op_sel[0]] and its high result from src1[op_sel[1]] -- the interleave of four texels of two
+// planes costs four instructions instead of seven moves (hipcc 7.2 does not form them by itself)
+__device__ __forceinline__ f32x2_t pk_lo(f32x2_t a, f32x2_t b) {
+  f32x2_t d;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2_t pk_hi(f32x2_t a, f32x2_t b) {
+  f32x2_t d;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 __device__ __forceinline__ void stage_store(float* pairplane, int item, const StageRegs& r) {
   f32x4_t* dst = reinterpret_cast<f32x4_t*>(pairplane + 8 * item);
+#if WALDO_STAGE_PKMOV
+  const f32x2_t a01 = __builtin_shufflevector(r.a, r.a, 0, 1), a23 = __builtin_shufflevector(r.a, r.a, 2, 3);
+  const f32x2_t b01 = __builtin_shufflevector(r.b, r.b, 0, 1), b23 = __builtin_shufflevector(r.b, r.b, 2, 3);
+  dst[0] = __builtin_shufflevector(pk_lo(a01, b01), pk_hi(a01, b01), 0, 1, 2, 3);
+  dst[1] = __builtin_shufflevector(pk_lo(a23, b23), pk_hi(a23, b23), 0, 1, 2, 3);
+#else
   dst[0] = (f32x4_t){r.a[0], r.b[0], r.a[1], r.b[1]};
   dst[1] = (f32x4_t){r.a[2], r.b[2], r.a[3], r.b[3]};
+#endif
+}
+
+// 16 bytes at a 32-bit byte offset from a wave-uniform base (scalar base + VGPR offset addressing)
+__device__ __forceinline__ f32x4_t ld16(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // the four taps of both channel pairs at texel index idx (row-major, pitch bw) of a layer image
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int frames_per_block, int ntx,
-    int ntiles, int nchunks, float delta) {
+    int ntiles, int nchunks, int nbands, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
@@ -155,10 +184,12 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  // wave index as a scalar: everything derived from it (tile rows, the staged channel pair, the
+  // plane pointers of the staging loads) stays in SGPRs
+  const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int arow = lane & 15, kk = lane >> 4;
-  int chunk, tile;
-  if (!xcd_decode(blockIdx.x, nchunks, ntiles, chunk, tile)) return;
+  int chunk, tile, rest_;
+  if (!xcd_decode_banded(blockIdx.x, nchunks, nbands, ntiles, 1, chunk, tile, rest_)) return;
   const int col0 = (tile % ntx) * kLdsTile, row0 = (tile / ntx) * kLdsTile + wave * 4;
   // 16 x 16 tile: wave w covers rows 4w .. 4w+3, lane -> (row 4w + lane / 16, column lane % 16)
   PixelMap pm;
@@ -311,10 +342,10 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
       const float rcp = __builtin_amdgcn_rcpf((float)bw4);
       const int item = min(item_l, n - 1);
       const int r = (int)(((float)item + 0.5f) * rcp);
-      const int xg = item - r * bw4;
-      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg);
-      stg[l].a = *reinterpret_cast<const f32x4*>(src + off);
-      stg[l].b = *reinterpret_cast<const f32x4*>(src + HW + off);
+      const int xg = item - __mul24(r, bw4);
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
+      stg[l].a = ld16(src, off);
+      stg[l].b = ld16(src + HW, off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -340,14 +371,14 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
           f32x2_t sv[2];
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1
-            const int idx = (tc.y0 - by0[l]) * bw[l] + (tc.x0 - bx0[l]);  // inside the box
+            const int idx = __mul24(tc.y0 - by0[l], bw[l]) + (tc.x0 - bx0[l]);  // inside the box
             const PairBlock pb = read_block(b0, idx, bw[l]);
 #pragma unroll
             for (int q = 0; q < 2; ++q) sv[q] = lerp2(pb.p00[q], pb.p01[q], pb.p10[q], pb.p11[q], tc.fx, tc.fy);
           } else {
             const BoxTaps t = make_box_taps(tc, H, W);
             // inside the box by construction; the clamp only matters for NaN coordinates
-            const int idx = min(max((t.yb - by0[l]) * bw[l] + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+            const int idx = min(max(__mul24(t.yb - by0[l], bw[l]) + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
             const PairBlock pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
             // delta padding (lvd.py:548,559): shift the corner values before their validity
             const f32x2_t d2 = {delta, delta};

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 17 ? 2 : 1))) void wa
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int K3rt, int frames_per_block,
-    int ntx, int ntiles, int nchunks, float delta) {
+    int ntx, int ntiles, int nchunks, int nbands, float delta) {
   const int L = EXL ? LP : Lrt;
   const int K3 = EXK ? K3P : K3rt;
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  int chunk, tile;  // frame chunk pinned to an XCD: the tiles of a frame share one L2
-  if (!xcd_decode(blockIdx.x, nchunks, ntiles, chunk, tile)) return;
+  int chunk, tile, rest_;  // (frame chunk, band of tiles) pinned to an XCD: neighbours share one L2
+  if (!xcd_decode_banded(blockIdx.x, nchunks, nbands, ntiles, 1, chunk, tile, rest_)) return;
   const PixelMap pm = pixel_of(tile, wave, lane, H, W, 4, ntx);
   const int64_t p = pm.p;
   float bas[K3P];
@@ -442,29 +442,34 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
   const TileGeom g = tile_geom(H, W, 4);
   const int fpb = chunk_frames(F, g.ntiles);
   const int nchunks = (F + fpb - 1) / fpb;
-  dim3 grid((unsigned)xcd_grid(nchunks, g.ntiles));
+  // fewer chunks than a multiple of the 8 XCDs (short batches): the tiles of a chunk are cut into
+  // bands so that every XCD gets work
+  const int nbands = xcd_bands(nchunks);
+  dim3 grid((unsigned)xcd_grid_banded(nchunks, nbands, g.ntiles, 1));
   if constexpr (EXK) {
     // LDS-staged sampling needs 16-byte-aligned rows and a 2x2 block inside the layer
     if (!debug_option(WALDO_DEBUG_FWD_PLAIN) && staged_eligible(H, W)) {
       const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
-      dim3 grid16((unsigned)xcd_grid(nchunks, nt16));
+      dim3 grid16((unsigned)xcd_grid_banded(nchunks, nbands, nt16, 1));
       if (L == LP)
         hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, true>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, delta);
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, nbands,
+                           delta);
       else
         hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, false>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, delta);
+                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, nbands,
+                           delta);
       return;
     }
   }
   if (L == LP)
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, true, EXK>), grid, dim3(kBlock), 0, st,
                        layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
-                       nchunks, delta);
+                       nchunks, nbands, delta);
   else
     hipLaunchKernelGGL((warp_composite_fwd_kernel<LP, K3P, false, EXK>), grid, dim3(kBlock), 0, st,
                        layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, fpb, g.ntx, g.ntiles,
-                       nchunks, delta);
+                       nchunks, nbands, delta);
 }
 
 template <int LP, int K3P>
@@ -481,6 +486,13 @@ static void launch_bwd(const float* layers, const float* basis_t, const float* m
 }
 
 // two-kernel backward; workspace = Bwd2Layout
+//
+// One pass over all frames: K1 -> reduce -> K2.  (Measured and dropped in round 2: passes of a few
+// frames over one small workspace, so that the records K1 writes are still in the 256 MiB Infinity
+// Cache when K2 reads them -- back to back the short launches lose more to ramp-up and drain than
+// the records cost, and with K2 of pass c on a side stream beside K1 of pass c + 1 the two kernels
+// only slow each other down; a timing-only build whose records never leave the cache bounds the
+// prize at 9 % of the backward.  DESIGN.md section 4.)
 template <int LP>
 static void launch_bwd2(const float* layers, const float* basis_t, const float* mapping,
                         const float* occ, const float* grad_rgb, const float* grad_alpha,
@@ -499,12 +511,15 @@ static void launch_bwd2(const float* layers, const float* basis_t, const float* 
   const int ntiles = lo.ntiles16;
   const int fpb = chunk_frames(F, ntiles);
   const int nchunks = (F + fpb - 1) / fpb;
-  dim3 grid((unsigned)xcd_grid(nchunks, ntiles));
+  // fewer chunks than a multiple of the 8 XCDs: the tiles of a chunk are cut into bands
+  const int nbands = xcd_bands(nchunks);
+  dim3 grid((unsigned)xcd_grid_banded(nchunks, nbands, ntiles, 1));
   auto go = [&](auto exl, auto gocc) {
     constexpr bool EXL = decltype(exl)::value, GOCC = decltype(gocc)::value;
     hipLaunchKernelGGL((warp_composite_bwd_px16_kernel<LP, EXL, GOCC>), grid, dim3(kBlock), 0, st, layers,
                        basis_t, mapping, occ, grad_rgb, grad_alpha, rec, boxes, bounds, part,
-                       grad_occ, F, L, H, W, fpb, lo.ntx16, ntiles, nchunks, lo.ncx, lo.ncells, delta);
+                       grad_occ, F, L, H, W, fpb, lo.ntx16, ntiles, nchunks, nbands, lo.ncx, lo.ncells,
+                       delta);
   };
   if (L == LP) {
     if (grad_occ != nullptr) go(T{}, T{}); else go(T{}, N{});

@@ -44,13 +44,19 @@ __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
   return make_int4(r.x, -r.y, r.z, -r.w);  // (x min, x max, y min, y max); empty: x min > x max
 }
 
-// LDS image of S: [channel][row][kPitch] int32.  kPitch = 80 = 16 (mod 32): the LDS serves a
-// wave-instruction as two 32-lane halves over 32 banks; a wave covers 4 pixel rows x 16 columns,
-// so with this pitch the two rows of a half land on disjoint bank ranges (pitch 64 is a 4-way
-// conflict).  Behind every channel plane, one dump word per lane takes the taps that fall outside
+// LDS image of S: [channel][row][kPitch] int32, kPitch = 64: the LDS serves a ds_add as two 32-lane
+// groups over 32 banks; a wave covers 4 pixel rows x 16 columns, so the two rows of a group share
+// banks (2-way) -- which costs a 4-byte store or add nothing extra on gfx950 (its address / data
+// transfer already takes as long as two array cycles) -- and at 34 KB per workgroup a CU holds
+// FOUR workgroups instead of the three that the conflict-free pitch 80 (43 KB) allowed: the
+// kernel waits on its dependent loads, not on the LDS (K2 -5.5 % at the headline shape).
+// Behind every channel plane, one dump word per lane takes the taps that fall outside
 // S (the same word offset in every plane, so a tap's four channel adds differ only in the
 // instruction's immediate offset).
-constexpr int kPitch = 80;
+#ifndef WALDO_K2_PITCH
+#define WALDO_K2_PITCH 64
+#endif
+constexpr int kPitch = WALDO_K2_PITCH;
 constexpr int kImgWords = kSrcRows * kPitch;           // image words per channel
 constexpr int kPlane = kImgWords + kWave;              // + the dump words
 constexpr int kDump = kImgWords;                       // + lane
@@ -66,25 +72,29 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
   const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
   const bool cx0 = (unsigned)lx0 < (unsigned)kSrcCols, cx1 = (unsigned)(lx0 + 1) < (unsigned)kSrcCols;
   const bool cy0 = on && (unsigned)ly0 < (unsigned)kSrcRows, cy1 = on && (unsigned)(ly0 + 1) < (unsigned)kSrcRows;
-  const int base = ly0 * kPitch + lx0;
-  const int dump = kDump + lane;
-  int* a00 = img + ((cx0 && cy0) ? base : dump);
-  int* a01 = img + ((cx1 && cy0) ? base + 1 : dump);
-  int* a10 = img + ((cx0 && cy1) ? base + kPitch : dump);
-  int* a11 = img + ((cx1 && cy1) ? base + kPitch + 1 : dump);
+  // byte offsets into the image (one shift for the four corners; 24-bit multiply: |ly0| is small)
+  const int base = (__mul24(ly0, kPitch) + lx0) * 4;
+  const int dump = (kDump + lane) * 4;
+  char* img8 = reinterpret_cast<char*>(img);
+  int* a00 = reinterpret_cast<int*>(img8 + ((cx0 && cy0) ? base : dump));
+  int* a01 = reinterpret_cast<int*>(img8 + ((cx1 && cy0) ? base + 4 : dump));
+  int* a10 = reinterpret_cast<int*>(img8 + ((cx0 && cy1) ? base + 4 * kPitch : dump));
+  int* a11 = reinterpret_cast<int*>(img8 + ((cx1 && cy1) ? base + 4 * kPitch + 4 : dump));
+  // the sixteen products on the packed-fp32 pipe, two per instruction: (g w00, g w01), (g w10, g w11)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const float as = rec.x * scale_rgb;
-  float gv[4];
-  gv[0] = as * g0;
-  gv[1] = as * g1;
-  gv[2] = as * g2;
-  gv[3] = rec.y * scale_a;
+  const f32x2 wt = {t.w00, t.w01}, wb = {t.w10, t.w11};
+  const f32x2 g01 = (f32x2){as, as} * (f32x2){g0, g1};
+  const f32x2 g23 = {as * g2, rec.y * scale_a};
+  const float gv[4] = {g01[0], g01[1], g23[0], g23[1]};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float gs = gv[c];
-    atomicAdd(a00 + c * kPlane, cvt_round(gs * t.w00));
-    atomicAdd(a01 + c * kPlane, cvt_round(gs * t.w01));
-    atomicAdd(a10 + c * kPlane, cvt_round(gs * t.w10));
-    atomicAdd(a11 + c * kPlane, cvt_round(gs * t.w11));
+    const f32x2 gs = {gv[c], gv[c]};
+    const f32x2 pt = gs * wt, pb = gs * wb;
+    atomicAdd(a00 + c * kPlane, cvt_round(pt[0]));
+    atomicAdd(a01 + c * kPlane, cvt_round(pt[1]));
+    atomicAdd(a10 + c * kPlane, cvt_round(pb[0]));
+    atomicAdd(a11 + c * kPlane, cvt_round(pb[1]));
   }
 }
 
@@ -97,8 +107,8 @@ __device__ __forceinline__ bool touches(const TapCore& t, int sx0, int sy0) {
 __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     const float4* __restrict__ rec, const float* __restrict__ grad_rgb,
     const int* __restrict__ cellbox, const unsigned* __restrict__ cellbound,
-    float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int ncx,
-    int ncells) {
+    float* __restrict__ grad_layers, int F, int L, int H, int W, int nsx, int nstiles, int nbands,
+    int ncx, int ncells) {
   const int64_t HW = (int64_t)H * W;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   // a FRAME is pinned to one XCD, source-tile-major inside it: the L layer planes of one source
@@ -106,11 +116,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   // frame, so its grad_rgb is read once from HBM instead of once per layer (it was 40 % of this
   // kernel's FETCH_SIZE with layer-major order); the records of a plane are still read ~1.8
   // times by neighbouring tiles, from L2.
-  int fi, rest;
-  if (!xcd_decode(blockIdx.x, F, L * nstiles, fi, rest)) return;
+  int fi, stile, layer;
+  if (!xcd_decode_banded(blockIdx.x, F, nbands, nstiles, L, fi, stile, layer)) return;
   const int64_t f = fi;
-  const int64_t fl = f * L + rest % L;
-  const int stile = rest / L;
+  const int64_t fl = f * L + layer;
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   // cannot be represented -- the tile becomes NaN, as loud as the reference's gradient would be
   const bool poison = !(bsum_rgb < __builtin_huge_valf()) || !(bsum_a < __builtin_huge_valf());
   const float* gplane = grad_rgb + f * 3 * HW;
-  const float4* rcp = rec + fl * HW;
+  const float4* rcp = rec + ((int64_t)WALDO_REC_FRAME(f) * L + layer) * HW;
 
   if ((bsum_rgb > 0.0f || bsum_a > 0.0f) && !poison) {
     if (nhit <= kMaxHit) {
@@ -342,10 +351,11 @@ void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
                   hipStream_t st) {
   const int nsx = (W + kSrcCols - 1) / kSrcCols, nsy = (H + kSrcRows - 1) / kSrcRows;
   const int ncx = (W + kCellCols - 1) / kCellCols, ncy = (H + kCellRows - 1) / kCellRows;
-  dim3 grid((unsigned)xcd_grid(F, (int64_t)L * nsx * nsy));
+  const int nbands = xcd_bands(F);
+  dim3 grid((unsigned)xcd_grid_banded(F, nbands, nsx * nsy, L));
   hipLaunchKernelGGL(warp_composite_splat_kernel, grid, dim3(kG2Threads), 0, st,
                      reinterpret_cast<const float4*>(rec),
-                     grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, ncx,
+                     grad_rgb, cellbox, cellbound, grad_layers, F, L, H, W, nsx, nsx * nsy, nbands, ncx,
                      ncx * ncy);
 }
 
