@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
   //   stage  per frame, in turn: the transposition slices of the grid, the staged layer image (two
   //          buffers), the transposed basis of phase (H) -- and, without parking, gg in front of it;
   //   boxred coordinate ranges per wave; wbound contribution-bound exponents per wave.
-  __shared__ __attribute__((aligned(16))) float lds[C::kLdsFloats];
+#ifndef WALDO_ABL_K1_LDS_PAD  // timing-only ablation: extra LDS floats per workgroup (occupancy sweep)
+#define WALDO_ABL_K1_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) float lds[C::kLdsFloats + WALDO_ABL_K1_LDS_PAD];
   float* park = lds;
   float* img = lds + C::kParkFloats;
   float* gg = kPark ? park : img;
@@ -281,29 +284,30 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     float a[LP], G[LP];
     float dxr[kPark ? 1 : LP], dxa[kPark ? 1 : LP], dyr[kPark ? 1 : LP], dya[kPark ? 1 : LP];
 
-    // ---- (E) staged sampling with derivatives.  Waves 2q / 2q + 1 move the two halves of channel
-    // pair q of a layer's box, 16 bytes per lane and plane, interleaved as float2 texels (see
-    // warp_composite_fwd_lds_kernel); a rolling window of kAhead layers is in flight (the load of
-    // layer l + kAhead is issued when layer l leaves its registers for LDS); the image is
-    // double-buffered, one barrier per layer.
+    // ---- (E) staged sampling with derivatives.  Every lane moves one item (two texels, four
+    // planes) of a layer's box into the float4-texel LDS image (see warp_composite_fwd_lds_kernel);
+    // a rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
+    // layer l leaves its registers for LDS); the image is double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
-    const int pairq = wave >> 1, item_l = lane + (wave & 1) * kWave;
+    const int item_l = threadIdx.x;
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + (((int64_t)f * L + lc) * 4 + 2 * pairq) * HW;
+      const float* src = layers + ((int64_t)f * L + lc) * 4 * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
-      const int bw4 = bw[l] >> 2, n = fits[l] ? bh[l] * bw4 : 1;
+      const int bw2 = bw[l] >> 1, n = fits[l] ? bh[l] * bw2 : 1;
       const int ox = fits[l] ? __mul24(by0[l], W) + bx0[l] : 0;
-      // item, bw4 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
-      const float rcp = __builtin_amdgcn_rcpf((float)bw4);
+      // item, bw2 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
+      const float rcp = __builtin_amdgcn_rcpf((float)bw2);
       const int item = min(item_l, n - 1);
       const int r = (int)(((float)item + 0.5f) * rcp);
-      const int xg = item - __mul24(r, bw4);
-      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
-      stg[l].a = ld16(src, off);
-      stg[l].b = ld16(src + HW, off);
+      const int xh = item - __mul24(r, bw2);
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 2 * xh) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
+      stg[l].c0 = ld8(src, off);
+      stg[l].c1 = ld8(src + HW, off);
+      stg[l].c2 = ld8(src + 2 * HW, off);
+      stg[l].c3 = ld8(src + 3 * HW, off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -323,9 +327,9 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           continue;
         }
         if (fits[l]) {
-          const int n = bh[l] * (bw[l] >> 2);
-          if (item_l < n)  // row-major with pitch bw: item = r * bw4 + xg
-            stage_store(img + (l & 1) * kImgBufFloats + pairq * kPairFloats, item_l, stg[l]);
+          const int n = bh[l] * (bw[l] >> 1);
+          if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
+            stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone

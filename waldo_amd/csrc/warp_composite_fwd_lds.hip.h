@@ -76,22 +76,19 @@ __device__ __forceinline__ int block_origin(float i, int size) {  // i: pixel un
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// ---- staged image of one layer's footprint box: two pair planes of float2 texels, row-major with
-// pitch bw; pair q starts kPairFloats further.  Item = four consecutive texels of a row.
-constexpr int kPairFloats = 2 * kStageCap;      // one pair plane: kStageCap texels x 2 channels
-constexpr int kImgBufFloats = 2 * kPairFloats;  // one layer image
+// ---- staged image of one layer's footprint box: float4 texels (all four channels of a texel in
+// 16 bytes), row-major with pitch bw.  A tap is ONE 16-byte LDS read (ds_read_b128: 4 LDS cycles
+// per wave, against 8 for the ds_read2_b64 of a two-channel image) that arrives as two packed-fp32
+// operands.  Staging item = two consecutive texels of a row: a lane loads them from the four
+// channel planes (8 bytes each), transposes with four v_pk_mov and writes two texels.
+constexpr int kImgBufFloats = 4 * kStageCap;  // one layer image
 
-// the lane's staging loads of layer `src` (channel plane 2q, then 2q + 1) for box item `item`
 struct StageRegs {
-  f32x4_t a, b;
+  f32x2_t c0, c1, c2, c3;  // texels (t, t + 1) of the four channel planes
 };
 
-#ifndef WALDO_STAGE_PKMOV
-#define WALDO_STAGE_PKMOV 1
-#endif
 // (a.lo, b.lo) and (a.hi, b.hi) of two register pairs: v_pk_mov_b32 takes its low result from
-// src0[op_sel[0]] and its high result from src1[op_sel[1]] -- the interleave of four texels of two
-// planes costs four instructions instead of seven moves (hipcc 7.2 does not form them by itself)
+// src0[op_sel[0]] and its high result from src1[op_sel[1]] (hipcc 7.2 does not form it by itself)
 __device__ __forceinline__ f32x2_t pk_lo(f32x2_t a, f32x2_t b) {
   f32x2_t d;
   asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
@@ -103,40 +100,35 @@ __device__ __forceinline__ f32x2_t pk_hi(f32x2_t a, f32x2_t b) {
   return d;
 }
 
-__device__ __forceinline__ void stage_store(float* pairplane, int item, const StageRegs& r) {
-  f32x4_t* dst = reinterpret_cast<f32x4_t*>(pairplane + 8 * item);
-#if WALDO_STAGE_PKMOV
-  const f32x2_t a01 = __builtin_shufflevector(r.a, r.a, 0, 1), a23 = __builtin_shufflevector(r.a, r.a, 2, 3);
-  const f32x2_t b01 = __builtin_shufflevector(r.b, r.b, 0, 1), b23 = __builtin_shufflevector(r.b, r.b, 2, 3);
-  dst[0] = __builtin_shufflevector(pk_lo(a01, b01), pk_hi(a01, b01), 0, 1, 2, 3);
-  dst[1] = __builtin_shufflevector(pk_lo(a23, b23), pk_hi(a23, b23), 0, 1, 2, 3);
-#else
-  dst[0] = (f32x4_t){r.a[0], r.b[0], r.a[1], r.b[1]};
-  dst[1] = (f32x4_t){r.a[2], r.b[2], r.a[3], r.b[3]};
-#endif
+__device__ __forceinline__ void stage_store(float* imgbuf, int item, const StageRegs& r) {
+  f32x4_t* dst = reinterpret_cast<f32x4_t*>(imgbuf + 8 * item);
+  dst[0] = __builtin_shufflevector(pk_lo(r.c0, r.c1), pk_lo(r.c2, r.c3), 0, 1, 2, 3);
+  dst[1] = __builtin_shufflevector(pk_hi(r.c0, r.c1), pk_hi(r.c2, r.c3), 0, 1, 2, 3);
 }
 
-// 16 bytes at a 32-bit byte offset from a wave-uniform base (scalar base + VGPR offset addressing)
-__device__ __forceinline__ f32x4_t ld16(const float* __restrict__ base, uint32_t byte_off) {
-  return *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const char*>(base) + byte_off);
+// 8 bytes at a 32-bit byte offset from a wave-uniform base (scalar base + VGPR offset addressing)
+__device__ __forceinline__ f32x2_t ld8(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// the four taps of both channel pairs at texel index idx (row-major, pitch bw) of a layer image
+// the four taps at texel index idx (row-major, pitch bw) of a layer image, as channel pairs
 struct PairBlock {
-  f32x2_t p00[2], p01[2], p10[2], p11[2];  // [pair]
+  f32x2_t p00[2], p01[2], p10[2], p11[2];  // [pair]: channels (0, 1) and (2, 3)
 };
 
 __device__ __forceinline__ PairBlock read_block(const float* imgbuf, int idx, int bw) {
+  const f32x4_t* r0 = reinterpret_cast<const f32x4_t*>(imgbuf + 4 * idx);
+  const f32x4_t* r1 = r0 + bw;
+  const f32x4_t t00 = r0[0], t01 = r0[1], t10 = r1[0], t11 = r1[1];
   PairBlock b;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const f32x2_t* r0 = reinterpret_cast<const f32x2_t*>(imgbuf + q * kPairFloats + 2 * idx);
-    const f32x2_t* r1 = r0 + bw;
-    b.p00[q] = r0[0];
-    b.p01[q] = r0[1];
-    b.p10[q] = r1[0];
-    b.p11[q] = r1[1];
-  }
+  b.p00[0] = __builtin_shufflevector(t00, t00, 0, 1);
+  b.p00[1] = __builtin_shufflevector(t00, t00, 2, 3);
+  b.p01[0] = __builtin_shufflevector(t01, t01, 0, 1);
+  b.p01[1] = __builtin_shufflevector(t01, t01, 2, 3);
+  b.p10[0] = __builtin_shufflevector(t10, t10, 0, 1);
+  b.p10[1] = __builtin_shufflevector(t10, t10, 2, 3);
+  b.p11[0] = __builtin_shufflevector(t11, t11, 0, 1);
+  b.p11[1] = __builtin_shufflevector(t11, t11, 2, 3);
   return b;
 }
 
@@ -320,32 +312,33 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
 #endif
     }
 
-    // ---- (E) staging: waves 2q / 2q + 1 move the two halves of channel pair q of a layer's box,
-    // 16 bytes per lane and plane.  A rolling window of kAhead layers is in flight (the load of
-    // layer l + kAhead is issued when layer l leaves its registers for LDS): memory latency is
-    // exposed once per frame; then each layer goes registers -> LDS -> taps; the image is
-    // double-buffered, one barrier per layer.
+    // ---- (E) staging: every lane moves one item (two texels, four planes) of a layer's box.  A
+    // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
+    // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
+    // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
-    static_assert(kStageCap / 4 == 2 * kWave, "one box item per lane of a wave pair");
-    const int pairq = wave >> 1, item_l = lane + (wave & 1) * kWave;
+    static_assert(kStageCap / 2 == kBlock, "one box item per lane");
+    const int item_l = threadIdx.x;
     float s[LP][4];
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + (((int64_t)f * L + lc) * 4 + 2 * pairq) * HW;
+      const float* src = layers + ((int64_t)f * L + lc) * 4 * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
       const bool fits = bh[l] * bw[l] <= kStageCap;
-      const int bw4 = bw[l] >> 2, n = fits ? bh[l] * bw4 : 1;
+      const int bw2 = bw[l] >> 1, n = fits ? bh[l] * bw2 : 1;
       const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
-      // item, bw4 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
-      const float rcp = __builtin_amdgcn_rcpf((float)bw4);
+      // item, bw2 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
+      const float rcp = __builtin_amdgcn_rcpf((float)bw2);
       const int item = min(item_l, n - 1);
       const int r = (int)(((float)item + 0.5f) * rcp);
-      const int xg = item - __mul24(r, bw4);
-      const unsigned off = (unsigned)(ox + __mul24(r, W) + 4 * xg) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
-      stg[l].a = ld16(src, off);
-      stg[l].b = ld16(src + HW, off);
+      const int xh = item - __mul24(r, bw2);
+      const unsigned off = (unsigned)(ox + __mul24(r, W) + 2 * xh) * 4u;  // bytes; HW * 4 < 2^32 (launcher)
+      stg[l].c0 = ld8(src, off);
+      stg[l].c1 = ld8(src + HW, off);
+      stg[l].c2 = ld8(src + 2 * HW, off);
+      stg[l].c3 = ld8(src + 3 * HW, off);
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
@@ -359,9 +352,9 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
         }
         const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
         if (fits) {
-          const int n = bh[l] * (bw[l] >> 2);
-          if (item_l < n)  // row-major with pitch bw: item = r * bw4 + xg
-            stage_store(img + (l & 1) * kImgBufFloats + pairq * kPairFloats, item_l, stg[l]);
+          const int n = bh[l] * (bw[l] >> 1);
+          if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
+            stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone

@@ -39,9 +39,12 @@ constexpr int kG2Threads = kG2Waves * kWave;          // 512
 constexpr int kMaxHit = 192 * 8 / kCellRows;         // cells listed per tile (else: slow scan)
 constexpr int kScanPer = 2;                           // cells per thread and trip of the table scan
 
+// ONE 16-byte load (a native vector: hipcc splits a HIP int4 struct into two 8-byte loads and sinks
+// the second behind the short-circuit test of the first -- two dependent round trips per cell)
 __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
-  const int4 r = reinterpret_cast<const int4*>(cellbox)[idx];
-  return make_int4(r.x, -r.y, r.z, -r.w);  // (x min, x max, y min, y max); empty: x min > x max
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 r = reinterpret_cast<const i32x4*>(cellbox)[idx];
+  return make_int4(r[0], -r[1], r[2], -r[3]);  // (x min, x max, y min, y max); empty: x min > x max
 }
 
 // LDS image of S: [channel][row][kPitch] int32, kPitch = 64: the LDS serves a ds_add as two 32-lane
@@ -53,6 +56,9 @@ __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
 // Behind every channel plane, one dump word per lane takes the taps that fall outside
 // S (the same word offset in every plane, so a tap's four channel adds differ only in the
 // instruction's immediate offset).
+#ifndef WALDO_K2_RING
+#define WALDO_K2_RING 2
+#endif
 #ifndef WALDO_K2_PITCH
 #define WALDO_K2_PITCH 64
 #endif
@@ -135,8 +141,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
   }
 
-  auto reaches = [&](const int4 ob) {
-    return ob.x <= ob.y && ob.x <= sx1 && ob.y >= sx0 && ob.z <= sy1 && ob.w >= sy0;
+  auto reaches = [&](const int4 ob) {  // bitwise: no short-circuit branches between the comparisons
+    return (bool)((ob.x <= ob.y) & (ob.x <= sx1) & (ob.y >= sx0) & (ob.z <= sy1) & (ob.w >= sy0));
   };
   // ---- cells whose box reaches S, listed in cell order, and the sums of their contribution
   // bounds (fixed butterfly, fixed wave order: deterministic).  kScanPer cells per thread and
@@ -148,11 +154,22 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   for (int c0 = 0; c0 < ncells; c0 += kScanPer * kG2Threads) {
     bool hit[kScanPer];
     unsigned eb[kScanPer];
+    int4 box[kScanPer];
+    // every load of the trip is issued before the first test (unconditional: the index is clamped);
+    // the empty asm pins the bounds' loads here -- left alone hipcc sinks them behind the box test,
+    // one more dependent round trip per trip
 #pragma unroll
     for (int u = 0; u < kScanPer; ++u) {
-      const int c = min(c0 + u * kG2Threads + (int)threadIdx.x, ncells - 1);  // unconditional loads
-      hit[u] = c0 + u * kG2Threads + (int)threadIdx.x < ncells && reaches(load_box(cellbox, fl * ncells + c));
-      eb[u] = hit[u] ? cellbound[fl * ncells + c] : 0u;
+      const int c = min(c0 + u * kG2Threads + (int)threadIdx.x, ncells - 1);
+      box[u] = load_box(cellbox, fl * ncells + c);
+      eb[u] = cellbound[fl * ncells + c];
+    }
+#pragma unroll
+    for (int u = 0; u < kScanPer; ++u) asm volatile("" : "+v"(eb[u]));
+#pragma unroll
+    for (int u = 0; u < kScanPer; ++u) {
+      hit[u] = (bool)((c0 + u * kG2Threads + (int)threadIdx.x < ncells) & reaches(box[u]));
+      eb[u] = hit[u] ? eb[u] : 0u;
     }
     float brgb = 0.0f, ba = 0.0f;
     int cnt[kScanPer];
@@ -167,11 +184,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       if (lane == 0) wcount[u * kG2Waves + wave] = cnt[u];
       cnt[u] = __popcll(m & ((1ull << lane) - 1ull));  // hits of this wave before this lane
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      brgb += __shfl_xor(brgb, d, kWave);
-      ba += __shfl_xor(ba, d, kWave);
-    }
+    brgb = wave_sum(brgb);  // DPP row steps + permlane swaps; same order in every lane: deterministic
+    ba = wave_sum(ba);
     if (lane == 0) {
       wbound[2 * wave] = brgb;
       wbound[2 * wave + 1] = ba;
@@ -272,16 +286,22 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
                       scale_rgb, scale_a, sx0, sy0);
         }
       };
-      Cand ka, kb;
+      // ring of kRing candidates per thread in flight: slot d is consumed, then refilled with the
+      // candidate kRing trips ahead (fetch() clamps past the end: harmless, masked by livep)
+      constexpr int kRing = WALDO_K2_RING;
+      Cand k[kRing];
       int i = threadIdx.x;
-      if (i < total) fetch(i, ka);
+#pragma unroll
+      for (int d = 0; d < kRing; ++d) fetch(i + d * kG2Threads, k[d]);
       while (i < total) {  // uniform per wave: total is a multiple of 128, the stride of 512
-        fetch(i + kG2Threads, kb);
-        splat(ka);
-        if (i + kG2Threads >= total) break;
-        fetch(i + 2 * kG2Threads, ka);
-        splat(kb);
-        i += 2 * kG2Threads;
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) {
+          if (i + d * kG2Threads < total) {  // wave-uniform
+            splat(k[d]);
+            fetch(i + (d + kRing) * kG2Threads, k[d]);
+          }
+        }
+        i += kRing * kG2Threads;
       }
     } else {
       // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
