@@ -638,6 +638,34 @@ def test_long_batches_go_in_pieces(dev, monkeypatch):
     assert 1 <= WF._frames_per_call(f, nl, h, w, 19) <= 3
 
 
+@pytest.mark.parametrize("f,nl", [(2, 8), (6, 5), (12, 4)])
+def test_short_batches_use_every_xcd_and_change_no_bit(dev, f, nl):
+    """Batches whose frame-chunk count is not a multiple of the 8 XCDs cut every frame's tiles into
+    bands (waldo_common.hip.h:xcd_decode_banded; 4 / 4 / 2 bands here); frames are independent, so
+    the batch must equal its frames computed one call at a time (8 bands each), bit for bit --
+    forward, layer gradients (two-kernel backward) and control-point gradients."""
+    from waldo_amd import functional as WF
+    import waldo_amd
+    h, w = 96, 160
+    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=21)
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+    torch.manual_seed(4)
+    wgt = torch.randn(f, 3, h, w, device=dev)
+
+    def run(sl):
+        ld = layers[sl].to(dev).requires_grad_()
+        pd = pts.view(f, nl, 16, 2)[sl].reshape(-1, 16, 2).to(dev).requires_grad_()
+        rgb = WF.warp_composite(ld, pd, occ[sl].to(dev), tps.inverse_kernel, tps.basis_t)
+        (rgb * wgt[sl]).sum().backward()
+        return rgb.detach(), ld.grad, pd.grad.view(-1, nl, 16, 2)
+
+    whole = run(slice(0, f))
+    for i in range(f):
+        one = run(slice(i, i + 1))
+        for a, b in zip(whole, one):
+            assert torch.equal(a[i:i + 1], b), i
+
+
 def test_graphed_forward_replay(dev):
     """A captured HIP graph of the fused forward replays bit-identically on new input contents
     (the library launches on the capturing stream and never synchronises)."""

@@ -332,6 +332,11 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
+        // the incoming alpha gradient of this layer travels with the staging loads (loaded where it
+        // is used, the wave would wait for it with vmcnt(0) -- and with it for every box load in
+        // flight)
+        float gal = 0.0f;
+        if (grad_alpha != nullptr) gal = grad_alpha[((int64_t)f * L + l) * HW + p];
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (l < 8) WALDO_STAMP(3 + l);
         const TapCore tc = tap_core_px(gxs[l], gys[l], H, W);
@@ -403,8 +408,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           dyr[l] = vyr;
           dya[l] = sy[3];
         }
-        if (grad_alpha != nullptr)
-          G[l] = fmaf(2.0f * livef, grad_alpha[((int64_t)f * L + l) * HW + p], G[l]);
+        G[l] = fmaf(2.0f * livef, gal, G[l]);
       }
     }
 

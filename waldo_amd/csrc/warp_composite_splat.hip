@@ -135,11 +135,6 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   int* wcount = hitlist + kMaxHit;                      // [cell of the trip][wave]: hits
   float* wbound = reinterpret_cast<float*>(wcount + kScanPer * kG2Waves);  // [wave][rgb, alpha]
 
-  {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    static_assert((4 * kPlane) % 4 == 0, "16-byte zero fill");
-    for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
-  }
 
   auto reaches = [&](const int4 ob) {  // bitwise: no short-circuit branches between the comparisons
     return (bool)((ob.x <= ob.y) & (ob.x <= sx1) & (ob.y >= sx0) & (ob.z <= sy1) & (ob.w >= sy0));
@@ -163,6 +158,11 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const int c = min(c0 + u * kG2Threads + (int)threadIdx.x, ncells - 1);
       box[u] = load_box(cellbox, fl * ncells + c);
       eb[u] = cellbound[fl * ncells + c];
+    }
+    if (c0 == 0) {  // the image is cleared while the first trip's loads are in flight
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      static_assert((4 * kPlane) % 4 == 0, "16-byte zero fill");
+      for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
     }
 #pragma unroll
     for (int u = 0; u < kScanPer; ++u) asm volatile("" : "+v"(eb[u]));
@@ -286,23 +286,27 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
                       scale_rgb, scale_a, sx0, sy0);
         }
       };
-      // ring of kRing candidates per thread in flight: slot d is consumed, then refilled with the
-      // candidate kRing trips ahead (fetch() clamps past the end: harmless, masked by livep)
+      // ring of kRing candidates per thread in flight (2: with 3 / 4 the backward is 1 % / 1.7 %
+      // slower): slot d is consumed, then refilled with the
+      // candidate kRing trips ahead (fetch() clamps past the end: harmless, masked by livep).  The
+      // steady-state loop has no branch between a splat and the next fetch (a join makes hipcc wait
+      // for every outstanding load); the last, partial round is peeled.
       constexpr int kRing = WALDO_K2_RING;
       Cand k[kRing];
       int i = threadIdx.x;
 #pragma unroll
       for (int d = 0; d < kRing; ++d) fetch(i + d * kG2Threads, k[d]);
-      while (i < total) {  // uniform per wave: total is a multiple of 128, the stride of 512
+      while (i + (kRing - 1) * kG2Threads < total) {  // uniform per wave: total is a multiple of 128
 #pragma unroll
         for (int d = 0; d < kRing; ++d) {
-          if (i + d * kG2Threads < total) {  // wave-uniform
-            splat(k[d]);
-            fetch(i + (d + kRing) * kG2Threads, k[d]);
-          }
+          splat(k[d]);
+          fetch(i + (d + kRing) * kG2Threads, k[d]);
         }
         i += kRing * kG2Threads;
       }
+#pragma unroll
+      for (int d = 0; d < kRing - 1; ++d)
+        if (i + d * kG2Threads < total) splat(k[d]);
     } else {
       // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
       for (int c = 0; c < ncells; ++c) {
