@@ -9,7 +9,10 @@ namespace waldo {
 
 constexpr int kGmapK3 = 19;
 constexpr int kTileW = 64;                     // pixel tiles of the plain kernels: rows x 64
-constexpr int kCellRows = 8, kCellCols = 16;   // cell of the footprint table (measured: K2 1.11 /
+#ifndef WALDO_CELL_ROWS
+#define WALDO_CELL_ROWS 8
+#endif
+constexpr int kCellRows = WALDO_CELL_ROWS, kCellCols = 16;   // cell of the footprint table (measured: K2 1.11 /
                                                // 1.01 / 1.04 ms for 4 / 8 / 16 rows)
 constexpr int kBwd2MaxLayers = 17;             // largest L the two-kernel backward is compiled for
 constexpr int kLdsTile = 16;                   // LDS-staged kernels: 16 x 16 pixels per workgroup
