@@ -301,7 +301,17 @@ int waldo_lyt_dist_bwd(const float* grad_dist, const float* alpha, const float* 
 int waldo_warp_composite_fwd(const float* layers, const float* basis_t, const float* mapping,
                              const float* occ, float* rgb, float* alpha, int64_t F, int L, int H,
                              int W, int K3, float delta, waldo_stream_t stream);
-/* Backward of the above.
+/* The same forward from the control points: mapping = inverse_kernel (N+3,N+3) @ [src_pts (F*L,N,2); 0]
+ * (A2, warp.py:52-53) is computed inside the kernel (same fma order as waldo_tps_mapping_fwd: the
+ * outputs have the same bits as waldo_tps_mapping_fwd + waldo_warp_composite_fwd), so a forward-only
+ * call is ONE launch.  Served shapes: waldo_warp_composite_pts_supported() != 0 (N = 16, 4 | W);
+ * otherwise EINVAL -- call the two-step path. */
+int waldo_warp_composite_pts_supported(int L, int H, int W, int N);
+int waldo_warp_composite_pts_fwd(const float* layers, const float* basis_t,
+                                 const float* inverse_kernel, const float* src_pts,
+                                 const float* occ, float* rgb, float* alpha, int64_t F, int L,
+                                 int H, int W, int N, float delta, waldo_stream_t stream);
+/* Backward of waldo_warp_composite_fwd.
  *   grad_rgb (F,3,H,W); grad_alpha (F,L,H,W) or NULL;
  *   workspace: scratch of at least waldo_warp_composite_bwd_workspace_bytes() bytes (256-byte
  *       aligned, contents irrelevant).  Non-NULL selects the two-kernel path (K3 == 19, L <= 17,

@@ -666,6 +666,29 @@ def test_short_batches_use_every_xcd_and_change_no_bit(dev, f, nl):
             assert torch.equal(a[i:i + 1], b), i
 
 
+@pytest.mark.parametrize("f,nl,h,w,delta", [(8, 8, 128, 128, 0.0), (3, 5, 40, 72, 1.0), (1, 12, 64, 96, 0.0),
+                                            (5, 17, 32, 64, 0.5)])
+def test_forward_from_control_points_is_one_launch_and_the_same_bits(dev, f, nl, h, w, delta):
+    """Without autograd the forward goes straight from the control points
+    (waldo_warp_composite_pts_fwd: the TPS mapping of warp.py:52-53 computed inside the kernel, a
+    frame ahead); rgb and the composited alphas must carry the same bits as tps_mapping + the
+    two-step forward that runs under autograd."""
+    from waldo_amd import functional as WF
+    import waldo_amd
+    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=31)
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+    ld, pd, od = layers.to(dev), pts.to(dev), occ.to(dev)
+    assert WF._lib.load().waldo_warp_composite_pts_supported(nl, h, w, 16)
+    with torch.no_grad():
+        rgb1, a1 = WF.warp_composite(ld, pd, od, tps.inverse_kernel, tps.basis_t, return_alpha=True, delta=delta)
+    rgb2, a2 = WF.warp_composite(ld, pd.clone().requires_grad_(), od, tps.inverse_kernel, tps.basis_t,
+                                 return_alpha=True, delta=delta)
+    assert torch.equal(rgb1, rgb2.detach()) and torch.equal(a1, a2.detach())
+    ref, ref_a = O.warp_composite(layers, pts, occ, tps.inverse_kernel.cpu(), tps.tgt_grid_repr.cpu(), delta=delta)
+    close(rgb1, ref, tol=2e-4, what="rgb (control-point forward)")
+    close(a1, ref_a, tol=2e-4, what="alpha (control-point forward)")
+
+
 def test_graphed_forward_replay(dev):
     """A captured HIP graph of the fused forward replays bit-identically on new input contents
     (the library launches on the capturing stream and never synchronises)."""

@@ -54,12 +54,15 @@ SIGNATURES = {
                            _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
                                  _flt, _stream],
+    "waldo_warp_composite_pts_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
+                                     _flt, _stream],
     "waldo_warp_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64,
                                  _i64, _int, _int, _int, _int, _flt, _stream],
 }
 PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
          "waldo_warp_composite_bwd_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int]),
          "waldo_lyt_dist_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
+         "waldo_warp_composite_pts_supported": (_int, [_int, _int, _int, _int]),
          "waldo_last_error_string": (ctypes.c_char_p, []),
          "waldo_set_debug_option": (_int, [_int, _int])}
 

@@ -10,8 +10,9 @@ constexpr int kMaxK3 = 32;
 
 #define WALDO_DECL_LP(LPV)                                                                      \
   void wc_fwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
-                      const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,   \
-                      int K3, float delta, hipStream_t st);                                     \
+                      const float* inv_kernel, const float* src_pts, const float* occ,          \
+                      float* rgb, float* alpha, int F, int L, int H, int W, int K3, float delta, \
+                      hipStream_t st);                                                          \
   void wc_bwd_lp##LPV(bool k19, const float* layers, const float* basis_t, const float* mapping, \
                       const float* occ, const float* grad_rgb, const float* grad_alpha,         \
                       float* grad_layers, float* grad_mapping, float* grad_occ,                 \
@@ -73,9 +74,38 @@ extern "C" int waldo_warp_composite_fwd(const float* layers, const float* basis_
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  WALDO_CALL_LP(wc_fwd_lp, K3 == 19, layers, basis_t, mapping, occ, rgb, alpha, (int)F, L, H, W,
-                K3, delta, st);
+  WALDO_CALL_LP(wc_fwd_lp, K3 == 19, layers, basis_t, mapping, nullptr, nullptr, occ, rgb, alpha, (int)F,
+                L, H, W, K3, delta, st);
   return launch_status("waldo_warp_composite_fwd");
+}
+
+extern "C" int waldo_warp_composite_pts_supported(int L, int H, int W, int N) {
+  return N + 3 == kGmapK3 && L >= 1 && L <= kMaxLayers && H >= 1 && W >= 1 && staged_eligible(H, W) &&
+         (int64_t)H * W * kGmapK3 * 4 < 4294967296ll && !debug_option(WALDO_DEBUG_FWD_PLAIN);
+}
+
+extern "C" int waldo_warp_composite_pts_fwd(const float* layers, const float* basis_t,
+                                            const float* inverse_kernel, const float* src_pts,
+                                            const float* occ, float* rgb, float* alpha, int64_t F,
+                                            int L, int H, int W, int N, float delta,
+                                            waldo_stream_t stream) {
+  int rc = check_common("waldo_warp_composite_pts_fwd", F, L, H, W, N + 3);
+  if (rc) return rc;
+  if (!waldo_warp_composite_pts_supported(L, H, W, N)) {
+    set_error("waldo_warp_composite_pts_fwd: shape not served (N=%d H=%d W=%d); use waldo_tps_mapping_fwd + "
+              "waldo_warp_composite_fwd", N, H, W);
+    return WALDO_EINVAL;
+  }
+  if (F == 0) return WALDO_OK;
+  if (!layers || !basis_t || !inverse_kernel || !src_pts || !occ || !rgb) {
+    set_error("waldo_warp_composite_pts_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int K3 = N + 3;
+  WALDO_CALL_LP(wc_fwd_lp, true, layers, basis_t, nullptr, inverse_kernel, src_pts, occ, rgb, alpha, (int)F, L,
+                H, W, K3, delta, st);
+  return launch_status("waldo_warp_composite_pts_fwd");
 }
 
 extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_t,

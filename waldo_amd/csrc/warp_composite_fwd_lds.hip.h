@@ -162,10 +162,16 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // At least 2 waves per SIMD (<= 256 VGPRs) for every LP: with 1 (LP >= 24 wants ~310 registers)
 // hipcc 7.2 parks MFMA accumulator components in AGPRs and reads some of them back wrong
 // (tools_dev/dbg_fwd.py: columns 4k of tile rows 0 and 3, layers 8..15); spilling is correct.
-template <int LP, bool EXL>
+// FOLD: `mapping` is not read; the workgroup computes the TPS mapping of its frame's layers itself,
+// mapping = inverse_kernel (19 x 19) @ [src_pts (16 x 2); 0] (warp.py:52-53), with the fma order of
+// tps_mapping_fwd_kernel (bit-identical values), one frame ahead, into an LDS table -- the
+// forward-only path then is ONE kernel (at 8 frames of 128 x 128 the separate mapping kernel and
+// its launch gap were a quarter of the call).
+template <int LP, bool EXL, bool FOLD>
 __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
-    const float* __restrict__ mapping, const float* __restrict__ occ, float* __restrict__ rgb,
+    const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
+    const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
     float* __restrict__ alpha_out, int F, int Lrt, int H, int W, int frames_per_block, int ntx,
     int ntiles, int nchunks, int nbands, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
@@ -189,9 +195,25 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
   pm.p = (int64_t)min(row0 + kk, H - 1) * W + min(col0 + arow, W - 1);
   const int64_t p = pm.p;
 
-  __shared__ __attribute__((aligned(16))) float lds[kMain + 4 * GGC * 2];
+  constexpr int kMapFloats = FOLD ? 2 * LP * K3 * 2 : 0;  // two frames' mapping tables
+  __shared__ __attribute__((aligned(16))) float lds[kMain + 4 * GGC * 2 + kMapFloats];
   float* img = lds;
   float* boxred = lds + kMain;  // [wave][column][min, max]
+  float* smap = boxred + 4 * GGC * 2;
+  // mapping of frame fm into table fm & 1: entry e = (layer * K3 + k) * 2 + xy
+  auto fold_mapping = [&](int fm) {
+    if constexpr (FOLD) {
+      for (int e = threadIdx.x; e < L * K3 * 2; e += kBlock) {
+        const int c = e & 1, r = (e >> 1) % K3, l = (e >> 1) / K3;
+        const float* row = inv_kernel + r * K3;
+        const float* x = src_pts + ((int64_t)fm * L + l) * (K3 - 3) * 2 + c;
+        float acc = 0.0f;
+#pragma unroll
+        for (int n = 0; n < K3 - 3; ++n) acc = fmaf(row[n], x[2 * n], acc);
+        smap[(fm & 1) * (LP * K3 * 2) + e] = acc;
+      }
+    }
+  };
   // zero-weight taps of wild (NaN) coordinates may read any word of the image: keep it finite
   for (int i = threadIdx.x; i < kMain; i += kBlock) lds[i] = 0.0f;
 
@@ -209,13 +231,14 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
       av[g][ks] = (k < K3) ? bs : 0.0f;
     }
   }
+  const int f0 = chunk * frames_per_block;
+  const int f1 = min(F, f0 + frames_per_block);
+  if (f0 < f1) fold_mapping(f0);
   __syncthreads();
 
   // pixel-unit grid: the MFMA column of this lane is an x column (even) or a y column (odd)
   const float half_size = 0.5f * (float)((arow & 1) ? H : W);
   const float half_size_m1 = 0.5f * (float)(((arow & 1) ? H : W) - 1);
-  const int f0 = chunk * frames_per_block;
-  const int f1 = min(F, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
     // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (scaled_map):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[g][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const float* mp = mapping + (int64_t)f * L * K3 * 2;
+    const float* mp = FOLD ? smap + (f & 1) * (LP * K3 * 2) : mapping + (int64_t)f * L * K3 * 2;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + kk;
@@ -241,6 +264,9 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
         for (int nt = 0; nt < NT; ++nt)
           acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][ks], bv[nt], acc[g][nt], 0, 0, 0);
     }
+    // the next frame's table (the other one: its last reader was the previous frame's phase (A),
+    // barriers ago; its first reader comes after this frame's closing barrier)
+    if (f + 1 < f1) fold_mapping(f + 1);
     // ---- (B) range of every grid coordinate over the workgroup's pixels.  In the accumulator
     // layout a lane holds 16 pixels of ONE column (layer, xy): 30 min/max + two cross-row steps
     // per 16 columns, instead of a cross-lane reduction per layer and coordinate.

@@ -7,13 +7,16 @@
 namespace waldo {
 
 void WALDO_CAT(wc_fwd_lp, WALDO_LP)(bool k19, const float* layers, const float* basis_t,
-                                    const float* mapping, const float* occ, float* rgb,
+                                    const float* mapping, const float* inv_kernel,
+                                    const float* src_pts, const float* occ, float* rgb,
                                     float* alpha, int F, int L, int H, int W, int K3, float delta,
                                     hipStream_t st) {
   if (k19)
-    launch_fwd<WALDO_LP, 19, true>(layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, delta, st);
+    launch_fwd<WALDO_LP, 19, true>(layers, basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, L, H, W,
+                                   K3, delta, st);
   else
-    launch_fwd<WALDO_LP, 32, false>(layers, basis_t, mapping, occ, rgb, alpha, F, L, H, W, K3, delta, st);
+    launch_fwd<WALDO_LP, 32, false>(layers, basis_t, mapping, nullptr, nullptr, occ, rgb, alpha, F, L, H, W,
+                                    K3, delta, st);
 }
 
 // `workspace` != nullptr selects the two-kernel backward (compiled for L <= kBwd2MaxLayers, K3 == 19)

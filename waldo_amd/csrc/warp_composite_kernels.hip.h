@@ -435,8 +435,11 @@ static inline TileGeom tile_geom(int H, int W, int rows) {
   return g;
 }
 
+// inv_kernel / src_pts != nullptr (K3 == 19, staged shapes only: checked by the C-ABI entry point):
+// the mapping is computed inside the forward kernel and `mapping` is not read
 template <int LP, int K3P, bool EXK>
 static void launch_fwd(const float* layers, const float* basis_t, const float* mapping,
+                       const float* inv_kernel, const float* src_pts,
                        const float* occ, float* rgb, float* alpha, int F, int L, int H, int W,
                        int K3, float delta, hipStream_t st) {
   const TileGeom g = tile_geom(H, W, 4);
@@ -451,14 +454,19 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
     if (!debug_option(WALDO_DEBUG_FWD_PLAIN) && staged_eligible(H, W)) {
       const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
       dim3 grid16((unsigned)xcd_grid_banded(nchunks, nbands, nt16, 1));
-      if (L == LP)
-        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, true>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, nbands,
-                           delta);
-      else
-        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, false>), grid16, dim3(kBlock), 0, st, layers,
-                           basis_t, mapping, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16, nchunks, nbands,
-                           delta);
+      auto go = [&](auto exl, auto fold) {
+        constexpr bool EXL = decltype(exl)::value, FOLD = decltype(fold)::value;
+        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, EXL, FOLD>), grid16, dim3(kBlock), 0, st, layers,
+                           basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16,
+                           nchunks, nbands, delta);
+      };
+      using T = std::true_type;
+      using N = std::false_type;
+      if (src_pts != nullptr) {
+        if (L == LP) go(T{}, T{}); else go(N{}, T{});
+      } else {
+        if (L == LP) go(T{}, N{}); else go(N{}, N{});
+      }
       return;
     }
   }

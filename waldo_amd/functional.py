@@ -747,8 +747,15 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
     grey after ``reduce_comp``'s ``(x + 1) / 2``); 1 is ``Warper.layer_to_output``'s default:
     out-of-range taps read -1, i.e. alpha 0 / black.  Precision / NaN contract of the backward:
     include/waldo_hip.h."""
-    mapping = tps_mapping(inverse_kernel, src_pts)
     f, nl = layers.shape[:2]
+    needs_grad = torch.is_grad_enabled() and any(
+        torch.is_tensor(t) and t.requires_grad for t in (layers, src_pts, occ, inverse_kernel, basis_t))
+    if not needs_grad and layers.dim() == 5 and layers.shape[2] == 4 and src_pts.dim() == 3 and \
+            _lib.load().waldo_warp_composite_pts_supported(nl, layers.shape[-2], layers.shape[-1],
+                                                           src_pts.shape[1]):
+        return _warp_composite_pts(layers, src_pts, occ, inverse_kernel, basis_t, bool(return_alpha),
+                                   float(delta))
+    mapping = tps_mapping(inverse_kernel, src_pts)
     chunk = _frames_per_call(f, nl, layers.shape[-2], layers.shape[-1], mapping.shape[1])
     if f <= chunk:
         rgb, alpha = _WarpComposite.apply(layers, mapping, occ, basis_t, bool(return_alpha), float(delta))
@@ -758,6 +765,33 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
         rgb = torch.cat([o[0] for o in outs])
         alpha = torch.cat([o[1] for o in outs]) if return_alpha else None
     return (rgb, alpha) if return_alpha else rgb
+
+
+def _warp_composite_pts(layers, src_pts, occ, inverse_kernel, basis_t, want_alpha, delta):
+    """Forward without autograd, straight from the control points: ONE launch per call
+    (waldo_warp_composite_pts_fwd; the TPS mapping is computed inside the kernel, same bits as
+    tps_mapping + the two-step forward)."""
+    _lib.check_cuda(layers, src_pts, occ, inverse_kernel, basis_t)
+    layers, src_pts, occ = _c(layers.detach()), _c(src_pts.detach().float()), _c(occ.detach())
+    inverse_kernel, basis_t = _c(inverse_kernel.detach()), _c(basis_t.detach())
+    f, nl, _, h, w = layers.shape
+    n = src_pts.shape[1]
+    if src_pts.shape[0] != f * nl or tuple(occ.shape) != (f, nl, nl) or \
+            tuple(basis_t.shape) != (n + 3, h * w) or tuple(inverse_kernel.shape) != (n + 3, n + 3):
+        raise _lib.WaldoHipError(
+            f"warp_composite: inconsistent shapes layers={tuple(layers.shape)} src_pts={tuple(src_pts.shape)} "
+            f"occ={tuple(occ.shape)} basis_t={tuple(basis_t.shape)} inverse_kernel={tuple(inverse_kernel.shape)}")
+    rgb = layers.new_empty(f, 3, h, w)
+    alpha = layers.new_empty(f, nl, h, w) if want_alpha else None
+    per = max(1, MAX_FL_PER_LAUNCH // nl)
+    with torch.cuda.device(layers.device):
+        for i in range(0, f, per):
+            j = min(f, i + per)
+            _lib.call("waldo_warp_composite_pts_fwd", _lib.ptr(layers[i:j]), _lib.ptr(basis_t),
+                      _lib.ptr(inverse_kernel), _lib.ptr(src_pts[i * nl:j * nl]), _lib.ptr(occ[i:j]),
+                      _lib.ptr(rgb[i:j]), _lib.ptr(alpha[i:j]) if want_alpha else None, j - i, nl, h, w, n,
+                      delta, _lib.current_stream(layers.device))
+    return (rgb, alpha) if want_alpha else rgb
 
 
 MAX_WORKSPACE_BYTES = 8 << 30   # backward workspace per call of the fused path

@@ -45,7 +45,9 @@ class TPSWarp(nn.Module):
         fwd[n, :n] = 1
         fwd[:n, n + 1:] = tgt_pts
         fwd[n + 1:, :n] = tgt_pts.t()
-        inverse_kernel = torch.inverse(fwd)
+        # torch.inverse returns a column-major result: stored row-major (same values, same state-dict
+        # entry), or every call of the kernels would first copy it into a contiguous temporary
+        inverse_kernel = torch.inverse(fwd).contiguous()
         raster = get_grid(tgt_height, tgt_width).view(-1, 2)
         rep = torch.cat([kernel_distance(raster, tgt_pts),
                          torch.ones(tgt_height * tgt_width, 1), raster], dim=1)
