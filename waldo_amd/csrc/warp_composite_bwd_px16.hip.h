@@ -42,6 +42,11 @@ __device__ __forceinline__ int pk_max_u16(int a, int b) {
 // biased exponent of a non-negative float (255: infinity or NaN)
 __device__ __forceinline__ int exponent_of(float v) { return (int)(__float_as_uint(v) >> 23) & 0xff; }
 
+#ifndef WALDO_K1_STAGE_AHEAD
+#define WALDO_K1_STAGE_AHEAD 3  // layers whose box loads are in flight (2 / 3: backward 2.19 / 2.16 ms; the
+                                // forward, with fewer registers to spare at four waves per SIMD, keeps 2)
+#endif
+
 template <int LP>
 struct Px16Cfg {
   static constexpr int K3 = kGmapK3, KS = (K3 + 3) / 4;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     // planes) of a layer's box into the float4-texel LDS image (see warp_composite_fwd_lds_kernel);
     // a rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
     // layer l leaves its registers for LDS); the image is double-buffered, one barrier per layer.
-    constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
+    constexpr int kAhead = LP < WALDO_K1_STAGE_AHEAD ? LP : WALDO_K1_STAGE_AHEAD;
     const int item_l = threadIdx.x;
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {

@@ -416,6 +416,9 @@ namespace waldo {
 // prefer a chunk count divisible by the 8 XCDs (each chunk is pinned to one) while keeping enough
 // workgroups to fill the chip several times over
 static inline int chunk_frames(int F, int64_t ntiles) {
+#ifdef WALDO_ABL_FPB  // timing-only sweep of the frames per workgroup
+  return WALDO_ABL_FPB < F ? WALDO_ABL_FPB : F;
+#endif
   for (int c = 8; c >= 2; --c) {
     const int chunks = (F + c - 1) / c;
     if (chunks % kXcds == 0 && (int64_t)chunks * ntiles >= 2048) return c;
