@@ -172,8 +172,23 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[g][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const float* mp = mapping + (int64_t)f * L * K3 * 2;
     {
-      const float* mp = mapping + (int64_t)f * L * K3 * 2;
+      // every B-operand load of the frame is issued before the first use: left alone hipcc sinks the
+      // last k-step's load behind its (k < K3) predicate -- a second dependent round trip at the head
+      // of every frame (the empty asm pins the loads; they return in order anyway)
+      float mraw[KS][NT];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int k = 4 * ks + kk, col = nt * 16 + arow, l = col >> 1;
+          mraw[ks][nt] = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
+        }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(mraw[ks][nt]));
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k = 4 * ks + kk;
@@ -181,8 +196,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int col = nt * 16 + arow, l = col >> 1;
-          const float m = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
-          bv[nt] = (k < K3 && l < L) ? scaled_map(m, k == K3 - 3, half_size, half_size_m1) : 0.0f;
+          bv[nt] = (k < K3 && l < L) ? scaled_map(mraw[ks][nt], k == K3 - 3, half_size, half_size_m1) : 0.0f;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -488,7 +502,11 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     // ---- (G) a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Records, contribution bounds
     // and the grid gradient of every layer.  The records go out FIRST: the stores get the rest of
     // this phase to drain.
+#ifndef WALDO_ABL_NO_REC_STORE  // timing-only ablation: K1 without its record stores (wrong gradients)
     if (live) {
+#else
+    if (live && H < 0) {
+#endif
 #pragma unroll
       for (int l = 0; l < LP; ++l)
         if (EXL || l < L)

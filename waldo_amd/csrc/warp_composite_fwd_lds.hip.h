@@ -248,21 +248,37 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[g][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const float* mp = FOLD ? smap + (f & 1) * (LP * K3 * 2) : mapping + (int64_t)f * L * K3 * 2;
+    {
+      // every B-operand load of the frame is issued before the first use: left alone hipcc sinks the
+      // last k-step's load behind its (k < K3) predicate -- a second dependent round trip at the head
+      // of every frame (the empty asm pins the loads; they return in order anyway)
+      float mraw[KS][NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + kk;
-      float bv[NT];
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = nt * 16 + arow, l = col >> 1;
-        const float m = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
-        bv[nt] = (k < K3 && l < L) ? scaled_map(m, k == K3 - 3, half_size, half_size_m1) : 0.0f;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int k = 4 * ks + kk, col = nt * 16 + arow, l = col >> 1;
+          mraw[ks][nt] = mp[(min(l, L - 1) * K3 + min(k, K3 - 1)) * 2 + (col & 1)];
+        }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(mraw[ks][nt]));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kk;
+        float bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + arow, l = col >> 1;
+          bv[nt] = (k < K3 && l < L) ? scaled_map(mraw[ks][nt], k == K3 - 3, half_size, half_size_m1) : 0.0f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][ks], bv[nt], acc[g][nt], 0, 0, 0);
       }
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][ks], bv[nt], acc[g][nt], 0, 0, 0);
     }
     // the next frame's table (the other one: its last reader was the previous frame's phase (A),
     // barriers ago; its first reader comes after this frame's closing barrier)
