@@ -181,8 +181,11 @@ __global__ __launch_bounds__(kBlock, 3) void flow_ctx_alpha_bwd_kernel(
     }
 }
 
+#ifndef WALDO_FCB_WARP_WAVES
+#define WALDO_FCB_WARP_WAVES 3
+#endif
 template <int LP>
-__global__ __launch_bounds__(kBlock, 3) void flow_ctx_warp_bwd_kernel(
+__global__ __launch_bounds__(kBlock, WALDO_FCB_WARP_WAVES) void flow_ctx_warp_bwd_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ,

@@ -19,7 +19,10 @@ __global__ __launch_bounds__(kBlock) void tps_mapping_fwd_kernel(
     const int64_t b = (e >> 1) / K3;
     const float* row = inv + (int64_t)r * K3;
     const float* x = pts + b * N * 2 + c;
+    // the fma chain keeps its order (bit-identical); unrolled so that eight steps' loads are in
+    // flight instead of one dependent round trip per control point (N = 128 for the background)
     float acc = 0.0f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) acc = fmaf(row[n], x[2 * n], acc);
     mapping[e] = acc;
   }
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(kBlock) void tps_mapping_bwd_kernel(
     const int64_t b = (e >> 1) / N;
     const float* g = gmap + b * K3 * 2 + c;
     float acc = 0.0f;
+#pragma unroll 8
     for (int r = 0; r < K3; ++r) acc = fmaf(inv[(int64_t)r * K3 + n], g[2 * r], acc);
     gpts[e] = acc;
   }
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_fwd_kernel(const float* __res
   float ax[kGridNB], ay[kGridNB];
 #pragma unroll
   for (int i = 0; i < kGridNB; ++i) ax[i] = ay[i] = 0.0f;
+#pragma unroll 8  // eight basis loads in flight (K3 = 131 for the background: the loop was one round trip per k)
   for (int k = 0; k < K3; ++k) {
     const float bv = basis_t[(int64_t)k * HW + pc];
 #pragma unroll
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
         }
       }
     }
+#pragma unroll 4  // four k-steps' basis loads in flight (unconditional: past the raster the gradient is 0)
     for (int k = 0; k < K3; ++k) {
       float part[kGradNB * 2];
 #pragma unroll
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
 #pragma unroll
       for (int q = 0; q < kGradPPT; ++q) {
         const int64_t p = pbase + q;
-        const float bv = (p < HW) ? basis_t[(int64_t)k * HW + p] : 0.0f;
+        const float bv = basis_t[(int64_t)k * HW + (p < HW ? p : HW - 1)];
 #pragma unroll
         for (int i = 0; i < kGradNB; ++i) {
           part[2 * i] = fmaf(bv, g[q][i][0], part[2 * i]);
