@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void pose_affine_bwd_kernel(
   if (k < 6) {
     const int a = k >> 1, b = k & 1;  // T[a][b]: coordinate a (x, y, 1) feeds output component b
     float acc = 0.0f;
+#pragma unroll 8  // P = 128 background points: keep eight steps' loads in flight (same fma order)
     for (int p = 0; p < P; ++p) {
       const float coord = a == 2 ? 1.0f : pts_mul * base[2 * p + a] + mul_delta * q[6 + 2 * p + a];
       acc = fmaf(coord, g[2 * p + b], acc);
