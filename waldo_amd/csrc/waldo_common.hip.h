@@ -281,13 +281,16 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[N], int lane) 
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
 
+#ifndef WALDO_BUF_STORE_AUX
+#define WALDO_BUF_STORE_AUX 16  // gfx942 / gfx950 cache-policy bits of a buffer store: 1 sc0, 2 nt, 16 sc1
+#endif
 template <int POLICY>
 __device__ __forceinline__ void stream_store16(float* uniform_base, uint32_t byte_off, int64_t bytes, f32x4_s v) {
   if constexpr (POLICY == 1) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_base, 0, (int)bytes, 0x00020000);
     u32x4_s u;
     __builtin_memcpy(&u, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)byte_off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)byte_off, 0, WALDO_BUF_STORE_AUX);
   } else if constexpr (POLICY == 2) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4_s*>(reinterpret_cast<char*>(uniform_base) + byte_off));
   } else {
