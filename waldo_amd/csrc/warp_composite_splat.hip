@@ -29,12 +29,23 @@
 
 namespace waldo {
 
-constexpr int kSrcRows = 32, kSrcCols = 64;          // S tile
+#ifndef WALDO_K2_COLS
+#define WALDO_K2_COLS 64
+#endif
+#ifndef WALDO_K2_WAVES
+#define WALDO_K2_WAVES 8
+#endif
+#ifndef WALDO_K2_ROWS
+#define WALDO_K2_ROWS 32
+#endif
+constexpr int kSrcRows = WALDO_K2_ROWS, kSrcCols = WALDO_K2_COLS;  // S tile (64 columns; 32 measured: see DESIGN)
+constexpr int kColShift = kSrcCols == 64 ? 6 : 5;
+static_assert((1 << kColShift) == kSrcCols, "S tile: 32 or 64 columns");
 constexpr int kSrcTex = kSrcRows * kSrcCols;          // 2048 texels (x4 channels)
 constexpr int kCellPix = kCellRows * kCellCols;       // 128
 constexpr int kCellShift = kCellPix == 64 ? 6 : (kCellPix == 128 ? 7 : 8);
 static_assert((1 << kCellShift) == kCellPix, "cell rows: 4, 8 or 16");
-constexpr int kG2Waves = 8;
+constexpr int kG2Waves = WALDO_K2_WAVES;
 constexpr int kG2Threads = kG2Waves * kWave;          // 512
 constexpr int kMaxHit = 192 * 8 / kCellRows;         // cells listed per tile (else: slow scan)
 constexpr int kScanPer = 2;                           // cells per thread and trip of the table scan
@@ -60,7 +71,7 @@ __device__ __forceinline__ int4 load_box(const int* cellbox, int64_t idx) {
 #define WALDO_K2_RING 2
 #endif
 #ifndef WALDO_K2_PITCH
-#define WALDO_K2_PITCH 64
+#define WALDO_K2_PITCH WALDO_K2_COLS
 #endif
 constexpr int kPitch = WALDO_K2_PITCH;
 constexpr int kImgWords = kSrcRows * kPitch;           // image words per channel
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   if (poison) {  // block-uniform
     const float qnan = __builtin_nanf("");
     for (int e = threadIdx.x; e < kSrcTex; e += kG2Threads) {
-      const int y = sy0 + (e >> 6), x = sx0 + (e & 63);
+      const int y = sy0 + (e >> kColShift), x = sx0 + (e & (kSrcCols - 1));
       if (y < H && x < W) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) (gbase + c * HW)[(unsigned)(__mul24(y, W) + x)] = qnan;
@@ -343,10 +354,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int e = threadIdx.x; e < kSrcTex / 4; e += kG2Threads) {
-      const int y = sy0 + (e >> 4), x = sx0 + 4 * (e & 15);
+      const int y = sy0 + (e >> (kColShift - 2)), x = sx0 + 4 * (e & (kSrcCols / 4 - 1));
       if (y < H && x < W) {
         const unsigned doff = (unsigned)(__mul24(y, W) + x);
-        const int li = (e >> 4) * kPitch + 4 * (e & 15);
+        const int li = (e >> (kColShift - 2)) * kPitch + 4 * (e & (kSrcCols / 4 - 1));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
@@ -359,10 +370,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     return;
   }
   for (int e = threadIdx.x; e < kSrcTex; e += kG2Threads) {
-    const int y = sy0 + (e >> 6), x = sx0 + (e & 63);
+    const int y = sy0 + (e >> kColShift), x = sx0 + (e & (kSrcCols - 1));
     if (y < H && x < W) {
       const unsigned doff = (unsigned)(__mul24(y, W) + x);
-      const int li = (e >> 6) * kPitch + (e & 63);
+      const int li = (e >> kColShift) * kPitch + (e & (kSrcCols - 1));
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * (c < 3 ? inv_rgb : inv_a);
