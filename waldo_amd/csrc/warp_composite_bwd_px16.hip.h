@@ -58,7 +58,7 @@ struct Px16Cfg {
   static constexpr int PP1 = kBlock + 1;         // pitch of the per-pixel columns (gg, park)
   static constexpr int BP = 21;                  // pitch of the transposed basis [pixel][k]
   static constexpr int kBtFloats = kWave * BP;   // one wave's slice of it
-  static constexpr int kImgFloats = 2 * kImgBufFloats;           // two buffers of two pair planes
+  static constexpr int kImgFloats = 2 * kImgBufFloats;           // two buffers of float4 texels
   static constexpr int kTFloats = 4 * kWave * TP;                // transposition slices of the grid
   static constexpr int kGgFloats = GGC * PP1;                    // grid gradients (MFMA B operand)
   static constexpr int kAccFloats = 4 * 2 * NT * 256;            // per-wave MFMA accumulators

@@ -6,8 +6,8 @@
 //    loads its own 2x2 taps, 4 bytes per lane).  Here a workgroup (16 x 16 pixels, four rows per
 //    wavefront -- square tiles: the warp's skew over a 64-pixel-wide tile makes its footprint box
 //    ~4x the tile, over 16 pixels ~1.5x) finds, per layer, the bounding box of the 2x2 blocks its
-//    pixels read, streams that box ONCE from global memory with 16-byte-per-lane loads (wave w
-//    stages channel plane w) and takes the bilinear taps out of LDS (ds_read2_b32 pairs);
+//    pixels read, streams that box ONCE from global memory (every lane two texels of the four
+//    channel planes) and takes the bilinear taps out of LDS;
 //  * with sampling off the vector-memory path the kernel is VALU-issue bound (rocprofv3:
 //    SQ_INSTS_VALU * 4 cycles ~ 80 % of its duration), so the TPS grid of all layers is one
 //    v_mfma_f32_16x16x4_f32 chain per 16 pixels (N = (layer, xy) columns), and the boxes come from
@@ -17,16 +17,17 @@
 // barrier per layer).  A box that does not fit the LDS image (violent warp) falls back to
 // gathering that layer straight from memory.
 //
-// The kernel is VALU-issue bound, so the per-(pixel, layer) arithmetic is kept minimal:
+// Per-(pixel, layer) arithmetic is kept minimal (round 2: what binds the kernel is a mix of VALU,
+// LDS and latency at four waves per SIMD -- DESIGN.md section 4):
 //  * the grid comes out of the MFMA chain already in PIXEL units (scaled_map(): the
 //    un-normalisation of grid_sample is folded into the B operand);
-//  * the staged image keeps the channels of a texel in PAIRS, (c0, c1) and (c2, c3) interleaved
-//    as float2 -- waves 0 / 1 stage the two halves of pair 0's box (each lane loads the same four
-//    texels of both planes and writes them interleaved), waves 2 / 3 pair 1 -- so a tap arrives as
-//    one 8-byte LDS read that is already a packed-fp32 operand: four ds_read2_b64 and twelve
-//    v_pk_* instructions per (pixel, layer) in the bilinear "lerp" form
+//  * the staged image keeps a texel's four channels together (float4), so a tap arrives as one
+//    16-byte LDS read whose halves are packed-fp32 operands: four ds_read_b128 and twelve v_pk_*
+//    instructions per (pixel, layer) in the bilinear "lerp" form
 //    top + fy (bot - top), top = p00 + fx (p01 - p00), instead of sixteen fmas on four corner
-//    weights (same value up to rounding).
+//    weights (same value up to rounding);
+//  * whatever is wave-uniform stays scalar: the wave index is read with readfirstlane, plane bases
+//    are SGPR pairs and lanes carry 32-bit offsets (122 VGPRs at L = 8: four waves per SIMD).
 //
 // Tap blocks: instead of clamping the four corners separately, a pixel reads the 2x2 block at
 // (xb, yb) = clamp((x0, y0), 0, (W-2, H-2)), which lies inside the layer; the block's cells are
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of two pair planes
+  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of float4 texels
   constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
