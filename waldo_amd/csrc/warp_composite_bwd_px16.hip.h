@@ -18,7 +18,7 @@
 //     contraction over pixels) and gets them through LDS from those same registers -- before, each
 //     (frame, tile) read them twice from memory (2.2 GB per launch at the headline shape);
 //   * the samples and their derivatives come out of an LDS image of each layer's footprint box,
-//     staged with 16-byte loads as in warp_composite_fwd_lds_kernel; a layer whose box does not fit
+//     staged as in warp_composite_fwd_lds_kernel (float4 texels); a layer whose box does not fit
 //     the image (violent warp) is gathered from memory instead;
 //   * the tile OWNS its cells of the footprint table: plain stores, no atomics, no memset.
 // The 4 L tap derivatives of a pixel are parked in LDS between sampling and the composite backward
