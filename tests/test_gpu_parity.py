@@ -679,6 +679,7 @@ def test_forward_from_control_points_is_one_launch_and_the_same_bits(dev, f, nl,
     tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
     ld, pd, od = layers.to(dev), pts.to(dev), occ.to(dev)
     assert WF._lib.load().waldo_warp_composite_pts_supported(nl, h, w, 16)
+    assert f * ((h + 15) // 16) * ((w + 15) // 16) <= WF.FOLD_MAX_TILE_FRAMES  # the folded path is taken
     with torch.no_grad():
         rgb1, a1 = WF.warp_composite(ld, pd, od, tps.inverse_kernel, tps.basis_t, return_alpha=True, delta=delta)
     rgb2, a2 = WF.warp_composite(ld, pd.clone().requires_grad_(), od, tps.inverse_kernel, tps.basis_t,

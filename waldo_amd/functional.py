@@ -750,7 +750,10 @@ def warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, return_alpha=F
     f, nl = layers.shape[:2]
     needs_grad = torch.is_grad_enabled() and any(
         torch.is_tensor(t) and t.requires_grad for t in (layers, src_pts, occ, inverse_kernel, basis_t))
-    if not needs_grad and layers.dim() == 5 and layers.shape[2] == 4 and src_pts.dim() == 3 and \
+    # the one-launch forward pays for its launch saving with a mapping computation per (tile, frame):
+    # worth it while the call is launch-bound (C2: 25 -> 19 us), 4 % slower at C4 size
+    small = f * ((layers.shape[-2] + 15) // 16) * ((layers.shape[-1] + 15) // 16) <= FOLD_MAX_TILE_FRAMES
+    if not needs_grad and small and layers.dim() == 5 and layers.shape[2] == 4 and src_pts.dim() == 3 and \
             _lib.load().waldo_warp_composite_pts_supported(nl, layers.shape[-2], layers.shape[-1],
                                                            src_pts.shape[1]):
         return _warp_composite_pts(layers, src_pts, occ, inverse_kernel, basis_t, bool(return_alpha),
@@ -794,6 +797,7 @@ def _warp_composite_pts(layers, src_pts, occ, inverse_kernel, basis_t, want_alph
     return (rgb, alpha) if want_alpha else rgb
 
 
+FOLD_MAX_TILE_FRAMES = 8192     # largest (frames x 16x16 tiles) the one-launch forward is used for
 MAX_WORKSPACE_BYTES = 8 << 30   # backward workspace per call of the fused path
 MAX_FL_PER_LAUNCH = 65535       # F * L limit of one launch (include/waldo_hip.h)
 
