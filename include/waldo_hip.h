@@ -41,7 +41,9 @@ int waldo_max_layers(void);
  * fast paths against the plain ones).  Process-wide, off by default; nothing reads the environment. */
 #define WALDO_DEBUG_FWD_PLAIN 0   /* fused forward: gather kernel instead of the LDS-staged one */
 #define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
-#define WALDO_DEBUG_COUNT 2
+#define WALDO_DEBUG_BWD_GENERIC 2 /* fused backward: the generic per-tap-atomics kernel for every shape
+                                     (waldo_warp_composite_bwd_workspace_bytes answers 0) */
+#define WALDO_DEBUG_COUNT 3
 int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------
@@ -148,7 +150,9 @@ int waldo_occ_composite_bwd(const float* alpha, const float* occ, const float* g
  *   no prior);  out (N,C,h*scale,w*scale) = F.interpolate(y, scale_factor=scale, "bilinear",
  *   align_corners=False);  then mode 1 (remove_obj): out = -1, mode 2 (freeze_obj): out = +1;
  *   then with mask (h*scale,w*scale) (the `obj_alpha_mask` buffer; NULL: none):
- *   out = mask * out - (1 - mask).   Backward: grad_x (N,C,h,w) is OVERWRITTEN (gathered: no atomics).
+ *   out = mask * out - (1 - mask).   mode != 0 and mask act on the ONE-channel object alpha of
+ *   lvd.py:128-132: with C > 1 either of them is refused (WALDO_EINVAL).
+ *   Backward: grad_x (N,C,h,w) is OVERWRITTEN (gathered: no atomics).
  * waldo_pose_affine_*: the pose heads' affine (models/nets/flp.py:259-273, lvd.py:440-449).
  *   pose (R,6+2P) (after tanh / + last);  T = (mul6 * pose[:6] + bias6) as (3,2);
  *   pts[p] = pts_mul * base_pts[p] + mul_delta * pose[6+2p : 8+2p];  out (R,P,2) = [pts, 1] @ T.

@@ -311,9 +311,7 @@ def gen_producers(ns):
       * ImageDecoder.forward (lvd.py:239-255): `norm` = identity, `to_img` = a fixed raw image;
       * LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135): `decoder` = the decoder output
         above, `warper` = a no-op; it calls the real compute_occ;
-    The pose affine (flp.py:259-273) sits in the middle of PoseDecoder.forward and cannot be called
-    on its own: its vectors come from the restatement in oracle/producers_oracle.py checked against
-    an independent float64 einsum of the same published formula (tests/test_oracle_golden.py)."""
+    The pose affine (flp.py:259-273) sits in the middle of PoseDecoder.forward: gen_pose_affine below."""
     g = torch.Generator().manual_seed(11)
     b, no, lo, c_tok = 3, 4, 16, 8
     ho, wo, sf = 16, 16, 4  # decoder raw image 16x16 (obj_shape 4x4 x patch 4), x4 upsampling
@@ -351,6 +349,49 @@ def gen_producers(ns):
              grad_raw=raw.grad if raw.grad is not None else torch.zeros_like(raw), grad_score=score.grad)
 
 
+def gen_pose_affine(ns):
+    """Row f2, the pose heads' affine (models/nets/flp.py:252-273): the reference's OWN
+    ``PoseDecoder.forward`` run with a stub `self` whose transformer is empty (no blocks, identity norm)
+    and whose two linear heads return fixed tensors -- lines 252-273 then execute as they stand on
+    known inputs: tanh of the head outputs, the optional ``+ last``, transform / delta / ``pts @ transform``
+    for objects and background, and the scatter into the pose sequences.  Saved: the head outputs, the
+    buffers, the returned poses of the predicted frames and the gradients of a weighted sum of them
+    with respect to the head outputs."""
+    g = torch.Generator().manual_seed(19)
+    b, t, ctx_len, no, c = 2, 5, 2, 3, 4
+    lat, lat_obj = 8, 4  # background grid 2 x 4, object grid 2 x 2
+    for tag, use_last in (("plain", False), ("last", True)):
+        head_obj = torch.randn(b * (t - ctx_len), no, 6 + 2 * lat_obj + 1, generator=g).requires_grad_()
+        head_bg = torch.randn(b * (t - ctx_len), 1, 6 + 2 * lat, generator=g).requires_grad_()
+        last_obj = 0.1 * torch.randn(b, no, 6 + 2 * lat_obj, generator=g)
+        last_bg = 0.1 * torch.randn(b, 1, 6 + 2 * lat, generator=g)
+        stub = types.SimpleNamespace(
+            latent_size=lat, latent_obj_size=lat_obj, num_obj=no, embed_dim=c, cat_z=False, modulate_noise=False,
+            self_blocks=[], cross_blocks=[], norm=lambda x: x,
+            obj_head=lambda x: head_obj.view(-1, no * (6 + 2 * lat_obj + 1)),
+            bg_head=lambda x: head_bg.view(-1, 6 + 2 * lat), use_last=use_last,
+            mul_obj=torch.tensor([[[0.25, 0.25, 0.25, 0.25, 1.0, 1.0]]]), bias_obj=torch.tensor([[[0.25, 0.0, 0.0, 0.5, 0.0, 0.0]]]),
+            mul_delta_obj=0.2, tgt_pts_obj=ns.get_grid(2, 2).view(1, 1, lat_obj, 2),
+            bg_mul=1.2, tgt_pts_bg=ns.get_grid(2, 4).view(1, 1, lat, 2), bias_bg=torch.tensor([[[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]]]))
+        ctx_mask = (torch.arange(t).view(1, -1) < ctx_len).expand(b, -1)
+        x = torch.zeros(b, t, no + 1, c)
+        obj_in = torch.randn(b, t, no, lat_obj, 2, generator=g)
+        bg_in = torch.randn(b, t, 1, lat, 2, generator=g)
+        occ_in = torch.randn(b, t, no, generator=g)
+        obj_pose, bg_pose, occ_score = ns.PoseDecoder.forward(stub, obj_in, bg_in, occ_in, x, ctx_mask, last_obj, last_bg)
+        pred = ~ctx_mask
+        assert torch.equal(obj_pose[ctx_mask], obj_in[ctx_mask]) and torch.equal(bg_pose[ctx_mask], bg_in[ctx_mask])
+        po, pb = obj_pose[pred], bg_pose[pred]              # (B (T - ctx), No, Lo, 2), (B (T - ctx), 1, L, 2)
+        w1 = torch.randn(po.shape, generator=g)
+        w2 = torch.randn(pb.shape, generator=g)
+        ((po * w1).sum() + (pb * w2).sum()).backward()
+        save(f"pose_affine_{tag}", head_obj=head_obj, head_bg=head_bg, last_obj=last_obj, last_bg=last_bg,
+             use_last=int(use_last), frames_per_clip=t - ctx_len, mul_obj=stub.mul_obj, bias_obj=stub.bias_obj,
+             mul_delta_obj=float(stub.mul_delta_obj), tgt_pts_obj=stub.tgt_pts_obj, bg_mul=float(stub.bg_mul),
+             tgt_pts_bg=stub.tgt_pts_bg, bias_bg=stub.bias_bg, obj_pose=po, bg_pose=pb, occ_score=occ_score[pred],
+             w1=w1, w2=w2, grad_head_obj=head_obj.grad, grad_head_bg=head_bg.grad)
+
+
 def gen_demo_clip():
     """BASELINE config C1: six frames of the in-tree demo clip (datasets/demo_cityscapes, munster),
     reduced 4x with PIL so that the fixture stays small -- frames bilinear (as the loader's own
@@ -379,7 +420,7 @@ def main():
     ns = R.load()
     only = set(sys.argv[1:])  # e.g. `make_golden.py inverse_warp_perm`; none = all
     for fn in (gen_tps, gen_grid_sample, gen_occ_comp, gen_warp_composite, gen_warp_composite_delta, gen_inverse_warp,
-               gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers):
+               gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers, gen_pose_affine):
         if not only or fn.__name__[4:] in only:
             fn(ns)
     if not only or "demo_clip" in only:

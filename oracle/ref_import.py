@@ -48,7 +48,7 @@ def _load(modname, relpath):
 
 def load():
     """Returns a namespace with the reference's TPSWarp, InverseWarp, Warper, LVD
-    (class only), WIF, get_grid, get_gaussian_kernel, gather_time, scale."""
+    (class only), PoseDecoder (class only), WIF, get_grid, get_gaussian_kernel, gather_time, scale."""
     if "ns" in _cache:
         return _cache["ns"]
     if not available():
@@ -99,7 +99,9 @@ def load():
         wif = _load("models.nets.wif", "models/nets/wif.py")
     finally:
         pass
+    flp = _load("models.nets.flp", "models/nets/flp.py")
     ns = types.SimpleNamespace(
+        PoseDecoder=flp.PoseDecoder,
         TPSWarp=warp.TPSWarp, InverseWarp=warp.InverseWarp, kernel_distance=warp.kernel_distance,
         Warper=lvd.Warper, LVD=lvd.LVD, ImageDecoder=lvd.ImageDecoder, get_circle=lvd.get_circle,
         gather_time=lvd.gather_time, scale=lvd.scale,

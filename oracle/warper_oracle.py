@@ -287,15 +287,15 @@ def _grid_to_flow(cfg, inp, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts
     # 6. ghost suppression (ctx variant only), lvd.py:784-791
     is_obj = 1
     if ctx_only and not cfg.allow_ghost:
-        ones = torch.ones(b * tc, tp, no, 1, ho, wo)
+        ones = torch.ones(b * tc, tp, no, 1, ho, wo, dtype=sgo_p.dtype)
         io = obj_to_output(cfg, ones, sgo_p, 0)
-        io = (rescale(io, cfg.scale_hd) > 0.9).float().view(b, tc, tp, no, 1, hd, wd)
+        io = (rescale(io, cfg.scale_hd) > 0.9).to(io.dtype).view(b, tc, tp, no, 1, hd, wd)
         is_obj = torch.cat([torch.ones_like(io[:, :, :, :1]), io], dim=3)
     # 7. flow of every layer warped to image space and upsampled, lvd.py:670-674 / 792-796
     flow = layer_to_output(cfg, obj_flow.reshape(b * tc, tp, no, 2, ho, wo),
                            bg_flow.reshape(b * tc, tp, 2, h, w), gridp, 0, 0)
     flow = rescale(flow.view(b, tc, tp, nl_layers, 2, h, w), cfg.scale_hd)      # B Tc Tp L 2 Hd Wd
-    samp = O.get_grid(hd, wd) + flow.permute(0, 1, 2, 3, 5, 6, 4).reshape(-1, hd, wd, 2)
+    samp = O.get_grid(hd, wd).to(flow.dtype) + flow.permute(0, 1, 2, 3, 5, 6, 4).reshape(-1, hd, wd, 2)
     # 8. context alpha warped by the flow, lvd.py:677-681 / 799-803
     actx = to_ctx(alpha)
     actx = O.grid_sample(actx.reshape(-1, 1, hd, wd), samp).reshape(b, tc, tp, nl_layers, 1, hd, wd) * is_obj
@@ -318,7 +318,7 @@ def input_to_output(cfg, inp, alpha, flow, ctx_ts, eps=1e-6):
     b, tc, tp = flow.shape[:3]
     hd, wd = cfg.src_shape_hd
     c = inp.shape[-3]
-    samp = O.get_grid(hd, wd) + flow.permute(0, 1, 2, 4, 5, 3).reshape(b * tc * tp, hd, wd, 2)
+    samp = O.get_grid(hd, wd).to(flow.dtype) + flow.permute(0, 1, 2, 4, 5, 3).reshape(b * tc * tp, hd, wd, 2)
     warped = O.grid_sample(gather_time(inp, ctx_ts).reshape(b * tc * tp, c, hd, wd), samp)
     warped = warped.reshape(b, tc, tp, c, hd, wd)
     score = ((alpha + 1) / 2).sum(dim=3, keepdim=True)

@@ -67,3 +67,43 @@ def test_sharded_warp_composite_two_ranks_one_gpu(dev, frames):
         out = torch.from_numpy(out)
         assert out.shape == single.shape
         assert torch.equal(out, single), f"rank {rank}: gathered frames differ from the single-rank result"
+
+
+def _rccl_rank(port, frames, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import waldo_amd
+    from waldo_amd.dist import all_gather_frames, init_distributed
+    init_distributed(backend="nccl", single_rank_group=True)  # "nccl" IS RCCL on ROCm
+    dev = torch.device("cuda:0")
+    nl, h, w = 4, 32, 64
+    layers, pts, occ, _, _ = O.make_synthetic(frames, nl, h, w, seed=11)
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+    from waldo_amd import functional as WF
+    with torch.no_grad():
+        rgb = WF.warp_composite(layers.to(dev), pts.to(dev), occ.to(dev), tps.inverse_kernel, tps.basis_t)
+        out = all_gather_frames(rgb, frames, collective_for_one=True)  # one all_gather_into_tensor on device buffers
+    torch.cuda.synchronize()
+    maps = open("/proc/self/maps").read()
+    q.put((dist.get_backend(), bool(out.is_cuda), out.data_ptr() != rgb.data_ptr(), torch.equal(out, rgb),
+           "librccl" in maps, "libwaldo_hip.so" in maps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_gather_runs_on_one_gpu(dev):
+    """The first RCCL call of this code base must not happen on the driver's 8-GPU node: a freshly
+    spawned child creates a world-size-1 "nccl" (= RCCL) group, composites frames with the HIP kernels
+    and sends them through the same ``all_gather_into_tensor`` the N-rank inference path ends with
+    (reference contract: tools/engine.py:35,86-92)."""
+    ctx = mp.get_context("spawn")  # spawn, never re-exec or fork a process that touched the GPU
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_rank, args=(_free_port(), 5, q))
+    p.start()
+    backend, on_gpu, fresh_buffer, equal, rccl_mapped, hip_mapped = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and on_gpu and fresh_buffer, (backend, on_gpu, fresh_buffer)
+    assert equal, "frames changed on their way through the collective"
+    assert rccl_mapped, "librccl is not mapped: the collective did not go through RCCL"
+    assert hip_mapped

@@ -11,42 +11,7 @@ from oracle import wif_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
-
-
-def close(a, b, tol=TOL, rel=False, what="", exact=None):
-    """|a - b|_max <= tol (x max|b| when rel) + 2 x (4 x for gradients) the reference's own fp32
-    rounding noise, AND |a - exact|_max <= the same bound.
-
-    ``exact`` is the same quantity evaluated by the oracle in float64 from the same fp32 inputs:
-    max|b - exact| measures how far the fp32 reference itself is from exact arithmetic on this
-    input (white-noise layers at 512 px make that ~2e-4 for outputs and percents for the
-    control-point gradients, whose integrand is discontinuous across texels).  Two fp32
-    evaluations with different summation orders cannot agree better than that, so it is added
-    to the budget; on well-conditioned inputs it is ~1e-6 and the bound is the plain 1e-4.
-    The second inequality says the HIP result is no further from exact arithmetic than 2 x (outputs)
-    / 4 x (gradients: sums over pixels of an integrand that jumps at texel boundaries) the fp32
-    reference itself is, plus the tolerance; both distances are printed (pytest -s / on failure)."""
-    a = a.detach().cpu().double()
-    b = b.detach().cpu().double()
-    assert a.shape == b.shape, (what, a.shape, b.shape)
-    if a.numel() == 0:
-        return
-    scale = b.abs().max().item() if rel else 1.0
-    err = (a - b).abs().max().item()
-    if exact is None:
-        assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
-        return
-    e64 = exact.detach().cpu().double()
-    noise = (b - e64).abs().max().item()
-    err64 = (a - e64).abs().max().item()
-    bound = tol * scale + (4.0 if rel else 2.0) * noise
-    print(f"[parity] {what}: |hip-ref32| {err:.3e}  |hip-ref64| {err64:.3e}  |ref32-ref64| {noise:.3e}  "
-          f"(tol*scale {tol * scale:.1e})")
-    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e} (tol*scale {tol * scale:.1e}, fp32 noise {noise:.1e})"
-    bound64 = tol * scale + (4.0 if rel else 2.0) * noise
-    assert err64 <= bound64, (f"{what}: |hip - ref64| {err64:.3e} > {bound64:.3e} "
-                              f"(tol*scale {tol * scale:.1e}, |ref32 - ref64| {noise:.1e})")
+from parity import TOL, close  # noqa: E402  (tests/parity.py: 1e-4 + the measured fp32 noise of the reference)
 
 
 def test_native_library_is_loaded(dev):
@@ -221,7 +186,9 @@ def _oracle_fused(layers, pts, occ, ctrl, w1, w2, dtype, loss="weights", delta=0
 def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None, generic=False, delta=0.0):
     from waldo_amd import functional as WF
     import waldo_amd
-    WF._FORCE_GENERIC_BWD = generic  # False: tiled backward where it applies (L <= 8, K3 == 19)
+    from waldo_amd import _lib
+    # 0: tiled backward where it applies (L <= 17, K3 == 19); 1: the generic kernel for every shape
+    assert _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, int(generic)) == 0
     f, nl, _, h, w = layers.shape
     tps = waldo_amd.TPSWarp(h, w, ctrl)
     if buffers is not None:  # as when a reference checkpoint is loaded
@@ -237,7 +204,7 @@ def _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, loss="weights", buffers=None
         else:
             rgb.square().mean().backward()
     finally:
-        WF._FORCE_GENERIC_BWD = False  # the hook must not leak into other tests
+        _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, 0)  # must not leak into other tests
     return rgb, alpha, l2.grad, p2.grad, o2.grad
 
 
@@ -504,7 +471,7 @@ def test_non_finite_gradients_stay_visible(dev, where):
     """A NaN in the incoming gradient or in a layer must reach grad_layers on BOTH backward paths
     (the reference's training loop checks its gradients for NaN): the generic kernel propagates
     it per texel, the two-kernel path turns every source tile the poisoned cell reaches into NaN."""
-    from waldo_amd import functional as WF
+    from waldo_amd import _lib, functional as WF
     import waldo_amd
     f, nl, h, w = 2, 8, 64, 96
     layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=4, smooth=4)
@@ -516,14 +483,14 @@ def test_non_finite_gradients_stay_visible(dev, where):
         layers[0, 3, 1, 20, 30] = float("nan")
     out = {}
     for generic in (False, True):
-        WF._FORCE_GENERIC_BWD = generic
+        assert _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, int(generic)) == 0
         try:
             ld = layers.to(dev).requires_grad_()
             rgb = WF.warp_composite(ld, pts.to(dev), occ.to(dev), tps.inverse_kernel, tps.basis_t)
             (rgb * wgt.to(dev)).sum().backward()
             out[generic] = ld.grad
         finally:
-            WF._FORCE_GENERIC_BWD = False
+            _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, 0)
     fr = 1 if where == "grad_rgb" else 0
     for generic, g in out.items():
         assert torch.isnan(g[fr]).any(), f"generic={generic}: the NaN disappeared"
@@ -685,9 +652,11 @@ def test_forward_from_control_points_is_one_launch_and_the_same_bits(dev, f, nl,
     rgb2, a2 = WF.warp_composite(ld, pd.clone().requires_grad_(), od, tps.inverse_kernel, tps.basis_t,
                                  return_alpha=True, delta=delta)
     assert torch.equal(rgb1, rgb2.detach()) and torch.equal(a1, a2.detach())
-    ref, ref_a = O.warp_composite(layers, pts, occ, tps.inverse_kernel.cpu(), tps.tgt_grid_repr.cpu(), delta=delta)
-    close(rgb1, ref, tol=2e-4, what="rgb (control-point forward)")
-    close(a1, ref_a, tol=2e-4, what="alpha (control-point forward)")
+    inv, rep = tps.inverse_kernel.cpu(), tps.tgt_grid_repr.cpu()
+    ref, ref_a = O.warp_composite(layers, pts, occ, inv, rep, delta=delta)
+    e64, e64_a = O.warp_composite(layers.double(), pts.double(), occ.double(), inv.double(), rep.double(), delta=delta)
+    close(rgb1, ref, what="rgb (control-point forward)", exact=e64)
+    close(a1, ref_a, what="alpha (control-point forward)", exact=e64_a)
 
 
 def test_graphed_forward_replay(dev):

@@ -10,18 +10,16 @@ from oracle import warper_oracle as WO
 from oracle import wif_oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+
+from parity import TOL, close  # noqa: E402  (tests/parity.py: 1e-4 + the MEASURED fp32 noise of the reference)
 
 
-def close(a, b, tol=TOL, rel=False, what=""):
-    if a is None or b is None:
-        assert a is None and b is None, what
-        return
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    assert a.shape == b.shape, (what, a.shape, b.shape)
-    scale = max(b.abs().max().item(), 1e-30) if rel else 1.0
-    err = (a - b).abs().max().item() if a.numel() else 0.0
-    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
+def dbl(x):
+    """The same fp32 values in float64 (lists / tuples element-wise, index tensors and None as they are):
+    the oracle evaluated on them is the `exact` argument of close()."""
+    if isinstance(x, (list, tuple)):
+        return type(x)(dbl(v) for v in x)
+    return x.double() if torch.is_tensor(x) and x.is_floating_point() else x
 
 
 def opt_ns(**over):
@@ -175,8 +173,12 @@ def test_warper_chain_golden(dev, golden):
         close(r[3], g[pre + "alpha_ctx"], what=pre + "alpha_ctx")
         close(r[4], g[pre + "disocc"], what=pre + "disocc")
     out, raw = wp.input_to_output(d["inp"], d["c_alpha_ctx"], d["c_flow"], d["ctx_ts"])
-    close(out, g["out"], 3e-4, what="out")   # white-noise frames sampled at fp32-noisy positions
-    close(raw, g["raw"], 3e-4, what="raw")
+    # frames sampled at flow-displaced positions: the allowance on top of 1e-4 is the distance of the
+    # reference's own fp32 result from the float64 evaluation of the same step on the same inputs
+    cfg = WO.WarperCfg.from_opt(opt_ns(num_obj=2, weight_cls=True, min_cls=0.05))
+    out64, raw64 = WO.input_to_output(cfg, g["inp"].double(), g["c_alpha_ctx"].double(), g["c_flow"].double(), g["ctx_ts"])
+    close(out, g["out"], what="out", exact=out64)
+    close(raw, g["raw"], what="raw", exact=raw64)
 
 
 @pytest.mark.parametrize("over", [dict(), dict(weight_cls=True, min_cls=0.1), dict(load_dim=0),
@@ -211,19 +213,25 @@ def test_warper_against_oracle(dev, over):
     torch.manual_seed(1)
     wgt = torch.randn(out_o.shape)
     (out_o * wgt).sum().backward()
+    # the same chain in float64 from the same fp32 inputs: the `exact` side of every comparison below
+    l64 = [x.detach().double().requires_grad_() for x in (*grid_o, obj_alpha)]
+    r64 = WO.grid_to_flow_ctx(cfg, inp.double(), l64[:4], occ.double(), l64[4], bg_alpha.double(), cls.double(), ctx_ts, pred_ts)
+    out64, raw64 = WO.input_to_output(cfg, inp.double(), r64[3], r64[0], ctx_ts)
+    (out64 * wgt.double()).sum().backward()
     dl = [x.clone().to(dev).requires_grad_() for x in (*grid_o, obj_alpha)]
     grid_h = dl[:4]
     args = (inp.to(dev), grid_h, occ.to(dev), dl[4], bg_alpha.to(dev), cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
     rh = wp.grid_to_flow_ctx(*args)
-    for x, y, name in zip(rh, ro, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
-        close(x, y, what="ctx:" + name)
+    for x, y, z, name in zip(rh, ro, r64, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
+        close(x, y, what="ctx:" + name, exact=z)
     out_h, raw_h = wp.input_to_output(inp.to(dev), rh[3], rh[0], ctx_ts.to(dev))
-    # frames sampled at positions that are themselves the fp32 result of the chain above: 3e-4
-    close(out_h, out_o, 3e-4, what="out")
-    close(raw_h, raw_o, 3e-4, what="raw")
+    # frames sampled at positions that are themselves the fp32 result of the chain above: the allowance
+    # is what that costs the fp32 ORACLE against its float64 self, measured
+    close(out_h, out_o, what="out", exact=out64)
+    close(raw_h, raw_o, what="raw", exact=raw64)
     (out_h * wgt.to(dev)).sum().backward()
-    for x, y, name in zip(dl, leaves, ("grad tgo", "grad sgo", "grad tgb", "grad sgb", "grad obj_alpha")):
-        close(x.grad, y.grad, tol=2e-3, rel=True, what=name)
+    for x, y, z, name in zip(dl, leaves, l64, ("grad tgo", "grad sgo", "grad tgb", "grad sgb", "grad obj_alpha")):
+        close(x.grad, y.grad, rel=True, what=name, exact=z.grad)
     grid_o = [x.detach() for x in leaves[:4]]
     grid_h = [x.detach() for x in dl[:4]]
     # training variant and the helpers
@@ -291,30 +299,49 @@ def test_fused_hd_backward(dev, over, ctx_only, include_self):
     grid_to_flow[_ctx] -> input_to_output: the four grids, the object alphas, the occlusion matrix
     and the class distributions; loss over every output (flow, both alphas, disocc, fused frames,
     raw frames)."""
+    _hd_backward_case(dev, opt_ns(include_self=include_self, **over), ctx_only, include_self, b=2, t=3, nl=6, seed=17)
+
+
+def test_fused_hd_backward_at_recipe_size(dev):
+    """The same comparison at the size the backward really runs at: the LVD recipe
+    (scripts/cityscapes/train_lvd.sh, models/synthesizer.py:826-841): 128 x 256 with no HD raster,
+    16 objects (L = 17 -- the <17> kernel variants, which spill at this size), 20 layout classes, 5 frames,
+    ctx_mode "prev", include_self, weighted layout filter with opacity; grid_to_flow -> input_to_output
+    against the oracle's autograd in fp32 and fp64."""
+    opt = opt_ns(num_obj=16, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=0,
+                 aspect_ratio=2, use_lyt_filtering=True, use_lyt_opacity=True, weight_cls=True, min_cls=0.1,
+                 include_self=True)
+    # fused kernels only: they are what runs at this size.  (The per-op composition of the same chain sums
+    # its object-alpha gradient with float atomics over thousands of samples and lands 4.5 x the fp32
+    # oracle's own distance from float64 here -- 4 % of the largest entry, 0.9 % for the oracle, 6e-5 for
+    # the fused kernels; it is checked at the sizes it is used at, in test_fused_hd_backward.)
+    _hd_backward_case(dev, opt, False, True, b=1, t=5, nl=20, seed=23, per_op=False)
+
+
+def _hd_backward_case(dev, opt, ctx_only, include_self, b, t, nl, seed, per_op=True):
     from waldo_amd.nets import Warper
-    opt = opt_ns(include_self=include_self, **over)
     cfg = WO.WarperCfg.from_opt(opt)
     wp = Warper(opt).to(dev)
-    b, t, nl = 2, 3, 6
-    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=17)
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=seed)
     if include_self:  # ctx_mode "prev" of synthesizer.py:826-828
         ctx_ts = torch.roll(torch.arange(t), 1).view(1, 1, t).expand(b, -1, -1).contiguous()
         pred_ts = torch.arange(t)
     else:
+        assert b == 2
         ctx_ts = torch.tensor([[[0], [1]], [[1], [1]]])
         pred_ts = torch.tensor([2])
     with torch.no_grad():
         grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
     names = ("tgo", "sgo", "tgb", "sgb", "obj_alpha", "occ", "cls")
 
-    def run(fn_flow, fn_out, to, leaves):
+    def run(fn_flow, fn_out, to, leaves, dtype=torch.float32):
         g4, oa, oc, cl = leaves[:4], leaves[4], leaves[5], leaves[6]
         r = fn_flow(inp.to(to), g4, oc, oa, bg_alpha.to(to), cl, ctx_ts.to(to), pred_ts.to(to))
         out, raw = fn_out(inp.to(to), r[3], r[0], ctx_ts.to(to))
         torch.manual_seed(2)
         loss = 0
         for x in (r[0], r[2], r[3], r[4], out, raw):
-            loss = loss + (x * torch.randn(x.shape).to(to)).sum()
+            loss = loss + (x * torch.randn(x.shape).to(to, dtype)).sum()
         loss.backward()
         return [x.grad for x in leaves], (r, out, raw)
 
@@ -322,8 +349,10 @@ def test_fused_hd_backward(dev, over, ctx_only, include_self):
     lo = [x.clone().requires_grad_() for x in base]
     fo = WO.grid_to_flow_ctx if ctx_only else WO.grid_to_flow
     g_o, _ = run(lambda *a: fo(cfg, *a), lambda *a: WO.input_to_output(cfg, *a), "cpu", lo)
+    g_64, _ = run(lambda *a: fo(cfg, *dbl(a)), lambda *a: WO.input_to_output(cfg, *dbl(a)), "cpu",
+                  [x.clone().double().requires_grad_() for x in base], dtype=torch.float64)
     grads = {}
-    for fused in (True, False):
+    for fused in ((True, False) if per_op else (True,)):
         wp.fuse_hd = fused
         lh = [x.clone().to(dev).requires_grad_() for x in base]
         fh = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
@@ -333,8 +362,11 @@ def test_fused_hd_backward(dev, over, ctx_only, include_self):
         if g_o[i] is None:
             assert grads[True][i] is None or grads[True][i].abs().max() == 0, name
             continue
-        close(grads[True][i], g_o[i], tol=2e-3, rel=True, what=f"fused vs oracle: grad {name}")
-        close(grads[True][i], grads[False][i], tol=2e-3, rel=True, what=f"fused vs per-op: grad {name}")
+        # 1e-4 of the largest gradient + 4 x the fp32 oracle's distance from its float64 self (gradients
+        # reach the loss through sample POSITIONS: a frame / alpha edge turns fp32 position noise into value noise)
+        close(grads[True][i], g_o[i], rel=True, what=f"fused vs oracle: grad {name}", exact=g_64[i])
+        if per_op:
+            close(grads[False][i], g_o[i], rel=True, what=f"per-op vs oracle: grad {name}", exact=g_64[i])
 
 
 def test_fused_hd_passes_at_recipe_size(dev):
@@ -355,6 +387,10 @@ def test_fused_hd_passes_at_recipe_size(dev):
         grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
         ro = WO.grid_to_flow_ctx(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
         out_o, raw_o = WO.input_to_output(cfg, inp, ro[3], ro[0], ctx_ts)
+        # float64 evaluation of the same two steps on the same fp32 inputs (the second on the fp32 flow /
+        # alphas, like out_o): the measured allowance of close()
+        r64 = WO.grid_to_flow_ctx(cfg, *dbl((inp, grid_o, occ, obj_alpha, bg_alpha, cls)), ctx_ts, pred_ts)
+        out64, raw64 = WO.input_to_output(cfg, inp.double(), ro[3].double(), ro[0].double(), ctx_ts)
         args = (inp.to(dev), [x.to(dev) for x in grid_o], occ.to(dev), obj_alpha.to(dev), bg_alpha.to(dev),
                 cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
         assert wp.fuse_hd and wp._fused_ok(list(args[:1]), cfg.num_obj + 1, nl)
@@ -364,16 +400,16 @@ def test_fused_hd_passes_at_recipe_size(dev):
         # the flow's tolerance a second time, not this kernel
         out_f, raw_f = wp.input_to_output(args[0], ro[3].to(dev), ro[0].to(dev), args[6])
     assert rf[0].shape == (1, 4, 1, 2, 512, 1024) and rf[3].shape == (1, 4, 1, 17, 512, 1024)
-    for x, y, name in zip(rf, ro, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
+    for x, y, z, name in zip(rf, ro, r64, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
         if y is None:
             assert x is None, name
             continue
         # alpha_ctx / disocc sample the composited HD alpha at flow-displaced positions: at 1024 px a
         # position is good to ~1e-5 grid units in fp32 on either side, which a steep alpha edge turns
-        # into ~1e-4 of value (measured 1.2e-4 on one pixel of 35 M); the rest keeps the plain 1e-4
-        close(x, y, 2.5e-4 if name in ("alpha_ctx", "disocc") else TOL, what="R size, fused vs oracle: " + name)
-    close(out_f, out_o, 3e-4, what="R size: output")
-    close(raw_f, raw_o, 3e-4, what="R size: raw_output")
+        # into ~1e-4 of value -- in the fp32 oracle too, which is what `exact` measures
+        close(x, y, what="R size, fused vs oracle: " + name, exact=z)
+    close(out_f, out_o, what="R size: output", exact=out64)
+    close(raw_f, raw_o, what="R size: raw_output", exact=raw64)
 
 
 @pytest.mark.parametrize("include_self", [False, True])
@@ -406,6 +442,30 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
+def test_time_indices_outside_the_window_are_refused(dev):
+    """gather_time (lvd.py:462-467) raises for an index outside the time axis; the fused kernels index
+    with ctx_ts / pred_ts directly, so the wrappers validate them instead of clamping silently."""
+    from waldo_amd import _lib, functional as WF
+    b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 1, 4, 3, 8, 16
+    inp = torch.randn(b, t, c, hd, wd, device=dev)
+    flow = torch.zeros(b, tc, tp, 2, hd, wd, device=dev)
+    alpha = torch.zeros(b, tc, tp, nl, hd, wd, device=dev)
+    ok = torch.tensor([[[0], [2]]], device=dev)
+    WF.frame_warp_fuse(inp, flow, alpha, ok)
+    for bad in (torch.tensor([[[0], [3]]], device=dev), torch.tensor([[[-1], [1]]], device=dev)):
+        with pytest.raises(_lib.WaldoHipError, match="valid range"):
+            WF.frame_warp_fuse(inp, flow, alpha, bad)
+    flow_lr = torch.zeros(b * tc * tp, nl, 2, hd, wd, device=dev)
+    a01 = torch.rand(b * 2, nl, hd, wd, device=dev)  # window of tw = 2 frames
+    occ = torch.zeros(b, t, nl, nl, device=dev)
+    pred = torch.tensor([2], device=dev)
+    WF.flow_ctx_warp(flow_lr, None, a01, torch.tensor([[[0], [1]]], device=dev), pred, occ, 2, 1)
+    with pytest.raises(_lib.WaldoHipError, match="valid range"):  # inside T, outside the context window
+        WF.flow_ctx_warp(flow_lr, None, a01, ok, pred, occ, 2, 1)
+    with pytest.raises(_lib.WaldoHipError, match="valid range"):
+        WF.flow_ctx_warp(flow_lr, None, a01, torch.tensor([[[0], [1]]], device=dev), torch.tensor([3], device=dev), occ, 2, 1)
+
+
 @pytest.mark.parametrize("restrict,use_disocc,include_self", [(True, False, False), (True, True, False),
                                                               (False, True, False), (True, True, True)])
 def test_decode_output_glue(dev, restrict, use_disocc, include_self):
@@ -427,6 +487,8 @@ def test_decode_output_glue(dev, restrict, use_disocc, include_self):
         grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
         ref = WO.decode_output(cfg, inp, grid_o, O.compute_occ(occ_score), mask * obj_alpha + (1 - mask) * -1.0,
                                bg_alpha, cls, ctx_ts, pred_ts, restrict, use_disocc)
+        ref64 = WO.decode_output(cfg, *dbl((inp, grid_o, O.compute_occ(occ_score), mask * obj_alpha + (1 - mask) * -1.0,
+                                            bg_alpha, cls)), ctx_ts, pred_ts, restrict, use_disocc)
         occ_h, oa_h, ba_h, grid_h = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev),
                                                             obj_pose.to(dev), bg_pose.to(dev), occ_score.to(dev),
                                                             obj_alpha_mask=mask.to(dev))
@@ -434,8 +496,8 @@ def test_decode_output_glue(dev, restrict, use_disocc, include_self):
         close(grid_h[0], grid_o[0], what="tgo")
         got = decode_output(wp, inp.to(dev), [x.to(dev) for x in grid_o], occ_h, oa_h, ba_h, cls.to(dev),
                             ctx_ts.to(dev), pred_ts.to(dev), restrict, use_disocc)
-    for x, y, name in zip(got, ref, ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")):
-        close(x, y, 3e-4 if name in ("output", "raw_output", "raw_alpha") else TOL, what=name)
+    for x, y, z, name in zip(got, ref, ref64, ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")):
+        close(x, y, what=name, exact=z)
 
 
 def test_warper_state_dict_names(dev):

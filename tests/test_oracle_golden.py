@@ -215,3 +215,33 @@ def test_pose_affine_oracle_vs_independent_formula():
     ref = torch.einsum("rnpa,rnab->rnpb", pts, T[:, :, :2]) + T[:, :, 2:3]
     assert out.shape == (r, no, p, 2)
     assert torch.allclose(out.double(), ref, atol=1e-6)
+
+
+def _pose_inputs(g):
+    """The tensors PoseDecoder.forward hands to flp.py:259-273, rebuilt from the golden's head outputs:
+    tanh (flp.py:256) and the optional ``+ last`` of the clip (flp.py:257-259)."""
+    fpc = int(g["frames_per_clip"])
+    head_obj = g["head_obj"].clone().requires_grad_()
+    head_bg = g["head_bg"].clone().requires_grad_()
+    obj, bg = head_obj[:, :, :-1].tanh(), head_bg.tanh()
+    if int(g["use_last"]):
+        obj = obj + g["last_obj"].repeat_interleave(fpc, dim=0)
+        bg = bg + g["last_bg"].repeat_interleave(fpc, dim=0)
+    return head_obj, head_bg, obj, bg
+
+
+@pytest.mark.parametrize("tag", ["plain", "last"])
+def test_pose_affine_golden(golden, tag):
+    """Pins oracle.producers_oracle.pose_affine on the reference's OWN PoseDecoder.forward
+    (models/nets/flp.py:252-273, run by oracle/make_golden.py:gen_pose_affine with an empty transformer
+    and fixed head outputs): control points of the predicted frames and the gradients back to the heads."""
+    from oracle import producers_oracle as PO
+    g = golden(f"pose_affine_{tag}")
+    head_obj, head_bg, obj, bg = _pose_inputs(g)
+    po = PO.pose_affine(obj, g["mul_obj"], g["bias_obj"], g["tgt_pts_obj"].view(-1, 2), float(g["mul_delta_obj"]), 1.0)
+    pb = PO.pose_affine(bg, torch.ones(6), g["bias_bg"], g["tgt_pts_bg"].view(-1, 2), 1.0, float(g["bg_mul"]))
+    assert torch.allclose(po, g["obj_pose"], atol=1e-6) and torch.allclose(pb, g["bg_pose"], atol=1e-6)
+    assert torch.equal(head_obj[:, :, -1].detach(), g["occ_score"])  # flp.py:256: the last channel is the score
+    ((po * g["w1"]).sum() + (pb * g["w2"]).sum()).backward()
+    assert torch.allclose(head_obj.grad, g["grad_head_obj"], atol=1e-6)
+    assert torch.allclose(head_bg.grad, g["grad_head_bg"], atol=1e-6)

@@ -18,6 +18,11 @@ from waldo_amd.nets import flp  # noqa: E402
 from waldo_amd.tools.utils import get_grid  # noqa: E402
 
 dev = torch.device("cuda:0")
+if "--lib" in sys.argv:  # A/B runs: another build of the library (tools_dev/run_lvd_ab.sh)
+    from waldo_amd import _lib
+    _i = sys.argv.index("--lib")
+    _lib.use_library(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 t, no, nl, lo, lb = 5, 16, 20, 16, 128

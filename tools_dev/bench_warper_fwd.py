@@ -10,6 +10,11 @@ opt = types.SimpleNamespace(latent_shape=[8, 16], obj_shape=[4, 4], time_dropout
                             scale_factor=1, dim=128, aspect_ratio=2, load_dim=512, num_perm_grid=1,
                             normalize_alpha=False, use_lyt_filtering=False, use_lyt_opacity=False,
                             weight_cls=False, min_cls=0.0, include_self=False, no_filter=False, allow_ghost=False)
+if "--lib" in sys.argv:  # A/B runs: another build of the library (tools_dev/run_lvd_ab.sh)
+    from waldo_amd import _lib
+    _i = sys.argv.index("--lib")
+    _lib.use_library(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 b, t, no = int(sys.argv[1]) if len(sys.argv) > 1 else 1, 5, 16
 wp = Warper(opt).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)

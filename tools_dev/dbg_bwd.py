@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, '.')
 from oracle import wif_oracle as O  # noqa: E402
 import waldo_amd  # noqa: E402
-from waldo_amd import functional as WF  # noqa: E402
+from waldo_amd import _lib, functional as WF  # noqa: E402
 
 dev = torch.device('cuda:0')
 
@@ -16,7 +16,7 @@ dev = torch.device('cuda:0')
 def run(nl, h, w, f=2, generic=False, seed=3, gocc=True):
     layers, pts, occ, inv, rep = O.make_synthetic(f, nl, h, w, seed=seed, sigma=0.1)
     tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
-    WF._FORCE_GENERIC_BWD = generic
+    _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, int(generic))
     l2 = layers.to(dev).requires_grad_()
     p2 = pts.to(dev).requires_grad_()
     o2 = occ.to(dev).requires_grad_(gocc)
@@ -25,7 +25,7 @@ def run(nl, h, w, f=2, generic=False, seed=3, gocc=True):
     w2 = torch.randn(f, nl, h, w, device=dev)
     rgb, alpha = WF.warp_composite(l2, p2, o2, tps.inverse_kernel, tps.basis_t, return_alpha=True)
     ((rgb * w1).sum() + (alpha * w2).sum()).backward()
-    WF._FORCE_GENERIC_BWD = False
+    _lib.load().waldo_set_debug_option(_lib.DEBUG_BWD_GENERIC, 0)
     return l2.grad.cpu(), p2.grad.cpu(), (o2.grad.cpu() if gocc else None)
 
 

@@ -9,9 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
-os.environ["WALDO_HIP_LIB"] = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "waldo_amd/lib/abl/stamps.so")
 import waldo_amd  # noqa: E402
 from waldo_amd import _lib, functional as WF  # noqa: E402
+_lib.use_library(sys.argv[1] if len(sys.argv) > 1 else "waldo_amd/lib/abl/stamps.so")
 from waldo_amd.tools.utils import get_grid  # noqa: E402
 
 dev = torch.device("cuda:0")

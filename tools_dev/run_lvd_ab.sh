@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do
 for so in waldo_amd/lib/abl/*.so; do
-  echo "$(basename $so): $(WALDO_HIP_LIB=$PWD/$so timeout 300 python tools_dev/bench_lvd_step.py 2>/dev/null | tail -1 | cut -c1-160)"
-  echo "$(basename $so): $(WALDO_HIP_LIB=$PWD/$so timeout 300 python tools_dev/bench_warper_fwd.py 2>/dev/null | tail -1 | cut -c1-200)"
+  echo "$(basename $so): $(timeout 300 python tools_dev/bench_lvd_step.py --lib $PWD/$so 2>/dev/null | tail -1 | cut -c1-160)"
+  echo "$(basename $so): $(timeout 300 python tools_dev/bench_warper_fwd.py --lib $PWD/$so 2>/dev/null | tail -1 | cut -c1-200)"
 done; done

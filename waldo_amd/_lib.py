@@ -12,7 +12,10 @@ import threading
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("WALDO_HIP_LIB") or os.path.join(_HERE, "lib", "libwaldo_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
+# ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
+# library of another version has other prototypes behind the same names and is refused by load()
+ABI_VERSION = 1004
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -69,6 +72,7 @@ PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
 # include/waldo_hip.h: test-only switches between kernel variants (waldo_set_debug_option)
 DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
+DEBUG_BWD_GENERIC = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -78,8 +82,18 @@ class WaldoHipError(RuntimeError):
     pass
 
 
+def use_library(path):
+    """Bind another build of the library (developer A/B runs: tools_dev/).  Only before the first call
+    of any op -- the process keeps ONE library; nothing reads the environment."""
+    global LIB_PATH
+    with _lock:
+        if _lib is not None:
+            raise WaldoHipError(f"use_library({path!r}): {LIB_PATH} is already loaded")
+        LIB_PATH = os.path.abspath(path)
+
+
 def load():
-    """Open the library (once) and declare every prototype.  Raises if it is absent."""
+    """Open the library (once) and declare every prototype.  Raises if it is absent or of another ABI."""
     global _lib
     if _lib is not None:
         return _lib
@@ -91,6 +105,12 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -m waldo_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        lib.waldo_version.restype = _int
+        lib.waldo_version.argtypes = []
+        if lib.waldo_version() != ABI_VERSION:
+            raise WaldoHipError(
+                f"{LIB_PATH} has ABI version {lib.waldo_version()}, this binding needs {ABI_VERSION}: "
+                "rebuild it with `python -m waldo_amd.build --force`")
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes

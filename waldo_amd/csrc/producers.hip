@@ -265,10 +265,16 @@ extern "C" int waldo_compute_occ_bwd(const float* score, const float* grad_occ, 
   return launch_status("waldo_compute_occ_bwd");
 }
 
-static int check_head(const char* fn, int64_t N, int C, int h, int w, int scale, int mode) {
+static int check_head(const char* fn, int64_t N, int C, int h, int w, int scale, int mode, const float* mask) {
   if (N < 0 || C < 1 || h < 1 || w < 1 || scale < 1 || scale > 16 || mode < 0 || mode > 2 ||
       N * C * (int64_t)h * w * scale * scale > 2147483647ll * kBlock || (int64_t)h * w * scale * scale > 2147483647ll) {
     set_error("%s: bad shape N=%lld C=%d h=%d w=%d scale=%d mode=%d", fn, (long long)N, C, h, w, scale, mode);
+    return WALDO_EINVAL;
+  }
+  // the padding mask and the remove / freeze modes are the arithmetic of the ONE-channel object alpha
+  // (lvd.py:128-132); applied to a C > 1 decoder output they would overwrite its colour channels
+  if (C > 1 && (mask != nullptr || mode != 0)) {
+    set_error("%s: mask / remove / freeze act on the one-channel object alpha only (C=%d)", fn, C);
     return WALDO_EINVAL;
   }
   return WALDO_OK;
@@ -277,7 +283,7 @@ static int check_head(const char* fn, int64_t N, int C, int h, int w, int scale,
 extern "C" int waldo_alpha_head_fwd(const float* x, const float* prior, const float* mask, float* out,
                                     int64_t N, int C, int h, int w, int scale, float bias,
                                     int has_alpha, int mode, waldo_stream_t stream) {
-  if (int rc = check_head("waldo_alpha_head_fwd", N, C, h, w, scale, mode)) return rc;
+  if (int rc = check_head("waldo_alpha_head_fwd", N, C, h, w, scale, mode, mask)) return rc;
   if (N == 0) return WALDO_OK;
   if (!x || !out) {
     set_error("waldo_alpha_head_fwd: null pointer");
@@ -293,7 +299,7 @@ extern "C" int waldo_alpha_head_bwd(const float* x, const float* prior, const fl
                                     const float* grad_out, float* grad_x, int64_t N, int C, int h,
                                     int w, int scale, float bias, int has_alpha, int mode,
                                     waldo_stream_t stream) {
-  if (int rc = check_head("waldo_alpha_head_bwd", N, C, h, w, scale, mode)) return rc;
+  if (int rc = check_head("waldo_alpha_head_bwd", N, C, h, w, scale, mode, mask)) return rc;
   if (N == 0) return WALDO_OK;
   if (!x || !grad_out || !grad_x) {
     set_error("waldo_alpha_head_bwd: null pointer");

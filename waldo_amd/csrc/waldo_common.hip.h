@@ -307,6 +307,13 @@ __device__ __forceinline__ void stream_store16(float* uniform_base, uint32_t byt
 #else
 #define WALDO_REC_FRAME(f) (f)
 #endif
+// timing-only ablation (-DWALDO_ABL_LAYER_ALIAS=n, wrong values): the staged boxes of every frame are read
+// from frame f % n, i.e. the layer reads are served by the caches instead of HBM
+#ifdef WALDO_ABL_LAYER_ALIAS
+#define WALDO_LAYER_FRAME(f) ((f) % WALDO_ABL_LAYER_ALIAS)
+#else
+#define WALDO_LAYER_FRAME(f) (f)
+#endif
 #ifndef WALDO_REC_STORE_POLICY
 #define WALDO_REC_STORE_POLICY 2
 #endif

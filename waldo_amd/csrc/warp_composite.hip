@@ -58,7 +58,7 @@ extern "C" int waldo_max_layers(void) { return kMaxLayers; }
 
 extern "C" int64_t waldo_warp_composite_bwd_workspace_bytes(int64_t F, int L, int H, int W,
                                                             int K3) {
-  if (F < 0 || L < 1 || H < 1 || W < 1) return 0;
+  if (F < 0 || L < 1 || H < 1 || W < 1 || debug_option(WALDO_DEBUG_BWD_GENERIC)) return 0;
   return bwd_workspace_bytes(F, L, H, W, K3);
 }
 
@@ -123,7 +123,7 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int64_t need = bwd_workspace_bytes(F, L, H, W, K3);
+  const int64_t need = debug_option(WALDO_DEBUG_BWD_GENERIC) ? 0 : bwd_workspace_bytes(F, L, H, W, K3);
   if (workspace != nullptr && (need == 0 || workspace_bytes < need)) {
     if (need != 0) {
       set_error("waldo_warp_composite_bwd: workspace of %lld bytes given, %lld needed",

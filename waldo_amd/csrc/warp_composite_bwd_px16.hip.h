@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + ((int64_t)f * L + lc) * 4 * HW;
+      const float* src = layers + ((int64_t)WALDO_LAYER_FRAME(f) * L + lc) * 4 * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
       const int bw2 = bw[l] >> 1, n = fits[l] ? bh[l] * bw2 : 1;

@@ -38,6 +38,9 @@
 
 namespace waldo {
 
+#ifndef WALDO_FWD12_WAVES
+#define WALDO_FWD12_WAVES 3  // waves per SIMD the L = 9 .. 12 forward is compiled for
+#endif
 #ifndef WALDO_STAGE_AHEAD
 #define WALDO_STAGE_AHEAD 2  // layers whose box loads are in flight at a time (measured 2 / 3 / 4 / 6 / 8:
                              // fwd 0.726 / 0.728 / 0.736 / 0.836 / 0.990 ms, bwd 2.222 / 2.225 / 2.242 / 2.58 / 2.59)
@@ -169,7 +172,7 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // forward-only path then is ONE kernel (at 8 frames of 128 x 128 the separate mapping kernel and
 // its launch gap were a quarter of the call).
 template <int LP, bool EXL, bool FOLD>
-__global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd_lds_kernel(
+__global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 12 ? WALDO_FWD12_WAVES : 2))) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
     const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 12 ? 3 : 2)) void warp_composite_fwd
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
-      const float* src = layers + ((int64_t)f * L + lc) * 4 * HW;
+      const float* src = layers + ((int64_t)WALDO_LAYER_FRAME(f) * L + lc) * 4 * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
       const bool fits = bh[l] * bw[l] <= kStageCap;

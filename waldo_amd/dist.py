@@ -14,13 +14,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, single_rank_group=False):
     """env:// initialisation mirroring the reference's Engine (tools/engine.py:17-35) without its
-    SLURM branch.  Returns (rank, local_rank, world_size).  A single process needs no group."""
+    SLURM branch.  Returns (rank, local_rank, world_size).  A single process needs no group;
+    ``single_rank_group`` creates one anyway (the reference's Engine does, tools/engine.py:35: the
+    collectives of a world of one then still go through RCCL -- what the one-GPU test box can run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -56,11 +58,12 @@ def shard_frames(tensors, frames, rank, world, layers=None):
     return out
 
 
-def all_gather_frames(local, frames, group=None):
+def all_gather_frames(local, frames, group=None, collective_for_one=False):
     """Gather every rank's block of composited frames (n_local, C, H, W) into (frames, C, H, W) on
     every rank.  Blocks may be ragged (shard_range): the payload is padded to the common block size,
-    gathered with one all_gather_into_tensor and trimmed."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    gathered with one all_gather_into_tensor and trimmed.  A world of one returns its block as it is
+    unless ``collective_for_one`` asks for the collective anyway (tests: the RCCL call on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not collective_for_one):
         assert local.shape[0] == frames
         return local
     world = dist.get_world_size(group)

@@ -4,6 +4,8 @@ Every function here launches hand-written gfx950 kernels on the caller's current
 function has a CPU or eager-PyTorch fallback (``_lib.check_cuda`` raises on CPU tensors).
 PyTorch is used for memory (output allocation), streams and autograd bookkeeping only.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -13,8 +15,33 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# test hook: route waldo_warp_composite_bwd to the generic per-tap-atomics kernel
-_FORCE_GENERIC_BWD = False
+_INDEX_CHECKED = {}  # id(index tensor) -> (weak reference to it, {(version, limit)} already validated)
+
+
+def _checked_set(ts):
+    key = id(ts)
+    ent = _INDEX_CHECKED.get(key)
+    if ent is None or ent[0]() is not ts:  # (tensors compare element-wise: identity, not ==)
+        ent = (weakref.ref(ts, lambda _ref, k=key: _INDEX_CHECKED.pop(k, None)), set())
+        _INDEX_CHECKED[key] = ent
+    return ent[1]
+
+
+def _check_time_index(fn, name, ts, limit):
+    """The reference's ``gather_time`` (models/nets/lvd.py:462-467, ``tensor.gather(1, ts)``) raises for an
+    index outside [0, limit); the fused kernels index with it directly, so it is validated here instead of
+    being clamped silently.  Costs one device -> host read per distinct (tensor, version) -- a loop that
+    reuses its index tensors pays it once -- and nothing while a HIP graph is being captured."""
+    if ts.numel() == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    seen = _checked_set(ts)
+    key = (ts._version, int(limit))
+    if key in seen:
+        return
+    lo, hi = (int(v) for v in torch.aminmax(ts))
+    if lo < 0 or hi >= limit:
+        raise _lib.WaldoHipError(f"{fn}: {name} holds indices in [{lo}, {hi}], valid range is [0, {int(limit) - 1}]")
+    seen.add(key)
 
 
 # --------------------------------------------------------------------------------------
@@ -618,6 +645,8 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
         raise _lib.WaldoHipError(
             f"flow_ctx_warp: inconsistent shapes flow_lr={tuple(flow_lr.shape)} a01={tuple(a01.shape)} "
             f"ctx_ts={tuple(ctx_ts.shape)} pred_ts={tuple(pred_ts.shape)} occ={tuple(occ.shape)}")
+    _check_time_index("flow_ctx_warp", "ctx_ts", ctx_ts, tw)
+    _check_time_index("flow_ctx_warp", "pred_ts", pred_ts, t)
     if isobj_lr is not None:
         _lib.check_cuda(isobj_lr)
         isobj_lr = _c(isobj_lr.detach())
@@ -679,6 +708,7 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
         raise _lib.WaldoHipError(
             f"frame_warp_fuse: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
             f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
+    _check_time_index("frame_warp_fuse", "ctx_ts", ctx_ts, t)
     return _FrameWarpFuse.apply(input, flow, alpha, ctx_ts, bool(include_self), eps)
 
 
@@ -720,8 +750,8 @@ class _WarpComposite(torch.autograd.Function):
             grad_alpha = _c(grad_alpha)
         gm = torch.zeros_like(mapping) if ctx.needs_input_grad[1] else None
         go = torch.zeros_like(occ) if ctx.needs_input_grad[2] else None
-        ws_bytes = 0 if _FORCE_GENERIC_BWD else \
-            _lib.load().waldo_warp_composite_bwd_workspace_bytes(f, nl, h, w, k3)
+        # 0: the shape is served by the generic kernel (or a test asked for it: WALDO_DEBUG_BWD_GENERIC)
+        ws_bytes = _lib.load().waldo_warp_composite_bwd_workspace_bytes(f, nl, h, w, k3)
         ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=layers.device) if ws_bytes else None
         # with a workspace the two-kernel path writes every texel of grad_layers exactly once;
         # the generic kernel accumulates with atomics into a zero-filled buffer

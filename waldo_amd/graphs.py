@@ -37,7 +37,7 @@ class GraphedCall:
                 if dst.shape != src.shape or dst.dtype != src.dtype:
                     raise ValueError(f"graphed call was captured for {tuple(dst.shape)} {dst.dtype}, "
                                      f"got {tuple(src.shape)} {src.dtype}")
-                if dst.data_ptr() != src.data_ptr():
+                if src is not dst:  # identity only: a view or a recycled pointer may alias other contents
                     dst.copy_(src)
         self._graph.replay()
         return self._out
