@@ -210,7 +210,11 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
  *   input (B,T,C,Hd,Wd); flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1];
  *   ctx_ts (B,Tc,Tp) int64; Tc' = Tc + (include_self ? 1 : 0) <= 8; include_self needs Tp == T
  *   out (B,Tp,C+1,Hd,Wd)  fused frames, last channel = fused (2 score - 1)
- *   raw (B,Tc',Tp,C+L,Hd,Wd)  per-context warped frames and alphas (the WIF input, wif.py:21)
+ *   raw (B,Tp,Tc',C+L,Hd,Wd)  per-context warped frames and alphas (the WIF input, wif.py:21), stored
+ *                             with the PREDICTED frame ahead of the context: the reference's
+ *                             (B,Tc',Tp,...) tensor is the view raw.permute(0,2,1,3,4,5) (strides, no
+ *                             copy), and WIF.forward's own permute + contiguous (wif.py:39) -- a copy of
+ *                             the largest tensor of the pipeline -- finds it already in place
  * ------------------------------------------------------------------------------------- */
 int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
                               const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,

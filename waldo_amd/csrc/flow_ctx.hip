@@ -30,20 +30,20 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, float* __restrict__ a01,
     float* __restrict__ alpha_out, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W,
-    int scale, int tiles) {
+    int scale, int units, int tiles, int nbands) {
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
-  const int n = blockIdx.x / tiles;  // (b, t) with t < Tw
+  int n, x, y;  // n = (b, t) with t < Tw
+  if (!hd_pixel(units, Hd, Wd, tiles, nbands, n, x, y)) return;
   const int b = n / Tw, t = n % Tw;
-  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  const int64_t p = (int64_t)y * Wd + x;
   // the objects' class distributions of this batch entry: broadcast reads from LDS
   __shared__ float sdist[(32 - 1) * kMaxCls];
   const int No = L - 1;
   if (dist != nullptr)
     for (int i = threadIdx.x; i < No * Nl; i += kBlock) sdist[i] = dist[(int64_t)b * No * Nl + i];
   __syncthreads();
-  if (p >= HWd) return;
-  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  if (x >= Wd || y >= Hd) return;
   const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
 
   float a[LP];
@@ -104,14 +104,13 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
     float* __restrict__ alpha_ctx, float* __restrict__ disocc, int T, int Tw, int Tc, int Tp, int L,
-    int H, int W, int scale, int tiles) {
+    int H, int W, int scale, int units, int tiles, int nbands) {
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
-  const int m = blockIdx.x / tiles;  // (b, tc, tp)
+  int m, x, y;  // m = (b, tc, tp)
+  if (!hd_pixel(units, Hd, Wd, tiles, nbands, m, x, y) || x >= Wd || y >= Hd) return;
   const int tp = m % Tp, b = m / (Tc * Tp);
-  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
-  if (p >= HWd) return;
-  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  const int64_t p = (int64_t)y * Wd + x;
   const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
   // frame of the context alpha (clamped: the index comes from device memory) and of the order
   const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1));
@@ -176,13 +175,12 @@ template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
     const int64_t* __restrict__ ctx_ts, float* __restrict__ out, float* __restrict__ raw, int T, int Tc,
-    int Tp, int C, int L, int Hd, int Wd, int include_self, float eps, int tiles) {
+    int Tp, int C, int L, int Hd, int Wd, int include_self, float eps, int units, int tiles, int nbands) {
   const int64_t HWd = (int64_t)Hd * Wd;
-  const int n = blockIdx.x / tiles;  // (b, tp)
+  int n, x, y;  // n = (b, tp)
+  if (!hd_pixel(units, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
   const int b = n / Tp, tp = n % Tp;
-  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
-  if (p >= HWd) return;
-  const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+  const int64_t p = (int64_t)y * Wd + x;
   float gx0, gy0;
   identity_grid(x, y, Wd, Hd, gx0, gy0);
 
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1));
     frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
     const float* al = alpha + m * L * HWd + p;
-    float* rw = raw + ((((int64_t)b * Tcx + tcc) * Tp + tp) * (C + L) + C) * HWd + p;
+    float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + tcc) * (C + L) + C) * HWd + p;
     float s = 0.0f;
     for (int l = 0; l < L; ++l) {
       const float av = al[(int64_t)l * HWd];
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     ssum += real ? fabsf(s + eps) : 0.0f;
   }
   if (include_self) {
-    float* rw = raw + ((((int64_t)b * Tcx + Tc) * Tp + tp) * (C + L) + C) * HWd + p;
+    float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + Tc) * (C + L) + C) * HWd + p;
     for (int l = 0; l < L; ++l) rw[(int64_t)l * HWd] = 1.0f;
     ssum += fabsf(1.0f + eps);
   }
@@ -232,25 +230,51 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
 #pragma unroll
   for (int tc = 0; tc < TCP; ++tc) wt[tc] = (tc < Tc) ? (sc[tc] + eps) / den : 0.0f;
   const float* self = input + ((int64_t)b * T + min(tp, T - 1)) * C * HWd + p;
-  float* rbase = raw + ((int64_t)b * Tcx * Tp + tp) * (C + L) * HWd + p;  // context tc: + tc * Tp * (C+L) * HWd
+  float* rbase = raw + ((int64_t)b * Tp + tp) * Tcx * (C + L) * HWd + p;  // context tc: + tc * (C+L) * HWd
   float* obase = out + ((int64_t)b * Tp + tp) * (C + 1) * HWd + p;
-  for (int c = 0; c < C; ++c) {
-    float acc = 0.0f;
+  // Channel loop, software-pipelined by hand: the sixteen tap loads of channel c + 1 are issued BEFORE the
+  // stores of channel c.  Vector-memory operations retire in issue order (loads, stores: one counter), so
+  // with the stores first every channel's taps would wait for the previous channel's stores to reach
+  // memory -- gathers and stores then take turns instead of overlapping (timing ablations at the C5 size:
+  // 4.5 ms as written that way, 3.3 without the raw stores, 3.3 without the gathers, 1.7 without both).
+  float tv[TCP][4];
+  auto load_taps = [&](int c, float (&v)[TCP][4]) {
 #pragma unroll
     for (int tc = 0; tc < TCP; ++tc) {
       const float* plane = frame[tc] + (int64_t)c * HWd;
-      const float v00 = ldb(plane, o00[tc]), v01 = ldb(plane, o01[tc]);
-      const float v10 = ldb(plane, o10[tc]), v11 = ldb(plane, o11[tc]);
-      const float v = fmaf(v11, w11[tc], fmaf(v10, w10[tc], fmaf(v01, w01[tc], v00 * w00[tc])));
-      if (tc < Tc) rbase[((int64_t)tc * Tp * (C + L) + c) * HWd] = v;
+#ifdef WALDO_ABL_FWF_NOGATHER  // timing-only ablation: one coalesced load instead of the four taps
+      v[tc][0] = v[tc][1] = v[tc][2] = v[tc][3] = plane[p];
+#else
+      v[tc][0] = ldb(plane, o00[tc]);
+      v[tc][1] = ldb(plane, o01[tc]);
+      v[tc][2] = ldb(plane, o10[tc]);
+      v[tc][3] = ldb(plane, o11[tc]);
+#endif
+    }
+  };
+  load_taps(0, tv);
+  for (int c = 0; c < C; ++c) {
+    float nv[TCP][4];
+    load_taps(min(c + 1, C - 1), nv);  // the last trip re-reads its own channel: no branch around the loads
+    const float vself = include_self ? self[(int64_t)c * HWd] : 0.0f;
+    float acc = 0.0f;
+#pragma unroll
+    for (int tc = 0; tc < TCP; ++tc) {
+      const float v = fmaf(tv[tc][3], w11[tc], fmaf(tv[tc][2], w10[tc], fmaf(tv[tc][1], w01[tc], tv[tc][0] * w00[tc])));
+#ifndef WALDO_ABL_FWF_NORAW  // timing-only ablation: without the per-context stores
+      if (tc < Tc) rbase[((int64_t)tc * (C + L) + c) * HWd] = v;
+#endif
       acc += v * wt[tc];
     }
     if (include_self) {
-      const float v = self[(int64_t)c * HWd];
-      rbase[((int64_t)Tc * Tp * (C + L) + c) * HWd] = v;
-      acc += v * wself;
+      rbase[((int64_t)Tc * (C + L) + c) * HWd] = vself;
+      acc += vself * wself;
     }
     obase[(int64_t)c * HWd] = acc;
+#pragma unroll
+    for (int tc = 0; tc < TCP; ++tc)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tv[tc][k] = nv[tc][k];
   }
   float acc = 0.0f;  // the score channel
 #pragma unroll
@@ -266,8 +290,7 @@ static int check_flow_ctx(const char* fn, int64_t N, int L, int H, int W, int sc
               fn, (long long)N, L, H, W, scale);
     return WALDO_EINVAL;
   }
-  const int64_t tiles = ((int64_t)H * scale * W * scale + kBlock - 1) / kBlock;
-  if (N * tiles > 2147483647) {
+  if (hd_grid(N, hd_geom(N, H * scale, W * scale)) > 2147483647) {
     set_error("%s: problem too large for one launch", fn);
     return WALDO_EINVAL;
   }
@@ -280,8 +303,8 @@ using namespace waldo;
 
 #define WALDO_FC_CASE(LPV, KERNEL, ...)                                                      \
   case LPV:                                                                                  \
-    hipLaunchKernelGGL((KERNEL<LPV>), dim3((unsigned)(N * tiles)), dim3(kBlock), 0, st,      \
-                       __VA_ARGS__);                                                         \
+    hipLaunchKernelGGL((KERNEL<LPV>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st, \
+                       __VA_ARGS__, (int)N, geom.tiles, geom.nbands);                        \
     break;
 
 extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const float* dist,
@@ -303,14 +326,14 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
+  const HdGeom geom = hd_geom(N, H * scale, W * scale);
   switch (flow_ctx_pad_l(L)) {
-    WALDO_FC_CASE(4, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
-    WALDO_FC_CASE(8, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
-    WALDO_FC_CASE(12, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
-    WALDO_FC_CASE(17, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
-    WALDO_FC_CASE(24, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
-    WALDO_FC_CASE(32, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles)
+    WALDO_FC_CASE(4, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FC_CASE(8, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FC_CASE(12, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FC_CASE(17, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FC_CASE(24, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FC_CASE(32, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
   }
   return launch_status("waldo_flow_ctx_alpha_fwd");
 }
@@ -333,14 +356,14 @@ extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
+  const HdGeom geom = hd_geom(N, H * scale, W * scale);
   switch (flow_ctx_pad_l(L)) {
-    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
-    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
-    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
-    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
-    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
-    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale, tiles)
+    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
   }
   return launch_status("waldo_flow_ctx_warp_fwd");
 }
@@ -356,8 +379,9 @@ extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, 
               include_self, kFwMaxCtx);
     return WALDO_EINVAL;
   }
-  const int64_t tiles = ((int64_t)Hd * Wd + kBlock - 1) / kBlock;
-  if ((int64_t)B * Tp * tiles > 2147483647) {
+  const int64_t units = (int64_t)B * Tp;
+  const HdGeom geom = hd_geom(units, Hd, Wd);
+  if (hd_grid(units, geom) > 2147483647) {
     set_error("waldo_frame_warp_fuse_fwd: problem too large for one launch");
     return WALDO_EINVAL;
   }
@@ -366,12 +390,12 @@ extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, 
     set_error("waldo_frame_warp_fuse_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  const dim3 grid((unsigned)((int64_t)B * Tp * tiles));
+  const dim3 grid((unsigned)hd_grid(units, geom));
   if (Tc <= 4)
     hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)tiles);
+                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   else
     hipLaunchKernelGGL(frame_warp_fuse_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)tiles);
+                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   return launch_status("waldo_frame_warp_fuse_fwd");
 }

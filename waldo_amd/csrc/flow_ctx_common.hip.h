@@ -65,6 +65,42 @@ __device__ __forceinline__ void identity_grid(int x, int y, int Wd, int Hd, floa
   gy0 = (y < Hd / 2) ? sy + stepy * (float)y : ey - stepy * (float)(Hd - 1 - y);
 }
 
+// ---------------------------------------------------------------------------------------
+// Pixels of a workgroup on the full-resolution raster.  A workgroup covers a TILE of 4 rows x 64
+// columns (one row segment per wavefront: every plane access stays a coalesced 256-byte run), and the
+// tiles of one outer unit (a frame of the batch) go to ONE XCD in row-major order (xcd_decode_banded;
+// placement is for speed only).  With the linear 256-pixel strips these kernels started with,
+// consecutive strips went to different XCDs: the tap row a wavefront shares with the one below, the
+// low-resolution texels an x S upsampling re-reads S x S times and the 128-byte lines neighbouring
+// strips split were fetched once per XCD -- rocprofv3 showed frame_warp_fuse fetching 2.4 x (and
+// flow_ctx_warp 4.8 x) the bytes it has to read at the KITTI recipe (profiles/r03_pipeline_C4_*).
+// ---------------------------------------------------------------------------------------
+constexpr int kHdRows = 4, kHdCols = 64;
+static_assert(kHdRows * kHdCols == kBlock && kHdCols == kWave, "one 64-pixel row segment per wavefront");
+
+struct HdGeom {
+  int tiles, nbands;
+};
+inline HdGeom hd_geom(int64_t units, int Hd, int Wd) {
+  HdGeom g;
+  g.tiles = ((Hd + kHdRows - 1) / kHdRows) * ((Wd + kHdCols - 1) / kHdCols);
+  g.nbands = xcd_bands((int)(units % 8 == 0 ? 8 : units % 8));  // 8 / gcd(units, 8)
+  return g;
+}
+inline int64_t hd_grid(int64_t units, const HdGeom& g) { return xcd_grid_banded(units, g.nbands, g.tiles, 1); }
+
+// unit and pixel (x, y) of this thread; false: the whole workgroup has nothing to do (uniform).  The
+// pixel may lie outside the raster (x >= Wd or y >= Hd at the right / bottom edge): callers test it.
+__device__ __forceinline__ bool hd_pixel(int units, int Hd, int Wd, int tiles, int nbands, int& unit, int& x, int& y) {
+  int tile, rest_;
+  if (!xcd_decode_banded(blockIdx.x, units, nbands, tiles, 1, unit, tile, rest_)) return false;
+  const int ntx = (Wd + kHdCols - 1) / kHdCols;
+  const int ty = tile / ntx;
+  x = (tile - ty * ntx) * kHdCols + (int)(threadIdx.x & (kWave - 1));
+  y = ty * kHdRows + (int)(threadIdx.x >> 6);
+  return true;
+}
+
 constexpr int kFwMaxCtx = 8;  // contexts (incl. self) of the fused frame warp
 
 inline int flow_ctx_pad_l(int L) {

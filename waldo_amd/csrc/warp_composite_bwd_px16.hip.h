@@ -161,7 +161,14 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
   const float half_size_m1 = 0.5f * (float)(((arow & 1) ? H : W) - 1);
   const int f0 = chunk * frames_per_block;
   const int f1 = min(F, f0 + frames_per_block);
+  const int lane_k = lane, arow_k = arow, kk_k = kk, pix_k = pix;
   for (int f = f0; f < f1; ++f) {
+    // The per-thread indices are re-materialised every frame.  Left visible as loop invariants, hipcc 7.2
+    // computes every LDS / global address derived from them ONCE per kernel -- dozens of VGPRs of
+    // base + constant -- and spills what does not fit; each reload then sits behind an s_waitcnt vmcnt(0),
+    // i.e. behind the frame's record stores (vector-memory operations retire in issue order).
+    int lane = lane_k, arow = arow_k, kk = kk_k, pix = pix_k;
+    asm volatile("" : "+v"(lane), "+v"(arow), "+v"(kk), "+v"(pix));
     const float* oc = occ + (int64_t)f * L * L;
     WALDO_STAMP(0);
     // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (see
@@ -308,7 +315,8 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     // a rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
     // layer l leaves its registers for LDS); the image is double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_K1_STAGE_AHEAD ? LP : WALDO_K1_STAGE_AHEAD;
-    const int item_l = threadIdx.x;
+    int item_l = threadIdx.x;
+    asm volatile("" : "+v"(item_l));
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {
       const int lc = EXL ? l : min(l, L - 1);
@@ -624,7 +632,12 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
           for (int r = 0; r < 4; ++r) gg[((wave * 2 + mt) * NT + nt) * 256 + r * 64 + lane] = macc[mt][nt][r];
       __syncthreads();
-      for (int o = threadIdx.x; o < 2 * NT * 256; o += kBlock) {
+      // wave-uniform base + 32-bit index: a per-thread 64-bit address here was hoisted out of the frame
+      // loop, spilled, and its reload (s_waitcnt vmcnt(0)) made every frame wait for the record stores
+      float* gp = gmap_partial + ((int64_t)f * ntiles + tile) * gmap_partial_floats(L);
+#pragma unroll
+      for (int o0 = 0; o0 < 2 * NT * 256; o0 += kBlock) {
+        const int o = o0 + (int)threadIdx.x;
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) sum += gg[w * 2 * NT * 256 + o];  // fixed order
@@ -632,9 +645,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         const int k = mt * 16 + (ln >> 4) * 4 + r;
         const int col = nt * 16 + (ln & 15);
         const int l = col >> 1;
-        if (k < K3 && l < L)
-          gmap_partial[((int64_t)f * ntiles + tile) * gmap_partial_floats(L) + ((int64_t)l * K3 + k) * 2 +
-                       (col & 1)] = sum;
+        if (k < K3 && l < L) gp[(l * K3 + k) * 2 + (col & 1)] = sum;
       }
     }
     __syncthreads();  // the stage region, boxred and wbound are re-used by the next frame

@@ -39,7 +39,11 @@
 namespace waldo {
 
 #ifndef WALDO_FWD12_WAVES
-#define WALDO_FWD12_WAVES 3  // waves per SIMD the L = 9 .. 12 forward is compiled for
+#define WALDO_FWD12_WAVES 4  // waves per SIMD the L = 12 forward is compiled for (125 VGPRs without a spill once the
+                             // per-thread indices are re-materialised per frame; L = 9 .. 11 spills there: 3)
+#endif
+#ifndef WALDO_FWD8_WAVES
+#define WALDO_FWD8_WAVES 3   // register cap of the L <= 8 forward (it needs 109: four waves per SIMD)
 #endif
 #ifndef WALDO_STAGE_AHEAD
 #define WALDO_STAGE_AHEAD 2  // layers whose box loads are in flight at a time (measured 2 / 3 / 4 / 6 / 8:
@@ -172,7 +176,7 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // forward-only path then is ONE kernel (at 8 frames of 128 x 128 the separate mapping kernel and
 // its launch gap were a quarter of the call).
 template <int LP, bool EXL, bool FOLD>
-__global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 12 ? WALDO_FWD12_WAVES : 2))) void warp_composite_fwd_lds_kernel(
+__global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
     const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
@@ -243,7 +247,13 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 12 ? WALDO_FWD12_WAVE
   // pixel-unit grid: the MFMA column of this lane is an x column (even) or a y column (odd)
   const float half_size = 0.5f * (float)((arow & 1) ? H : W);
   const float half_size_m1 = 0.5f * (float)(((arow & 1) ? H : W) - 1);
+  const int lane_k = lane, arow_k = arow, kk_k = kk;
   for (int f = f0; f < f1; ++f) {
+    // The per-thread indices are re-materialised every frame: left visible as loop invariants, hipcc 7.2
+    // computes every LDS / global address derived from them once per kernel (dozens of VGPRs of
+    // base + constant that it then keeps live across the whole frame loop, or spills).
+    int lane = lane_k, arow = arow_k, kk = kk_k;
+    asm volatile("" : "+v"(lane), "+v"(arow), "+v"(kk));
     // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (scaled_map):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
     f32x4 acc[4][NT];
@@ -364,7 +374,8 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? 3 : (LP <= 12 ? WALDO_FWD12_WAVE
     // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
     static_assert(kStageCap / 2 == kBlock, "one box item per lane");
-    const int item_l = threadIdx.x;
+    int item_l = threadIdx.x;
+    asm volatile("" : "+v"(item_l));
     float s[LP][4];
     StageRegs stg[LP];  // fully unrolled: a layer's registers live from its load to its LDS store
     auto issue = [&](int l) {

@@ -665,14 +665,17 @@ class _FrameWarpFuse(torch.autograd.Function):
         _, tc, tp, nl = alpha.shape[:4]
         tcx = tc + (1 if include_self else 0)
         out = input.new_empty(b, tp, c + 1, hd, wd)
-        raw = input.new_empty(b, tcx, tp, c + nl, hd, wd)
+        # stored (B, Tp, Tc', ...) and handed out as the reference's (B, Tc', Tp, ...) VIEW: WIF.forward's
+        # permute(0, 2, 1, ...).contiguous() (wif.py:39) then is a no-op instead of a copy of the
+        # pipeline's largest tensor (C4 recipe: 11.8 GB read + written per predict)
+        raw = input.new_empty(b, tp, tcx, c + nl, hd, wd)
         with torch.cuda.device(input.device):
             _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
                       _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
                       1 if include_self else 0, float(eps), _lib.current_stream(input.device))
         ctx.save_for_backward(input, flow, alpha, ctx_ts)
         ctx.cfg = (bool(include_self), float(eps))
-        return out, raw
+        return out, raw.permute(0, 2, 1, 3, 4, 5)
 
     @staticmethod
     def backward(ctx, g_out, g_raw):
