@@ -326,15 +326,17 @@ int waldo_warp_composite_pts_fwd(const float* layers, const float* basis_t,
  *       4 | W: pixel kernel + per-source-tile gather, no global atomics, bitwise reproducible
  *       grad_layers / grad_mapping); NULL -- and every other shape, for which the size query
  *       returns 0 -- selects the generic per-tap-atomics kernel.
- *   Precision of grad_layers on the two-kernel path: every 32x64-texel tile of a layer's gradient
- *       is summed in 32-bit FIXED POINT, one power-of-two quantum for its three colour planes and
- *       one for its alpha plane, chosen from an upper bound of the tile's sums so that nothing can
- *       overflow: quantum ~ 2^-17 of the largest possible sum of the group in that tile.  The
- *       error of a texel is therefore ABSOLUTE per tile and group (a few quanta), not relative to
- *       the texel: gradients several orders of magnitude below their tile's largest lose relative
- *       precision (the generic path keeps fp32 relative precision).  An infinity or NaN among the
- *       contributions that can reach a tile turns that whole tile (all four planes) into NaN --
- *       never into finite garbage.
+ *   Precision of grad_layers on the two-kernel path: a layer's gradient is summed in 32-bit FIXED
+ *       POINT per 8x16-texel sub-block (of the 32x64-texel tile a workgroup owns), one power-of-two
+ *       quantum for the sub-block's three colour planes and one for its alpha plane, chosen from an
+ *       upper bound of the sub-block's sums so that nothing can overflow: quantum ~ 2^-17 of the
+ *       largest possible sum of the group in that sub-block.  The error of a texel is therefore
+ *       ABSOLUTE per sub-block and group (a few quanta), not relative to the texel: gradients several
+ *       orders of magnitude below the largest ones of their 8x16 neighbourhood lose relative
+ *       precision (the generic path keeps fp32 relative precision); a region of small gradients
+ *       next to a region of large ones keeps its own.  An infinity or NaN among the contributions
+ *       that can reach a tile turns that whole tile (all four planes) into NaN -- never into finite
+ *       garbage.
  *   grad_layers (F,L,4,H,W): with a workspace it is OVERWRITTEN (every texel written once);
  *       without, it must be ZERO-FILLED by the caller (accumulated with float atomics);
  *   grad_mapping (F*L,K3,2): must be ZERO-FILLED by the caller (accumulated into); NULL to skip;

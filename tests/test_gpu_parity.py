@@ -502,8 +502,10 @@ def test_fixed_point_precision_inside_a_tile(dev):
     gradient is made 1000x larger than the colour planes' (separate scales: the colour planes must
     keep their precision), and half of the tile's pixels carry a 1e-3x smaller incoming gradient.
     Per texel against the generic kernel (float atomics, fp32 relative precision): the documented
-    ABSOLUTE bound per tile and channel group, 2^-12 of the group's largest magnitude -- observed
-    errors are orders of magnitude below; the test pins the contract of include/waldo_hip.h."""
+    ABSOLUTE bound per channel group, 2^-12 of the group's largest magnitude -- observed errors are
+    orders of magnitude below -- and, since round 3, scales per 8x16 SUB-BLOCK: the texels of the
+    small half that no large contribution can reach keep 1e-4-level RELATIVE precision (with one
+    scale per tile they had percent-level: ADVICE round 2); the test pins include/waldo_hip.h."""
     f, nl, h, w = 1, 4, 32, 64
     layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=8, smooth=4, sigma=0.03)
     ctrl = O.get_grid(4, 4).view(-1, 2)
@@ -526,6 +528,12 @@ def test_fixed_point_precision_inside_a_tile(dev):
     err_small = (gt[:, :, :3, :, 4: w // 2 - 8] - small).abs().max().item()
     print(f"[fixed point] small half: max err {err_small:.3e}, max |grad| {small.abs().max().item():.3e}")
     assert err_small <= 5e-2 * small.abs().max().item(), (err_small, small.abs().max().item())
+    # the first sub-block column (texels 0 .. 15): no footprint box of the large half reaches it (the
+    # warp moves a pixel by about one texel here), so its quantum follows ITS OWN bound
+    own = gg[:, :, :3, :, 2:14]
+    err_own = (gt[:, :, :3, :, 2:14] - own).abs().max().item()
+    print(f"[fixed point] sub-blocks of the small half: max err {err_own:.3e}, max |grad| {own.abs().max().item():.3e}")
+    assert err_own <= 2e-4 * own.abs().max().item(), (err_own, own.abs().max().item())
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 64, 96), (3, 5, 40, 72)])

@@ -325,43 +325,6 @@ __global__ __launch_bounds__(kBlock) void warp_composite_bwd_kernel(
 //     1-texel bilinear overlap), and shared texels would need atomics; the scatter is therefore
 //     organised by SOURCE tile (exclusive ownership), which is what the records buy.
 // ---------------------------------------------------------------------------------------
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using short2_ = __attribute__((ext_vector_type(2))) short;
-
-__device__ __forceinline__ int pk_min(int a, int b) {
-  short2_ x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  short2_ r = __builtin_elementwise_min(x, y);
-  int o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
-}
-
-// Reductions over each group of 16 consecutive lanes with DPP row rotations (row_ror:8/4/2/1):
-// plain VALU moves, no LDS crossbar (ds_bpermute) and no lgkmcnt waits.  A rotation is not an
-// xor exchange, but min / + over all 16 lanes only needs every lane to meet every other once.
-template <int ROR>
-__device__ __forceinline__ int row_ror_i(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0x120 + ROR, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ int group16_pk_min(int v) {
-  v = pk_min(v, row_ror_i<8>(v));
-  v = pk_min(v, row_ror_i<4>(v));
-  v = pk_min(v, row_ror_i<2>(v));
-  v = pk_min(v, row_ror_i<1>(v));
-  return v;
-}
-
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __int_as_float(row_ror_i<8>(__float_as_int(v)));
-  v += __int_as_float(row_ror_i<4>(__float_as_int(v)));
-  v += __int_as_float(row_ror_i<2>(__float_as_int(v)));
-  v += __int_as_float(row_ror_i<1>(__float_as_int(v)));
-  return v;
-}
-
 // second stage of the control-point gradient: grad_mapping[f,l,k,c] += sum_tile partial.
 // A workgroup sums 32 outputs of one frame: 8 thread groups take an eighth of the tiles each (32
 // consecutive floats per tile: 128-byte segments), then the eight partial sums are added in a

@@ -17,14 +17,18 @@
 // plain ds_write rate on gfx950 while ds_add_f32 retires ~3 cycles per lane
 // (tools_dev/lds_atomic_bench*.hip); integer sums are also order-independent.
 //
-// Precision contract (also in include/waldo_hip.h): a tile's sums are exact integers of a quantum
-// 2^-s per channel GROUP (the three colour planes share one scale, the alpha plane has its own),
-// with s chosen from an upper bound B of any texel sum in the tile -- the sum over the listed cells
-// of (pixels per cell) x (largest contribution in the cell, as a power of two) -- so that no sum
-// can overflow: quantum = 2^(ceil(log2 B) - 29).  Every contribution is rounded to that quantum, so
-// the error of a texel is at most (number of taps that reach it) / 2 quanta, ABSOLUTE for the tile
-// and group: texels far below the tile's largest sums lose relative precision.  A non-finite
-// contribution anywhere in a listed cell turns the whole tile (all four planes) into NaN.
+// Precision contract (also in include/waldo_hip.h): the sums are exact integers of a quantum 2^-s per
+// 8x16-texel SUB-BLOCK of the tile and channel GROUP (the three colour planes share one scale, the
+// alpha plane has its own), with s chosen from an upper bound B of any texel sum in the sub-block --
+// (number of listed cells whose box reaches the sub-block) x (the largest of their bounds: pixels per
+// cell x largest contribution in the cell, as a power of two) -- so that no sum can overflow:
+// quantum = 2^(ceil(log2 B) - 29).  Every contribution is rounded to the quantum of the sub-block its
+// tap lands in, so the error of a texel is at most (number of taps that reach it) / 2 quanta,
+// ABSOLUTE for the sub-block and group: a region whose contributions are small gets a fine quantum
+// of its own even when the same tile also holds large ones (round 2 had one quantum per tile).  A
+// non-finite contribution anywhere in a listed cell turns the whole tile (all four planes) into NaN.
+#include <type_traits>
+
 #include "waldo_common.hip.h"
 
 namespace waldo {
@@ -83,9 +87,17 @@ constexpr int kDump = kImgWords;                       // + lane
 // outside the LAYER has weight 0 and adds 0 wherever it lands.)  This loop is VALU-issue bound
 // (rocprofv3: SQ_INSTS_VALU * 4 cycles ~ 3/4 of the kernel), hence two VALU instructions per add:
 // the four corner addresses are selected once, the channel planes are immediate offsets.
+typedef float f32x2_k2 __attribute__((ext_vector_type(2)));
+constexpr int kSubRows = 8, kSubCols = 16;                       // sub-blocks that carry their own scales
+constexpr int kSubX = kSrcCols / kSubCols, kSubY = kSrcRows / kSubRows, kSubs = kSubX * kSubY;
+static_assert(kSubX * kSubCols == kSrcCols && kSubY * kSubRows == kSrcRows, "sub-blocks tile S");
+
+// MIXED: the corners take the scales of the sub-blocks they land in (a table read per corner); else
+// the tile has one scale per group (the usual case: the sub-blocks' bounds are alike).
+template <bool MIXED>
 __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const Taps& t,
                                             const float4 rec, float g0, float g1, float g2,
-                                            float scale_rgb, float scale_a, int sx0, int sy0) {
+                                            const f32x2_k2* sbscale, f32x2_k2 tile_scale, int sx0, int sy0) {
   const int lx0 = t.x0 - sx0, ly0 = t.y0 - sy0;
   const bool cx0 = (unsigned)lx0 < (unsigned)kSrcCols, cx1 = (unsigned)(lx0 + 1) < (unsigned)kSrcCols;
   const bool cy0 = on && (unsigned)ly0 < (unsigned)kSrcRows, cy1 = on && (unsigned)(ly0 + 1) < (unsigned)kSrcRows;
@@ -99,15 +111,35 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
   int* a11 = reinterpret_cast<int*>(img8 + ((cx1 && cy1) ? base + 4 * kPitch + 4 : dump));
   // the sixteen products on the packed-fp32 pipe, two per instruction: (g w00, g w01), (g w10, g w11)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const float as = rec.x * scale_rgb;
   const f32x2 wt = {t.w00, t.w01}, wb = {t.w10, t.w11};
-  const f32x2 g01 = (f32x2){as, as} * (f32x2){g0, g1};
-  const f32x2 g23 = {as * g2, rec.y * scale_a};
-  const float gv[4] = {g01[0], g01[1], g23[0], g23[1]};
+  f32x2 wt_rgb = wt, wb_rgb = wb, wt_a = wt, wb_a = wb;
+  float gv[4];
+  if constexpr (MIXED) {
+    // scales (colour, alpha) of the sub-blocks the four corners land in (a corner outside S goes to the
+    // dump word: any scale will do, the clamp only keeps the table read in range); the weights carry them
+    const int kx0 = min(max(lx0 >> 4, 0), kSubX - 1), kx1 = min(max((lx0 + 1) >> 4, 0), kSubX - 1);
+    const int ky0 = min(max(ly0 >> 3, 0), kSubY - 1) * kSubX, ky1 = min(max((ly0 + 1) >> 3, 0), kSubY - 1) * kSubX;
+    const f32x2_k2 s00 = sbscale[ky0 + kx0], s01 = sbscale[ky0 + kx1], s10 = sbscale[ky1 + kx0], s11 = sbscale[ky1 + kx1];
+    wt_rgb = wt * (f32x2){s00[0], s01[0]};
+    wb_rgb = wb * (f32x2){s10[0], s11[0]};
+    wt_a = wt * (f32x2){s00[1], s01[1]};
+    wb_a = wb * (f32x2){s10[1], s11[1]};
+    gv[0] = rec.x * g0;
+    gv[1] = rec.x * g1;
+    gv[2] = rec.x * g2;
+    gv[3] = rec.y;
+  } else {
+    const float as = rec.x * tile_scale[0];
+    const f32x2 g01 = (f32x2){as, as} * (f32x2){g0, g1};
+    gv[0] = g01[0];
+    gv[1] = g01[1];
+    gv[2] = as * g2;
+    gv[3] = rec.y * tile_scale[1];
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const f32x2 gs = {gv[c], gv[c]};
-    const f32x2 pt = gs * wt, pb = gs * wb;
+    const f32x2 pt = gs * (c < 3 ? wt_rgb : wt_a), pb = gs * (c < 3 ? wb_rgb : wb_a);
     atomicAdd(a00 + c * kPlane, cvt_round(pt[0]));
     atomicAdd(a01 + c * kPlane, cvt_round(pt[1]));
     atomicAdd(a10 + c * kPlane, cvt_round(pb[0]));
@@ -140,11 +172,16 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   const int sx0 = (stile % nsx) * kSrcCols, sy0 = (stile / nsx) * kSrcRows;
   const int sx1 = min(sx0 + kSrcCols, W) - 1, sy1 = min(sy0 + kSrcRows, H) - 1;
 
-  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + (kScanPer + 2) * kG2Waves + 4];
+  __shared__ __attribute__((aligned(16))) int lds[4 * kPlane + kMaxHit + kScanPer * kG2Waves + 5 * kSubs];
   int* img = lds;
   int* hitlist = lds + 4 * kPlane;
   int* wcount = hitlist + kMaxHit;                      // [cell of the trip][wave]: hits
-  float* wbound = reinterpret_cast<float*>(wcount + kScanPer * kG2Waves);  // [wave][rgb, alpha]
+  // per sub-block: listed cells whose box reaches it, the largest of their bounds (float bits; positive
+  // floats order like their bits: integer atomics, deterministic), then the scales derived from them
+  int* sbcnt = wcount + kScanPer * kG2Waves;
+  unsigned* sbmax = reinterpret_cast<unsigned*>(sbcnt + kSubs);          // [group][sub-block]
+  f32x2_k2* sbscale = reinterpret_cast<f32x2_k2*>(sbmax + 2 * kSubs);    // (colour, alpha) per sub-block
+  static_assert((4 * kPlane + kMaxHit + kScanPer * kG2Waves + 3 * kSubs) % 2 == 0, "8-byte aligned scale table");
 
 
   auto reaches = [&](const int4 ob) {  // bitwise: no short-circuit branches between the comparisons
@@ -155,7 +192,6 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
   // trip -- their loads are independent and in flight together, one barrier pair per
   // kScanPer * kG2Threads cells (one trip at 256x512); ballot-based compaction inside a wave.
   int nhit = 0;
-  float bsum_rgb = 0.0f, bsum_a = 0.0f;
   const float cell_rows = (float)kCellRows;  // K1 publishes a bound of a 16-pixel row sum
   for (int c0 = 0; c0 < ncells; c0 += kScanPer * kG2Threads) {
     bool hit[kScanPer];
@@ -174,6 +210,7 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       static_assert((4 * kPlane) % 4 == 0, "16-byte zero fill");
       for (int e = threadIdx.x; e < kPlane; e += kG2Threads) reinterpret_cast<i32x4*>(img)[e] = (i32x4){0, 0, 0, 0};
+      if (threadIdx.x < 3 * kSubs) sbcnt[threadIdx.x] = 0;  // sbcnt and both halves of sbmax (first added to behind the barrier below)
     }
 #pragma unroll
     for (int u = 0; u < kScanPer; ++u) asm volatile("" : "+v"(eb[u]));
@@ -182,24 +219,13 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       hit[u] = (bool)((c0 + u * kG2Threads + (int)threadIdx.x < ncells) & reaches(box[u]));
       eb[u] = hit[u] ? eb[u] : 0u;
     }
-    float brgb = 0.0f, ba = 0.0f;
     int cnt[kScanPer];
 #pragma unroll
     for (int u = 0; u < kScanPer; ++u) {
-      if (hit[u]) {
-        brgb += __uint_as_float((eb[u] & 0xffu) << 23) * cell_rows;
-        ba += __uint_as_float(((eb[u] >> 8) & 0xffu) << 23) * cell_rows;
-      }
       const unsigned long long m = __ballot(hit[u]);
       cnt[u] = __popcll(m);
       if (lane == 0) wcount[u * kG2Waves + wave] = cnt[u];
       cnt[u] = __popcll(m & ((1ull << lane) - 1ull));  // hits of this wave before this lane
-    }
-    brgb = wave_sum(brgb);  // DPP row steps + permlane swaps; same order in every lane: deterministic
-    ba = wave_sum(ba);
-    if (lane == 0) {
-      wbound[2 * wave] = brgb;
-      wbound[2 * wave + 1] = ba;
     }
     __syncthreads();
 #pragma unroll
@@ -214,28 +240,76 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const int c = c0 + u * kG2Threads + (int)threadIdx.x;
       if (hit[u] && base + cnt[u] < kMaxHit)
         hitlist[base + cnt[u]] = (((c / ncx) * kCellRows) << 16) | ((c % ncx) * kCellCols);
-    }
-#pragma unroll
-    for (int w = 0; w < kG2Waves; ++w) {
-      bsum_rgb += wbound[2 * w];
-      bsum_a += wbound[2 * w + 1];
+      if (hit[u]) {
+        // the cell's bounds go to every sub-block its box reaches (exponent 255 = infinity: poison)
+        const unsigned brgb = __float_as_uint(__uint_as_float((eb[u] & 0xffu) << 23) * cell_rows);
+        const unsigned ba = __float_as_uint(__uint_as_float(((eb[u] >> 8) & 0xffu) << 23) * cell_rows);
+        const int kx0 = max((box[u].x - sx0) >> 4, 0), kx1 = min((box[u].y - sx0) >> 4, kSubX - 1);
+        const int ky0 = max((box[u].z - sy0) >> 3, 0), ky1 = min((box[u].w - sy0) >> 3, kSubY - 1);
+        for (int ky = ky0; ky <= ky1; ++ky)
+          for (int kx = kx0; kx <= kx1; ++kx) {
+            atomicAdd(&sbcnt[ky * kSubX + kx], 1);
+            atomicMax(&sbmax[ky * kSubX + kx], brgb);
+            atomicMax(&sbmax[kSubs + ky * kSubX + kx], ba);
+          }
+      }
     }
     __syncthreads();
   }
-  // fixed-point scales: a bound B of the magnitude of ANY texel sum of the group (bilinear weights
-  // are <= 1); scale = 2^(29 - floor(log2 B)) keeps |sum| * scale < 2^30
+  // fixed-point scales per sub-block and group: B = (cells that reach the sub-block) x (their largest
+  // bound) bounds the magnitude of ANY texel sum there (bilinear weights are <= 1);
+  // scale = 2^(29 - floor(log2 B)) keeps |sum| * scale < 2^30
   auto scale_exp = [](float b) {
     const int eB = (int)((__float_as_uint(b) >> 23) & 0xffu) - 127;
     return min(29 - eB, 126);
   };
-  const int es_rgb = scale_exp(bsum_rgb), es_a = scale_exp(bsum_a);
-  const float scale_rgb = __uint_as_float((unsigned)(127 + es_rgb) << 23);
-  const float scale_a = __uint_as_float((unsigned)(127 + es_a) << 23);
-  const float inv_rgb = __uint_as_float((unsigned)(127 - es_rgb) << 23);
-  const float inv_a = __uint_as_float((unsigned)(127 - es_a) << 23);
+  // Sub-blocks whose bounds are alike share the tile's coarsest exponent (one scale per group: the corners
+  // of a pixel then need no table); only when some sub-block could take a quantum at least 2^4 finer --
+  // a region of small gradients next to large ones -- does every sub-block get its own.  Sixteen lanes
+  // (one per sub-block) decide, with DPP reductions over their row of 16; the verdict goes through LDS.
+  int* verdict = reinterpret_cast<int*>(sbmax);  // reused once the table is read: [mixed, any, poison]
+  if (threadIdx.x < kWave) {
+    const int k = min((int)threadIdx.x, kSubs - 1);
+    const int cnt = sbcnt[k];
+    const float n = (float)cnt;
+    const float br = n * __uint_as_float(sbmax[k]), ba = n * __uint_as_float(sbmax[kSubs + k]);
+    // a sub-block no listed cell reaches receives no tap: it takes no part in the decision
+    const int er = scale_exp(br), ea = scale_exp(ba);
+    // exponents + 200 are positive 16-bit numbers: packed minima / maxima (as minima of 1000 - x) over
+    // the row of 16 lanes with DPP rotations
+    int lo = (cnt ? er + 200 : 326) | ((cnt ? ea + 200 : 326) << 16);
+    int hi = (cnt ? 800 - er : 1000) | ((cnt ? 800 - ea : 1000) << 16);
+    lo = group16_pk_min(lo);
+    hi = group16_pk_min(hi);
+    int bmi = (int)__float_as_uint(fmaxf(br, ba));  // non-negative floats order like their bits
+    bmi = max(bmi, row_ror_i<8>(bmi));
+    bmi = max(bmi, row_ror_i<4>(bmi));
+    bmi = max(bmi, row_ror_i<2>(bmi));
+    bmi = max(bmi, row_ror_i<1>(bmi));
+    const float bm = __uint_as_float((unsigned)bmi);
+    const int lo_r = (lo & 0xffff) - 200, lo_a = ((lo >> 16) & 0xffff) - 200;
+    const int hi_r = 800 - (hi & 0xffff), hi_a = 800 - ((hi >> 16) & 0xffff);  // -200: no sub-block is reached
+    const bool mix = (hi_r - lo_r >= 4) || (hi_a - lo_a >= 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read sbmax before the verdict overwrites it
+    if (threadIdx.x < kSubs)
+      sbscale[k] = (f32x2_k2){__uint_as_float((unsigned)(127 + (mix ? er : lo_r)) << 23),
+                              __uint_as_float((unsigned)(127 + (mix ? ea : lo_a)) << 23)};
+    if (threadIdx.x == 0) {
+      verdict[0] = mix;
+      verdict[1] = bm > 0.0f;
+      verdict[2] = !(bm < __builtin_huge_valf());
+      verdict[3] = lo;  // the coarsest exponents (+ 200, packed): the tile's scales when not mixed
+    }
+  }
+  __syncthreads();
+  const bool mixed = verdict[0] != 0;  // block-uniform
   // an infinity / NaN in a listed cell (exponent 255 from K1) or bounds that overflow: the sums
   // cannot be represented -- the tile becomes NaN, as loud as the reference's gradient would be
-  const bool poison = !(bsum_rgb < __builtin_huge_valf()) || !(bsum_a < __builtin_huge_valf());
+  const bool poison = verdict[2] != 0;
+  const float bsum_rgb = verdict[1] ? 1.0f : 0.0f, bsum_a = 0.0f;
+  const f32x2_k2 tile_scale = {__uint_as_float((unsigned)(127 - 200 + (verdict[3] & 0xffff)) << 23),
+                               __uint_as_float((unsigned)(127 - 200 + ((verdict[3] >> 16) & 0xffff)) << 23)};
   const float* gplane = grad_rgb + f * 3 * HW;
   const float4* rcp = rec + ((int64_t)WALDO_REC_FRAME(f) * L + layer) * HW;
 
@@ -275,7 +349,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         k.g1 = ldb(gplane + HW, k.p * 4u);
         k.g2 = ldb(gplane + 2 * HW, k.p * 4u);
       };
-      auto splat = [&](const Cand& k) {
+      auto splat = [&](auto mixed_tag, const Cand& k) {
+        constexpr bool MIXED = decltype(mixed_tag)::value;
         const TapCore tc = tap_core_px(k.rc.x, k.rc.y, H, W);
         const bool any = k.livep && touches(tc, sx0, sy0);
         // a wave = 4 rows x 16 columns of one cell: skip the adds when none of its taps reach S
@@ -293,8 +368,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           } else {
             t = finish_taps(tc, H, W);
           }
-          splat_pixel(img, lane, any, t, make_float4(k.rc.z, k.rc.w, k.rc.x, k.rc.y), k.g0, k.g1, k.g2,
-                      scale_rgb, scale_a, sx0, sy0);
+          splat_pixel<MIXED>(img, lane, any, t, make_float4(k.rc.z, k.rc.w, k.rc.x, k.rc.y), k.g0, k.g1, k.g2,
+                             sbscale, tile_scale, sx0, sy0);
         }
       };
       // ring of kRing candidates per thread in flight (2: with 3 / 4 the backward is 1 % / 1.7 %
@@ -303,21 +378,24 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       // steady-state loop has no branch between a splat and the next fetch (a join makes hipcc wait
       // for every outstanding load); the last, partial round is peeled.
       constexpr int kRing = WALDO_K2_RING;
-      Cand k[kRing];
-      int i = threadIdx.x;
+      auto run = [&](auto mixed_tag) {
+        Cand k[kRing];
+        int i = threadIdx.x;
 #pragma unroll
-      for (int d = 0; d < kRing; ++d) fetch(i + d * kG2Threads, k[d]);
-      while (i + (kRing - 1) * kG2Threads < total) {  // uniform per wave: total is a multiple of 128
+        for (int d = 0; d < kRing; ++d) fetch(i + d * kG2Threads, k[d]);
+        while (i + (kRing - 1) * kG2Threads < total) {  // uniform per wave: total is a multiple of 128
 #pragma unroll
-        for (int d = 0; d < kRing; ++d) {
-          splat(k[d]);
-          fetch(i + (d + kRing) * kG2Threads, k[d]);
+          for (int d = 0; d < kRing; ++d) {
+            splat(mixed_tag, k[d]);
+            fetch(i + (d + kRing) * kG2Threads, k[d]);
+          }
+          i += kRing * kG2Threads;
         }
-        i += kRing * kG2Threads;
-      }
 #pragma unroll
-      for (int d = 0; d < kRing - 1; ++d)
-        if (i + d * kG2Threads < total) splat(k[d]);
+        for (int d = 0; d < kRing - 1; ++d)
+          if (i + d * kG2Threads < total) splat(mixed_tag, k[d]);
+      };
+      if (mixed) run(std::true_type{}); else run(std::false_type{});  // block-uniform
     } else {
       // violent warp (more cells reach S than the list holds): scan every cell, wave-uniformly
       for (int c = 0; c < ncells; ++c) {
@@ -330,8 +408,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
           const float4 rc = rcp[p];
           const float4 rec = make_float4(rc.z, rc.w, rc.x, rc.y);
           const Taps t = make_taps_px(rec.z, rec.w, H, W);
-          splat_pixel(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
-                      scale_rgb, scale_a, sx0, sy0);
+          splat_pixel<true>(img, lane, true, t, rec, gplane[p], (gplane + HW)[p], (gplane + 2 * HW)[p],
+                            sbscale, tile_scale, sx0, sy0);
         }
       }
     }
@@ -358,6 +436,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       if (y < H && x < W) {
         const unsigned doff = (unsigned)(__mul24(y, W) + x);
         const int li = (e >> (kColShift - 2)) * kPitch + 4 * (e & (kSrcCols / 4 - 1));
+        // the four texels of a lane lie in one sub-block; 1 / 2^s = 2^(254 - biased exponent)
+        const f32x2_k2 sc = sbscale[((y - sy0) >> 3) * kSubX + ((x - sx0) >> 4)];
+        const float inv_rgb = __uint_as_float(0x7f000000u - __float_as_uint(sc[0]));
+        const float inv_a = __uint_as_float(0x7f000000u - __float_as_uint(sc[1]));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
@@ -374,9 +456,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
     if (y < H && x < W) {
       const unsigned doff = (unsigned)(__mul24(y, W) + x);
       const int li = (e >> kColShift) * kPitch + (e & (kSrcCols - 1));
+      const f32x2_k2 sc = sbscale[((y - sy0) >> 3) * kSubX + ((x - sx0) >> 4)];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * (c < 3 ? inv_rgb : inv_a);
+        (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * __uint_as_float(0x7f000000u - __float_as_uint(sc[c < 3 ? 0 : 1]));
     }
   }
 }
