@@ -23,6 +23,12 @@
 namespace waldo {
 
 constexpr int kAccTilesMax = 16;  // pixel tiles a workgroup walks before it flushes its LDS tables
+#ifndef WALDO_FCB_ALPHA_WAVES
+#define WALDO_FCB_ALPHA_WAVES 3
+#endif
+#ifndef WALDO_FCB_MIN_WGS
+#define WALDO_FCB_MIN_WGS 512
+#endif
 // The two flow_ctx backward kernels are compiled for >= 3 waves per SIMD (168 VGPRs): at L = 17 they
 // want 210 / 300+ registers and would run one or two waves per SIMD; with the cap they spill ~100 /
 // ~1000 bytes per lane to scratch and the LVD-recipe step is 5 % faster (3.85 -> 3.67 ms).
@@ -76,7 +82,7 @@ __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float 
 }
 
 template <int LP>
-__global__ __launch_bounds__(kBlock, 3) void flow_ctx_alpha_bwd_kernel(
+__global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_bwd_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, const float* __restrict__ g_a01,
     float* __restrict__ g_up, float* __restrict__ g_dist, float* __restrict__ g_occ, int T, int Tw,
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_bwd_kernel(
 }
 
 static int acc_tiles(int64_t units, int64_t tiles) {  // tiles per workgroup: keep >= ~512 workgroups (fewer: measured slower, the per-tile reductions dominate)
-  return (int)min((int64_t)kAccTilesMax, max((int64_t)1, units * tiles / 512));
+  return (int)min((int64_t)kAccTilesMax, max((int64_t)1, units * tiles / WALDO_FCB_MIN_WGS));
 }
 
 }  // namespace waldo

@@ -81,6 +81,14 @@ constexpr int kPitch = WALDO_K2_PITCH;
 constexpr int kImgWords = kSrcRows * kPitch;           // image words per channel
 constexpr int kPlane = kImgWords + kWave;              // + the dump words
 constexpr int kDump = kImgWords;                       // + lane
+// WALDO_K2_PK64: two channel planes share a 64-bit word per texel (lo = plane 2q, hi = plane 2q + 1) and a
+// tap is added with ONE ds_add_u64 per pair: 8 LDS atomics per pixel instead of 16 (tools_dev/r3_micro.hip:
+// 52.8 vs 69.1 LDS cycles per pixel-wave).  The signed 32-bit sums decode exactly from the 64-bit total: the
+// low half is the low sum modulo 2^32 (no overflow: the scale guarantees it), and the high half carries the
+// high sum plus the borrows of negative low halves, -1 per addend, i.e. minus [low sum < 0] in the end.
+#ifndef WALDO_K2_PK64
+#define WALDO_K2_PK64 1  // measured: backward 2.133 -> 2.092 ms at the headline shape, bit-identical sums
+#endif
 
 // taps of one candidate pixel into the S image.  Branch-free: a tap outside S adds to the lane's
 // own dump word -- never to a shared address, where same-address adds would serialise.  (A corner
@@ -136,6 +144,24 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
     gv[2] = as * g2;
     gv[3] = rec.y * tile_scale[1];
   }
+#if WALDO_K2_PK64
+  // the 64-bit image: pair q of texel word w at 8 * (q * kPlane + w); a00 .. a11 hold 4 * w
+  auto add2 = [&](int* a, int q, float vlo, float vhi) {
+    const int lo = cvt_round(vlo), hi = cvt_round(vhi);
+    const unsigned long long v = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32);
+    atomicAdd(reinterpret_cast<unsigned long long*>(img) + q * kPlane + (a - img), v);
+  };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x2 g0s = {gv[2 * q], gv[2 * q]}, g1s = {gv[2 * q + 1], gv[2 * q + 1]};
+    const f32x2 pt0 = g0s * wt_rgb, pb0 = g0s * wb_rgb;
+    const f32x2 pt1 = g1s * (q == 0 ? wt_rgb : wt_a), pb1 = g1s * (q == 0 ? wb_rgb : wb_a);
+    add2(a00, q, pt0[0], pt1[0]);
+    add2(a01, q, pt0[1], pt1[1]);
+    add2(a10, q, pb0[0], pb1[0]);
+    add2(a11, q, pb0[1], pb1[1]);
+  }
+#else
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const f32x2 gs = {gv[c], gv[c]};
@@ -145,6 +171,7 @@ __device__ __forceinline__ void splat_pixel(int* img, int lane, bool on, const T
     atomicAdd(a10 + c * kPlane, cvt_round(pb[0]));
     atomicAdd(a11 + c * kPlane, cvt_round(pb[1]));
   }
+#endif
 }
 
 // does any tap of this pixel fall into S?
@@ -442,7 +469,14 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
         const float inv_a = __uint_as_float(0x7f000000u - __float_as_uint(sc[1]));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#if WALDO_K2_PK64
+          const i32x4* w64 = reinterpret_cast<const i32x4*>(reinterpret_cast<const long long*>(img) + (c >> 1) * kPlane + li);
+          const i32x4 wa = w64[0], wb = w64[1];  // (lo, hi) of texels li .. li + 3
+          const i32x4 los = {wa[0], wa[2], wb[0], wb[2]}, his = {wa[1], wa[3], wb[1], wb[3]};
+          const i32x4 v = (c & 1) ? his - (los >> 31) : los;
+#else
           const i32x4 v = *reinterpret_cast<const i32x4*>(img + c * kPlane + li);
+#endif
           const float inv = c < 3 ? inv_rgb : inv_a;
           stream_store16<WALDO_GRAD_STORE_POLICY>(gbase + c * HW, doff * 4u, HW * 4,
                                                   (f32x4){(float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv});
@@ -458,8 +492,15 @@ __global__ __launch_bounds__(kG2Threads, 2) void warp_composite_splat_kernel(
       const int li = (e >> kColShift) * kPitch + (e & (kSrcCols - 1));
       const f32x2_k2 sc = sbscale[((y - sy0) >> 3) * kSubX + ((x - sx0) >> 4)];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        (gbase + c * HW)[doff] = (float)img[c * kPlane + li] * __uint_as_float(0x7f000000u - __float_as_uint(sc[c < 3 ? 0 : 1]));
+      for (int c = 0; c < 4; ++c) {
+#if WALDO_K2_PK64
+        const int lo = img[2 * ((c >> 1) * kPlane + li)], hi = img[2 * ((c >> 1) * kPlane + li) + 1];
+        const int v = (c & 1) ? hi - (lo >> 31) : lo;
+#else
+        const int v = img[c * kPlane + li];
+#endif
+        (gbase + c * HW)[doff] = (float)v * __uint_as_float(0x7f000000u - __float_as_uint(sc[c < 3 ? 0 : 1]));
+      }
     }
   }
 }
