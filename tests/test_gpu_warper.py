@@ -105,6 +105,19 @@ def test_inverse_warp_random(dev, cfg):
     close(out, ref, what="out")
     (out * wgt.to(dev)).sum().backward()
     close(s2.grad, sg.grad, rel=True, what="grad")
+    # the one-launch tile + halo kernels (forward fill / erosion, backward fill passes) against the
+    # per-pass kernels they replace: same arithmetic in the same order, bit for bit
+    from waldo_amd import _lib
+    lib = _lib.load()
+    assert lib.waldo_set_debug_option(_lib.DEBUG_IW_PASSES, 1) == 0
+    try:
+        s3 = sg.detach().to(dev).requires_grad_()
+        out3 = mod(s3, niter=niter, erode=erode)
+        (out3 * wgt.to(dev)).sum().backward()
+    finally:
+        lib.waldo_set_debug_option(_lib.DEBUG_IW_PASSES, 0)
+    assert torch.equal(out3, out), "fused forward differs from the per-pass kernels"
+    assert torch.equal(s3.grad, s2.grad), "fused backward differs from the per-pass kernels"
 
 
 def test_inverse_warp_identity_and_errors(dev):

@@ -402,6 +402,91 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fill_kernel(float* __restrict__
   gy[e] += ay;
 }
 
+// init + every reverse fill pass in ONE launch (round 3; the per-pass kernels above stay for iteration
+// counts whose halo does not fit the LDS and as the reference the tests compare with): a workgroup owns a
+// 32 x 32 tile of the padded raster and redoes the passes on the tile plus a halo of niter cells in LDS --
+// the gradient a cell ends with depends on cells at most niter away (pass `it` moves gradient from the
+// cells filled in pass `it` to their 3 x 3 neighbours filled earlier; passes run niter .. 1).  Same
+// arithmetic in the same order as iw_bwd_init_kernel + iw_bwd_fill_kernel: bit-identical gfield.  At the
+// LVD recipe the backward of the two grid inversions was 2 x (1 + 5) launches of 13-19 us each.
+constexpr int kBwdTH = 32, kBwdTW = 32;
+
+__global__ __launch_bounds__(kBlock) void iw_bwd_fused_kernel(
+    const float* __restrict__ gout, const unsigned char* __restrict__ mask,
+    const unsigned char* __restrict__ fill_iter, const float* __restrict__ denom,
+    const float* __restrict__ kern, float* __restrict__ gfield, int H, int W, int niter, int tiles_x, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int pad = niter + 1, halo = niter;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
+  const int RW = kBwdTW + 2 * halo + 2, RH = kBwdTH + 2 * halo + 2;  // region incl. a one-cell border of state 255
+  const int cells = RH * RW;
+  float* gx = reinterpret_cast<float*>(smem);
+  float* gy = gx + cells;
+  float* rd = gy + cells;  // 1 / denom of the cell's own fill pass (0 for winners and unfilled cells)
+  unsigned char* fi = reinterpret_cast<unsigned char*>(rd + cells);
+  const int64_t b = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const int ty0 = (tile / tiles_x) * kBwdTH, tx0 = (tile % tiles_x) * kBwdTW;  // padded coords
+  const int oy = ty0 - halo - 1, ox = tx0 - halo - 1;                              // of region cell (0, 0)
+  float k9[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k9[i] = kern[i];
+  // ---- load (= iw_bwd_init_kernel on the region): gradient of the masked image cells, fill states
+  int any = 0;
+  for (int c = threadIdx.x; c < cells; c += kBlock) {
+    const int i = c / RW, j = c - i * RW;
+    const int yp = oy + i, xp = ox + j;
+    float vx = 0.0f, vy = 0.0f, d = 1.0f;
+    unsigned char st = 255;  // never a source (fi == it) nor a sink (fi < it) of any pass
+    if (i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp) {
+      const int e = yp * Wp + xp;
+      st = fill_iter[b * HWp + e];
+      const int y = yp - pad, x = xp - pad;
+      if (y >= 0 && y < H && x >= 0 && x < W && mask[b * HWp + e]) {
+        vx = gout[(b * HW + y * W + x) * 2 + 0] * 2.0f / (float)W;
+        vy = gout[(b * HW + y * W + x) * 2 + 1] * 2.0f / (float)H;
+      }
+      if (st >= 1 && st <= niter) d = denom[b * HWp + e];
+    }
+    gx[c] = vx;
+    gy[c] = vy;
+    rd[c] = d;
+    fi[c] = st;
+    any |= (st >= 1 && st <= niter);
+  }
+  // a region without a single filled cell: nothing moves
+  const int n_pass = __syncthreads_or(any) ? niter : 0;
+  for (int it = n_pass; it >= 1; --it) {
+    for (int c = threadIdx.x; c < cells; c += kBlock) {
+      if (fi[c] >= it) continue;  // only earlier-filled cells fed pass `it` (border cells: 255)
+      float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int n = c + dy * RW + dx;
+          if (fi[n] == it) {
+            // this cell sits at offset (-dy, -dx) in n's stencil; the Gaussian is symmetric
+            const float k = k9[(1 - dy) * 3 + (1 - dx)] / rd[n];
+            ax = fmaf(k, gx[n], ax);
+            ay = fmaf(k, gy[n], ay);
+          }
+        }
+      gx[c] += ax;  // cells of pass `it` are only read here, cells before it only written: in place
+      gy[c] += ay;
+    }
+    __syncthreads();
+  }
+  // ---- the tile's own cells
+  for (int e = threadIdx.x; e < kBwdTH * kBwdTW; e += kBlock) {
+    const int yp = ty0 + e / kBwdTW, xp = tx0 + e % kBwdTW;
+    if (yp >= Hp || xp >= Wp) continue;
+    const int c = (yp - oy) * RW + (xp - ox);
+    gfield[(b * 2 + 0) * HWp + yp * Wp + xp] = gx[c];
+    gfield[(b * 2 + 1) * HWp + yp * Wp + xp] = gy[c];
+  }
+}
+
 // d loss / d (dx, dy) of the winners, then the adjoint of the bilinear resize -- as a GATHER: one
 // thread per source texel and component pair sums the samples whose bilinear footprint contains the
 // texel (those with y0 == j or y1 == j, likewise in x: a (2 H / Hs) x (2 W / Ws) window), each with
@@ -600,10 +685,18 @@ extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3
   const int Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int HW = H * W, HWp = Hp * Wp;
   dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
-  hipLaunchKernelGGL(iw_bwd_init_kernel, gp, dim3(kBlock), 0, st, grad_out, mask, gfield, H, W, pad);
-  for (int it = niter; it >= 1; --it)
-    hipLaunchKernelGGL(iw_bwd_fill_kernel, gp, dim3(kBlock), 0, st, gfield, fill_iter, denom,
-                       gauss3x3, Hp, Wp, it);
+  const int bw_rw = kBwdTW + 2 * niter + 2, bw_rh = kBwdTH + 2 * niter + 2;
+  const size_t bw_lds = (size_t)bw_rw * bw_rh * 13;
+  const int btx = (Wp + kBwdTW - 1) / kBwdTW, bty = (Hp + kBwdTH - 1) / kBwdTH;
+  if (!debug_option(WALDO_DEBUG_IW_PASSES) && bw_lds <= kFusedMaxLds && B * btx * bty <= 2147483647ll) {
+    hipLaunchKernelGGL(iw_bwd_fused_kernel, dim3((unsigned)(B * btx * bty)), dim3(kBlock), bw_lds, st, grad_out,
+                       mask, fill_iter, denom, gauss3x3, gfield, H, W, niter, btx, btx * bty);
+  } else {
+    hipLaunchKernelGGL(iw_bwd_init_kernel, gp, dim3(kBlock), 0, st, grad_out, mask, gfield, H, W, pad);
+    for (int it = niter; it >= 1; --it)
+      hipLaunchKernelGGL(iw_bwd_fill_kernel, gp, dim3(kBlock), 0, st, gfield, fill_iter, denom,
+                         gauss3x3, Hp, Wp, it);
+  }
   hipLaunchKernelGGL(iw_bwd_gather_kernel, dim3((Hs * Ws + kBlock - 1) / kBlock, (unsigned)B), dim3(kBlock), 0,
                      st, gfield, cell, winner, grad_src_grid, Hs, Ws, H, W, pad);
   return launch_status("waldo_inverse_warp_bwd");
