@@ -171,6 +171,17 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 // of a pixel stay in registers and every input channel is sampled, written to `raw` and fused
 // into `out` in one pass.
 
+#ifndef WALDO_FWF_NT
+#define WALDO_FWF_NT 1  // non-temporal stores for out / raw (read next by another kernel, far larger than any cache): -3.5 %
+#endif
+__device__ __forceinline__ void fwf_store(float* p, float v) {
+#if WALDO_FWF_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
@@ -214,14 +225,14 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     for (int l = 0; l < L; ++l) {
       const float av = al[(int64_t)l * HWd];
       s += (av + 1.0f) / 2.0f;
-      if (real) rw[(int64_t)l * HWd] = av;
+      if (real) fwf_store(rw + (int64_t)l * HWd, av);
     }
     sc[tc] = s;
     ssum += real ? fabsf(s + eps) : 0.0f;
   }
   if (include_self) {
     float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + Tc) * (C + L) + C) * HWd + p;
-    for (int l = 0; l < L; ++l) rw[(int64_t)l * HWd] = 1.0f;
+    for (int l = 0; l < L; ++l) fwf_store(rw + (int64_t)l * HWd, 1.0f);
     ssum += fabsf(1.0f + eps);
   }
   const float den = fmaxf(ssum, 1e-12f);
@@ -262,15 +273,15 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     for (int tc = 0; tc < TCP; ++tc) {
       const float v = fmaf(tv[tc][3], w11[tc], fmaf(tv[tc][2], w10[tc], fmaf(tv[tc][1], w01[tc], tv[tc][0] * w00[tc])));
 #ifndef WALDO_ABL_FWF_NORAW  // timing-only ablation: without the per-context stores
-      if (tc < Tc) rbase[((int64_t)tc * (C + L) + c) * HWd] = v;
+      if (tc < Tc) fwf_store(rbase + ((int64_t)tc * (C + L) + c) * HWd, v);
 #endif
       acc += v * wt[tc];
     }
     if (include_self) {
-      rbase[((int64_t)Tc * (C + L) + c) * HWd] = vself;
+      fwf_store(rbase + ((int64_t)Tc * (C + L) + c) * HWd, vself);
       acc += vself * wself;
     }
-    obase[(int64_t)c * HWd] = acc;
+    fwf_store(obase + (int64_t)c * HWd, acc);
 #pragma unroll
     for (int tc = 0; tc < TCP; ++tc)
 #pragma unroll
