@@ -21,6 +21,8 @@
 //
 // Both are HBM streaming passes: A reads Nl + (L taps from the 16x smaller LR planes) and writes
 // 2L floats per HD pixel; B reads ~L gathered alphas and writes L + 3.
+#include <type_traits>
+
 #include "flow_ctx_common.hip.h"
 
 namespace waldo {
@@ -98,6 +100,21 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
   }
 }
 
+// Layout of the staged low-resolution data of one tile (flow_ctx_warp): CELL-major, one 16-byte record per
+// layer -- {flow x, flow y, object mask of the layer below the ghost test, unused} -- and the records of
+// the padding layers filled with those of layer L - 1.  A tap of a layer is then ONE ds_read_b128 at a
+// compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
+// ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
+#ifndef WALDO_FCW_CHUNK
+#define WALDO_FCW_CHUNK 4  // 4: 116 registers at L = 12 (four waves per SIMD) and 1.92 ms at the C5 size; 6: 140 and 2.04 ms
+#endif
+template <int LP>
+struct FcwLds {
+  static constexpr int kCell = 4 * LP + 4;             // floats per cell (+ 4: cells of a row on different banks)
+  static constexpr int kCap = LP <= 12 ? 7168 : 8192;  // floats: 136 cells (x 2 upsampling) up to L = 12
+  static constexpr int kOccRow = (LP + 3) & ~3;        // row stride of the occlusion matrix (16-byte rows)
+};
+
 template <int LP>
 __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
@@ -105,56 +122,171 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
     float* __restrict__ alpha_ctx, float* __restrict__ disocc, int T, int Tw, int Tc, int Tp, int L,
     int H, int W, int scale, int units, int tiles, int nbands) {
+  using G = FcwLds<LP>;
+  typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
   int m, x, y;  // m = (b, tc, tp)
-  if (!hd_pixel(units, Hd, Wd, tiles, nbands, m, x, y) || x >= Wd || y >= Hd) return;
+  if (!hd_pixel(units, Hd, Wd, tiles, nbands, m, x, y)) return;
   const int tp = m % Tp, b = m / (Tc * Tp);
-  const int64_t p = (int64_t)y * Wd + x;
-  const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
+  const float rscale = 1.0f / (float)scale;
   // frame of the context alpha (clamped: the index comes from device memory) and of the order
-  const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1));
-  const int tpred = (int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1));
+  // (read through the vector path, the frame indices land in VGPRs and every plane address derived from
+  // them becomes per-lane 64-bit arithmetic: they are wave-uniform, say so)
+  const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1)));
+  const int tpred = __builtin_amdgcn_readfirstlane((int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1)));
+
+  __shared__ __attribute__((aligned(16))) float lrimg[G::kCap];
+  __shared__ __attribute__((aligned(16))) float occm[LP * G::kOccRow];
+  // ---- the order of the predicted frame, padded to LP x LP (a padding row / column repeats the last real
+  // one: its alpha is 0).  Read from LDS -- one broadcast ds_read_b128 per four columns -- instead of through
+  // the scalar cache: L x L scalar loads with a run-time row stride were ~7 SALU instructions EACH, and
+  // at L = 12 the kernel issued as many scalar as vector instructions (1480 / 1464 per wavefront).
+  {
+    const float* oc = occ + ((int64_t)b * T + tpred) * L * L;
+    for (int e = threadIdx.x; e < LP * G::kOccRow; e += kBlock) {
+      const int i = e / G::kOccRow, j = e - i * G::kOccRow;
+      occm[e] = oc[min(i, L - 1) * L + min(j, L - 1)];
+    }
+  }
+  // ---- the tile's patch of the low-resolution planes (2 L flow planes, L - 1 object masks)
+  const int nob = isobj_lr != nullptr ? L - 1 : 0;
+  LrPatch lq = lr_patch(y - (int)(threadIdx.x >> 6), x - (int)(threadIdx.x & (kWave - 1)), Hd, Wd, rscale, H, W);
+  lq.r_lo = __builtin_amdgcn_readfirstlane(lq.r_lo);  // the same in every thread of the workgroup
+  lq.c_lo = __builtin_amdgcn_readfirstlane(lq.c_lo);
+  lq.nrows = __builtin_amdgcn_readfirstlane(lq.nrows);
+  lq.ncols = __builtin_amdgcn_readfirstlane(lq.ncols);
+  const int area = lq.nrows * lq.ncols;
+  const bool staged = area <= kBlock && area * G::kCell <= G::kCap;  // uniform
+  if (staged) {
+    // thread = (cell, layer group): kBlock / area groups share the layers of a cell
+    const int ngrp = kBlock / area;
+    const int t = (int)threadIdx.x;
+    // t < 256, area / ncols <= 256, the + 0.5: the approximate reciprocal gives the exact quotients
+    const int grp = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)area));
+    const int cell = t - grp * area;
+    const int r = (int)(((float)cell + 0.5f) * __builtin_amdgcn_rcpf((float)lq.ncols));
+    const int64_t off = (int64_t)(lq.r_lo + r) * W + lq.c_lo + (cell - r * lq.ncols);
+    if (grp < ngrp)
+      for (int l = grp; l < LP; l += ngrp) {
+        const int lc = min(l, L - 1);
+        const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW + off;
+        f32x4 rec = {fl[0], fl[HW], 0.0f, 0.0f};
+        if (nob && lc >= 1) rec[2] = isobj_lr[((int64_t)m * (L - 1) + (lc - 1)) * HW + off];
+        *reinterpret_cast<f32x4*>(lrimg + cell * G::kCell + 4 * l) = rec;
+      }
+  }
+  __syncthreads();
+  if (x >= Wd || y >= Hd) return;
+  const int64_t p = (int64_t)y * Wd + x;
+  const UpTaps ut = up_taps(y, x, rscale, H, W);
+  LrTaps lt = lr_taps(y, x, rscale, H, W, lq);
+  lt.o00 *= G::kCell, lt.o01 *= G::kCell, lt.o10 *= G::kCell, lt.o11 *= G::kCell;
   float gx0, gy0;  // texel centre of the HD identity grid exactly as get_grid() builds it
   identity_grid(x, y, Wd, Hd, gx0, gy0);
 
-  // branch-free over the padded layer count (a padding layer re-reads layer L-1 and is zeroed):
-  // conditional writes to the per-layer arrays would keep them out of registers
+  // branch-free over the padded layer count (a padding layer repeats layer L-1 and its alpha is zeroed):
+  // conditional writes to the per-layer arrays would keep them out of registers.  In chunks of up to six
+  // layers: the flows, taps and LOADS of the chunk first (twelve eight-byte loads in flight per lane), then
+  // its values -- taken two layers at a time (round 2) a wavefront waits L / 2 times for memory, and at
+  // three waves per SIMD that wait is what the kernel's time was made of.  Two copies of the loop, one per
+  // source of the low-resolution taps (the direct one keeps two layers in flight: its taps are 12 loads a layer).
   float a[LP], fx[LP], fy[LP];
   float dis = -INFINITY;
+  const float* ap = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer min(l, L - 1), stepped
+  auto layers = [&](auto from_lds) {
+    constexpr bool LDS = decltype(from_lds)::value;
+    constexpr int CH = !LDS ? 2 : (LP < WALDO_FCW_CHUNK ? LP : WALDO_FCW_CHUNK);  // layers whose loads are in flight together
 #pragma unroll
-  for (int l = 0; l < LP; ++l) {
-    const int lc = min(l, L - 1);
-    const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW;
-    const float fxl = up_sample(fl, ut), fyl = up_sample(fl + HW, ut);
-    const Taps t = make_taps(gx0 + fxl, gy0 + fyl, Hd, Wd);
-    float v = tap_sample(a01 + (((int64_t)b * Tw + ts) * L + lc) * HWd, t);
-    if (isobj_lr != nullptr && l >= 1)
-      v *= (up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(lc - 1, 0)) * HW, ut) > 0.9f) ? 1.0f : 0.0f;
-    const bool real = l < L;
-    a[l] = real ? v : 0.0f;
-    fx[l] = real ? fxl : 0.0f;
-    fy[l] = real ? fyl : 0.0f;
-    dis = real ? fmaxf(dis, v) : dis;
-    // two layers' loads in flight at a time: left alone, the scheduler hoists the 16 loads of all
-    // L layers to the top
-    if ((l & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-  }
+    for (int l0 = 0; l0 < LP; l0 += CH) {
+      PairTaps pt[CH];
+      f32x2_p ra[CH], rb[CH];
+      bool inter[CH];
+      float ghost[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int l = l0 + k;
+        if (l >= LP) break;
+        float fxl, fyl, g = 1.0f;
+        if (LDS) {
+          const f32x4 v00 = *reinterpret_cast<const f32x4*>(lrimg + lt.o00 + 4 * l);
+          const f32x4 v01 = *reinterpret_cast<const f32x4*>(lrimg + lt.o01 + 4 * l);
+          const f32x4 v10 = *reinterpret_cast<const f32x4*>(lrimg + lt.o10 + 4 * l);
+          const f32x4 v11 = *reinterpret_cast<const f32x4*>(lrimg + lt.o11 + 4 * l);
+          fxl = up_blend(ut, v00[0], v01[0], v10[0], v11[0]);
+          fyl = up_blend(ut, v00[1], v01[1], v10[1], v11[1]);
+          if (l >= 1) g = up_blend(ut, v00[2], v01[2], v10[2], v11[2]);
+        } else {
+          const int lc = min(l, L - 1);
+          const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW;
+          fxl = up_sample(fl, ut);
+          fyl = up_sample(fl + HW, ut);
+          if (nob && l >= 1) g = up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(lc - 1, 0)) * HW, ut);
+        }
+        fx[l] = fxl;
+        fy[l] = fyl;
+        ghost[k] = g;
+        pt[k] = pair_taps(gx0 + fxl, gy0 + fyl, Hd, Wd, inter[k]);
+#ifdef WALDO_ABL_FCW_NOGATHER  // timing-only ablation: one coalesced load instead of the taps
+        ra[k] = rb[k] = (f32x2_p){ap[p], fxl};
+#else
+        pair_load(ap, pt[k], ra[k], rb[k]);
+#endif
+        if (l + 1 < L) ap += HWd;
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);  // the LDS records of two layers at a time (32 registers)
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int l = l0 + k;
+        if (l >= LP) break;
+        float v = pair_value(ra[k], rb[k], pt[k], inter[k]);
+        if (l >= 1) v = (nob && !(ghost[k] > 0.9f)) ? 0.0f : v;
+        // the value HERE: the wave-uniform border branches cut the loop body into basic blocks, and the
+        // compiler sinks this arithmetic to the first use of a[] after the loop -- keeping the taps and loaded
+        // pairs of EVERY layer alive to the end (216 registers at L = 12)
+        asm volatile("" : "+v"(v));
+        dis = fmaxf(dis, v);  // (a padding layer repeats a real one: the maximum does not notice)
+        a[l] = l < L ? v : 0.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one chunk's loads at a time
+    }
+  };
+  if (staged) layers(std::true_type{});
+  else layers(std::false_type{});
   disocc[(int64_t)m * HWd + p] = dis;
-  const float* oc = occ + ((int64_t)b * T + tpred) * L * L;
   float ox = 0.0f, oy = 0.0f;
+  float* ac = alpha_ctx + (int64_t)m * L * HWd;
+  // four columns j of the order per step, two and two on the packed-fp32 pipe (the product of every column
+  // runs over i in the same order as in the other kernels of the path)
 #pragma unroll
-  for (int j = 0; j < LP; ++j) {
-    const int jc = min(j, L - 1);
-    float prd = 1.0f;
+  for (int j = 0; j < LP; j += 4) {
+    f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+#ifdef WALDO_ABL_FCW_NOOCC  // timing-only ablation: without the L x L products
+    prd[0][0] = occm[j];
+#else
 #pragma unroll
-    for (int i = 0; i < LP; ++i) prd *= (1.0f - a[i] * oc[min(i, L - 1) * L + jc]);
-    const float v = a[j] * prd;  // 0 for padding layers
-    ox += v * fx[j];
-    oy += v * fy[j];
-    if (j < L) alpha_ctx[((int64_t)m * L + j) * HWd + p] = v * 2.0f - 1.0f;
-    // one column of occ (scalar loads) at a time: hoisting all L*L of them spills SGPRs
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < LP; ++i) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(occm + i * G::kOccRow + j);
+      const f32x2_w ai = {a[i], a[i]};
+      prd[0] = prd[0] * ((f32x2_w){1.0f, 1.0f} - ai * (f32x2_w){o[0], o[1]});
+      if (j + 2 < LP) prd[1] = prd[1] * ((f32x2_w){1.0f, 1.0f} - ai * (f32x2_w){o[2], o[3]});
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (j + k >= LP) break;
+      const float v = a[j + k] * prd[k >> 1][k & 1];  // 0 for padding layers
+      ox += v * fx[j + k];
+      oy += v * fy[j + k];
+#ifndef WALDO_ABL_FCW_NOSTORE
+      if (j + k < L) {
+        ac[p] = v * 2.0f - 1.0f;
+        ac += HWd;
+      }
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);  // a quad of columns at a time (bounds the registers)
   }
   flow[((int64_t)m * 2) * HWd + p] = ox;
   flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
@@ -198,10 +330,18 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
   // taps, score and source frame of every context of this pixel, in registers (branch-free over the
   // padded context count: a padding context repeats context Tc-1 and is never stored or summed)
   const int Tcx = Tc + (include_self ? 1 : 0);
-  uint32_t o00[TCP], o01[TCP], o10[TCP], o11[TCP];
+  // The two taps of a row are ONE 8-byte load at the pair origin xb = clamp(x0, 0, Wd - 2) (inside the row;
+  // 4-byte aligned: gfx950 takes unaligned dwordx2 loads): half the gather instructions of four single
+  // taps.  Within one texel of the left / right border the pair sits one column off the footprint
+  // (shift = x0 - xb = -1 / +1) and its elements are re-assigned to the corners; the corner outside the
+  // frame carries weight 0 as before.  Interior wavefronts (shift == 0 in every lane, for every context)
+  // skip the re-assignment.
+  uint32_t ob0[TCP], ob1[TCP];
+  int shift[TCP];
   float w00[TCP], w01[TCP], w10[TCP], w11[TCP], sc[TCP];
   const float* frame[TCP];
   float ssum = 0.0f;
+  bool shifted = false;
 #pragma unroll
   for (int tc = 0; tc < TCP; ++tc) {
     const int tcc = min(tc, Tc - 1);
@@ -209,15 +349,19 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const int64_t m = ((int64_t)b * Tc + tcc) * Tp + tp;
     const float* fl = flow + m * 2 * HWd + p;
     const Taps t = make_taps(gx0 + fl[0], gy0 + fl[HWd], Hd, Wd);
-    o00[tc] = t.o00;
-    o01[tc] = t.o01;
-    o10[tc] = t.o10;
-    o11[tc] = t.o11;
+    {
+      const int xb = min(max(t.x0, 0), Wd - 2);
+      const int cy0 = min(max(t.y0, 0), Hd - 1), cy1 = min(max(t.y0 + 1, 0), Hd - 1);
+      ob0[tc] = (uint32_t)(__mul24(cy0, Wd) + xb) * 4u;
+      ob1[tc] = (uint32_t)(__mul24(cy1, Wd) + xb) * 4u;
+      shift[tc] = t.x0 - xb;
+      shifted |= shift[tc] != 0;
+    }
     w00[tc] = t.w00;
     w01[tc] = t.w01;
     w10[tc] = t.w10;
     w11[tc] = t.w11;
-    const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1));
+    const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)));  // wave-uniform
     frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
     const float* al = alpha + m * L * HWd + p;
     float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + tcc) * (C + L) + C) * HWd + p;
@@ -248,6 +392,8 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
   // with the stores first every channel's taps would wait for the previous channel's stores to reach
   // memory -- gathers and stores then take turns instead of overlapping (timing ablations at the C5 size:
   // 4.5 ms as written that way, 3.3 without the raw stores, 3.3 without the gathers, 1.7 without both).
+  typedef float f32x2_fw __attribute__((ext_vector_type(2)));
+  const bool any_shift = __ballot(shifted) != 0ull;  // wave-uniform
   float tv[TCP][4];
   auto load_taps = [&](int c, float (&v)[TCP][4]) {
 #pragma unroll
@@ -256,17 +402,33 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
 #ifdef WALDO_ABL_FWF_NOGATHER  // timing-only ablation: one coalesced load instead of the four taps
       v[tc][0] = v[tc][1] = v[tc][2] = v[tc][3] = plane[p];
 #else
-      v[tc][0] = ldb(plane, o00[tc]);
-      v[tc][1] = ldb(plane, o01[tc]);
-      v[tc][2] = ldb(plane, o10[tc]);
-      v[tc][3] = ldb(plane, o11[tc]);
+      const f32x2_fw top = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob0[tc]);
+      const f32x2_fw bot = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob1[tc]);
+      v[tc][0] = top[0];
+      v[tc][1] = top[1];
+      v[tc][2] = bot[0];
+      v[tc][3] = bot[1];
 #endif
+    }
+  };
+  // corners of the footprint from the pair elements (see above); a no-op for interior wavefronts
+  auto assign = [&](float (&v)[TCP][4]) {
+    if (any_shift) {
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) {
+        const float a0 = v[tc][0], a1 = v[tc][1], b0 = v[tc][2], b1 = v[tc][3];
+        v[tc][0] = shift[tc] > 0 ? a1 : a0;
+        v[tc][1] = shift[tc] < 0 ? a0 : a1;
+        v[tc][2] = shift[tc] > 0 ? b1 : b0;
+        v[tc][3] = shift[tc] < 0 ? b0 : b1;
+      }
     }
   };
   load_taps(0, tv);
   for (int c = 0; c < C; ++c) {
     float nv[TCP][4];
     load_taps(min(c + 1, C - 1), nv);  // the last trip re-reads its own channel: no branch around the loads
+    assign(tv);
     const float vself = include_self ? self[(int64_t)c * HWd] : 0.0f;
     float acc = 0.0f;
 #pragma unroll
@@ -388,6 +550,10 @@ extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, 
     set_error("waldo_frame_warp_fuse_fwd: bad shape B=%d T=%d Tc=%d Tp=%d C=%d L=%d Hd=%d Wd=%d include_self=%d "
               "(at most %d contexts incl. self; include_self needs Tp == T)", B, T, Tc, Tp, C, L, Hd, Wd,
               include_self, kFwMaxCtx);
+    return WALDO_EINVAL;
+  }
+  if (Wd < 2 || Hd < 1) {
+    set_error("waldo_frame_warp_fuse_fwd: frames of %d x %d (need at least two columns)", Hd, Wd);
     return WALDO_EINVAL;
   }
   const int64_t units = (int64_t)B * Tp;

@@ -44,10 +44,16 @@ __device__ __forceinline__ UpTaps up_taps(int y, int x, float rscale, int H, int
   return t;
 }
 
+// the weighted sum of F.interpolate's four taps, rows first (six operations; the ONE form every kernel of
+// the path evaluates, whether the taps come from memory or from LDS)
+__device__ __forceinline__ float up_blend(const UpTaps& t, float v00, float v01, float v10, float v11) {
+  const float top = fmaf(t.lx1, v01, t.lx0 * v00);
+  const float bot = fmaf(t.lx1, v11, t.lx0 * v10);
+  return fmaf(t.ly1, bot, t.ly0 * top);
+}
+
 __device__ __forceinline__ float up_sample(const float* __restrict__ plane, const UpTaps& t) {
-  const float top = t.lx0 * ldb(plane, t.o00) + t.lx1 * ldb(plane, t.o01);
-  const float bot = t.lx0 * ldb(plane, t.o10) + t.lx1 * ldb(plane, t.o11);
-  return t.ly0 * top + t.ly1 * bot;
+  return up_blend(t, ldb(plane, t.o00), ldb(plane, t.o01), ldb(plane, t.o10), ldb(plane, t.o11));
 }
 
 constexpr int kMaxCls = 32;
@@ -99,6 +105,138 @@ __device__ __forceinline__ bool hd_pixel(int units, int Hd, int Wd, int tiles, i
   x = (tile - ty * ntx) * kHdCols + (int)(threadIdx.x & (kWave - 1));
   y = ty * kHdRows + (int)(threadIdx.x >> 6);
   return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Low-resolution planes of a tile, staged in LDS.  A 4 x 64 tile of the x S raster reads an
+// (4 / S + 2) x (64 / S + 2) patch of every low-resolution plane it upsamples; taken tap by tap from
+// memory that was 4 loads per plane and pixel (8 L + 4 (L - 1) vector-memory instructions per pixel in
+// flow_ctx_warp: the kernels count their memory INSTRUCTIONS as much as their bytes).
+// Here every thread loads at most one texel per plane, once, and the taps come out of LDS with the same
+// arithmetic as up_sample().  lr_patch() is wave-uniform; a patch of more than 256 texels (S == 1) or
+// more than kLrCap floats in all does not qualify (callers keep the direct path).
+// ---------------------------------------------------------------------------------------
+constexpr int kLrCap = 6144;  // floats of LDS for the staged planes (24 KB: four workgroups per CU and more)
+
+struct LrPatch {
+  int r_lo, c_lo, nrows, ncols;
+};
+
+__device__ __forceinline__ LrPatch lr_patch(int ty0, int tx0, int Hd, int Wd, float rscale, int H, int W) {
+  LrPatch q;
+  q.r_lo = up_tap(ty0, rscale, H).i0;
+  q.c_lo = up_tap(tx0, rscale, W).i0;
+  q.nrows = up_tap(min(ty0 + kHdRows - 1, Hd - 1), rscale, H).i1 - q.r_lo + 1;
+  q.ncols = up_tap(min(tx0 + kHdCols - 1, Wd - 1), rscale, W).i1 - q.c_lo + 1;
+  return q;
+}
+
+// planes [0, nplanes) of `src` (plane stride HW floats) into img[plane][nrows][ncols]; needs area <= kBlock.
+// No barrier inside.
+__device__ __forceinline__ void lr_stage(float* img, const float* __restrict__ src, int nplanes, int64_t HW, int W,
+                                         const LrPatch& q) {
+  const int area = q.nrows * q.ncols;
+  const int t = min((int)threadIdx.x, area - 1);
+  // t < 256, ncols < 256, the + 0.5: the approximate reciprocal gives the exact quotient
+  const int r = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)q.ncols));
+  const uint32_t off = (uint32_t)(__mul24(q.r_lo + r, W) + q.c_lo + (t - __mul24(r, q.ncols))) * 4u;
+  if ((int)threadIdx.x < area)
+    for (int pl = 0; pl < nplanes; ++pl) img[pl * area + t] = ldb(src + (int64_t)pl * HW, off);
+}
+
+// word offsets of a pixel's four taps inside one staged plane + the weights (those of up_taps())
+struct LrTaps {
+  int o00, o01, o10, o11;
+  float lx0, lx1, ly0, ly1;
+};
+
+__device__ __forceinline__ LrTaps lr_taps(int y, int x, float rscale, int H, int W, const LrPatch& q) {
+  const UpTap ty = up_tap(y, rscale, H), tx = up_tap(x, rscale, W);
+  LrTaps t;
+  const int r0 = __mul24(ty.i0 - q.r_lo, q.ncols), r1 = __mul24(ty.i1 - q.r_lo, q.ncols);
+  t.o00 = r0 + tx.i0 - q.c_lo;
+  t.o01 = r0 + tx.i1 - q.c_lo;
+  t.o10 = r1 + tx.i0 - q.c_lo;
+  t.o11 = r1 + tx.i1 - q.c_lo;
+  t.lx0 = tx.l0;
+  t.lx1 = tx.l1;
+  t.ly0 = ty.l0;
+  t.ly1 = ty.l1;
+  return t;
+}
+
+__device__ __forceinline__ float lr_sample(const float* plane_img, const LrTaps& t) {
+  const float top = t.lx0 * plane_img[t.o00] + t.lx1 * plane_img[t.o01];
+  const float bot = t.lx0 * plane_img[t.o10] + t.lx1 * plane_img[t.o11];
+  return t.ly0 * top + t.ly1 * bot;
+}
+
+// ---------------------------------------------------------------------------------------
+// Bilinear sample of F.grid_sample (zeros padding, align_corners=False) with the two taps of a row as
+// ONE 8-byte load at the pair origin xb = clamp(x0, 0, W - 2): half the gather instructions of four
+// single taps (unaligned dwordx2 loads are fine on gfx950).  Same value, bit for bit, as
+// tap_sample(plane, make_taps(gx, gy)): within one texel of the left / right border the pair sits one
+// column off the footprint and its elements are re-assigned to the corners (corners outside the image
+// carry validity 0 as before).  `interior` (wave-uniform: every lane has all four corners inside) skips
+// validity and re-assignment.
+// ---------------------------------------------------------------------------------------
+struct PairTaps {
+  uint32_t ob0, ob1;
+  float fx, fy;
+  int edge;  // border lanes only: validity of the corners (bits 0-3: 00, 01, 10, 11) and x0 - xb + 1 (bits 4-5)
+};
+
+__device__ __forceinline__ PairTaps pair_taps(float gx, float gy, int Hi, int Wi, bool& interior) {
+  const TapCore c = tap_core(gx, gy, Hi, Wi);
+  PairTaps t;
+  t.fx = c.fx;
+  t.fy = c.fy;
+  interior = __ballot(!tap_interior(c, Hi, Wi)) == 0ull;
+  if (interior) {
+    t.ob0 = (uint32_t)(__mul24(c.y0, Wi) + c.x0) * 4u;
+    t.ob1 = t.ob0 + (uint32_t)Wi * 4u;
+    t.edge = 15 | (1 << 4);
+  } else {
+    const Taps f = finish_taps(c, Hi, Wi);
+    const int xb = min(max(c.x0, 0), Wi - 2);
+    const int cy0 = min(max(c.y0, 0), Hi - 1), cy1 = min(max(c.y0 + 1, 0), Hi - 1);
+    t.ob0 = (uint32_t)(__mul24(cy0, Wi) + xb) * 4u;
+    t.ob1 = (uint32_t)(__mul24(cy1, Wi) + xb) * 4u;
+    // (the validities are 0 / 1: their products are conjunctions)
+    t.edge = (f.vx0 * f.vy0 != 0.0f ? 1 : 0) | (f.vx1 * f.vy0 != 0.0f ? 2 : 0) | (f.vx0 * f.vy1 != 0.0f ? 4 : 0) |
+             (f.vx1 * f.vy1 != 0.0f ? 8 : 0) | ((c.x0 - xb + 1) << 4);
+  }
+  return t;
+}
+
+typedef float f32x2_p __attribute__((ext_vector_type(2)));
+
+// the two loads and the arithmetic apart, so that a kernel can put the loads of MANY samples in flight
+// before it consumes the first (a wavefront that waits for each sample in turn is bound by the memory
+// latency times the number of samples)
+__device__ __forceinline__ void pair_load(const float* __restrict__ plane, const PairTaps& t, f32x2_p& a, f32x2_p& b) {
+  a = *reinterpret_cast<const f32x2_p*>(reinterpret_cast<const char*>(plane) + t.ob0);
+  b = *reinterpret_cast<const f32x2_p*>(reinterpret_cast<const char*>(plane) + t.ob1);
+}
+
+__device__ __forceinline__ float pair_value(const f32x2_p a, const f32x2_p b, const PairTaps& t, bool interior) {
+  float p00 = a[0], p01 = a[1], p10 = b[0], p11 = b[1];
+  if (!interior) {  // wave-uniform
+    const int shift = (t.edge >> 4) - 1;
+    p00 = (shift > 0 ? a[1] : a[0]) * ((t.edge & 1) ? 1.0f : 0.0f);
+    p01 = (shift < 0 ? a[0] : a[1]) * ((t.edge & 2) ? 1.0f : 0.0f);
+    p10 = (shift > 0 ? b[1] : b[0]) * ((t.edge & 4) ? 1.0f : 0.0f);
+    p11 = (shift < 0 ? b[0] : b[1]) * ((t.edge & 8) ? 1.0f : 0.0f);
+  }
+  const float top = fmaf(t.fx, p01 - p00, p00);
+  const float bot = fmaf(t.fx, p11 - p10, p10);
+  return fmaf(t.fy, bot - top, top);
+}
+
+__device__ __forceinline__ float pair_sample(const float* __restrict__ plane, const PairTaps& t, bool interior) {
+  f32x2_p a, b;
+  pair_load(plane, t, a, b);
+  return pair_value(a, b, t, interior);
 }
 
 constexpr int kFwMaxCtx = 8;  // contexts (incl. self) of the fused frame warp
