@@ -40,10 +40,10 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
   const int b = n / Tw, t = n % Tw;
   const int64_t p = (int64_t)y * Wd + x;
   // the objects' class distributions of this batch entry: broadcast reads from LDS
-  __shared__ float sdist[(32 - 1) * kMaxCls];
-  const int No = L - 1;
-  if (dist != nullptr)
-    for (int i = threadIdx.x; i < No * Nl; i += kBlock) sdist[i] = dist[(int64_t)b * No * Nl + i];
+  __shared__ __attribute__((aligned(16))) float sdist[(LP - 1) * kMaxCls];
+  __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
+  if (dist != nullptr) dist_stage<LP>(sdist, dist + (int64_t)b * (L - 1) * Nl, L, Nl);
+  occ_stage<LP>(occm, occ + ((int64_t)b * T + t) * L * L, L);
   __syncthreads();
   if (x >= Wd || y >= Hd) return;
   const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
@@ -72,31 +72,34 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 #pragma unroll
     for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
 #pragma unroll
-    for (int l = 1; l < LP; ++l) {
-      const int lc = min(l, L - 1) - 1;
-      float d = 0.0f;
-#pragma unroll
-      for (int c = 0; c < kMaxCls; ++c)
-        if (c < Nl) d += fabsf(sdist[lc * Nl + c] - pr[c]);
-      a[l] *= 1.0f - d / 2.0f;  // padding layers: a == 0 stays 0
-    }
+    for (int l = 1; l < LP; ++l) a[l] *= 1.0f - dist_l1(sdist + (l - 1) * kMaxCls, pr, Nl) / 2.0f;  // padding: 0 stays 0
   }
 
-  // padding layers carry alpha 0 (factor exactly 1); branch-free so that the arrays stay in registers
-  const float* oc = occ + ((int64_t)b * T + t) * L * L;
+  // padding layers carry alpha 0 (factor exactly 1); branch-free so that the arrays stay in registers.
+  // Four columns of the order per step (OccLds), two and two on the packed-fp32 pipe.
+  typedef float f32x2_w __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int j = 0; j < LP; ++j) {
-    const int jc = min(j, L - 1);
-    float prd = 1.0f;
+  for (int j = 0; j < LP; j += 4) {
+    f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
 #pragma unroll
-    for (int i = 0; i < LP; ++i) prd *= (1.0f - a[i] * oc[min(i, L - 1) * L + jc]);
-    const float v = a[j] * prd;
-    if (j < L) {
-      a01[((int64_t)n * L + j) * HWd + p] = v;
-      if (alpha_out != nullptr) alpha_out[((int64_t)n * L + j) * HWd + p] = v * 2.0f - 1.0f;
+    for (int i = 0; i < LP; ++i) {
+      const f32x4_o o = occ_quad<LP, false>(occm, i, j);
+      const f32x2_w ai = {a[i], a[i]};
+      const f32x2_w one = {1.0f, 1.0f};  // 1 - a o in one rounding (v_pk_fma_f32)
+      prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
+      if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
     }
-    // one column of occ (scalar loads) at a time: hoisting all L*L of them spills SGPRs
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (j + k >= LP) break;
+      const float v = a[j + k] * prd[k >> 1][k & 1];
+      if (j + k < L) {
+        a01[((int64_t)n * L + j + k) * HWd + p] = v;
+        if (alpha_out != nullptr) alpha_out[((int64_t)n * L + j + k) * HWd + p] = v * 2.0f - 1.0f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // a quad of columns at a time (bounds the registers)
   }
 }
 
@@ -112,7 +115,6 @@ template <int LP>
 struct FcwLds {
   static constexpr int kCell = 4 * LP + 4;             // floats per cell (+ 4: cells of a row on different banks)
   static constexpr int kCap = LP <= 12 ? 7168 : 8192;  // floats: 136 cells (x 2 upsampling) up to L = 12
-  static constexpr int kOccRow = (LP + 3) & ~3;        // row stride of the occlusion matrix (16-byte rows)
 };
 
 template <int LP>
@@ -137,18 +139,10 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   const int tpred = __builtin_amdgcn_readfirstlane((int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1)));
 
   __shared__ __attribute__((aligned(16))) float lrimg[G::kCap];
-  __shared__ __attribute__((aligned(16))) float occm[LP * G::kOccRow];
-  // ---- the order of the predicted frame, padded to LP x LP (a padding row / column repeats the last real
-  // one: its alpha is 0).  Read from LDS -- one broadcast ds_read_b128 per four columns -- instead of through
-  // the scalar cache: L x L scalar loads with a run-time row stride were ~7 SALU instructions EACH, and
-  // at L = 12 the kernel issued as many scalar as vector instructions (1480 / 1464 per wavefront).
-  {
-    const float* oc = occ + ((int64_t)b * T + tpred) * L * L;
-    for (int e = threadIdx.x; e < LP * G::kOccRow; e += kBlock) {
-      const int i = e / G::kOccRow, j = e - i * G::kOccRow;
-      occm[e] = oc[min(i, L - 1) * L + min(j, L - 1)];
-    }
-  }
+  // the order of the predicted frame from LDS (OccLds): at L = 12 the scalar loads made the kernel issue as
+  // many scalar as vector instructions (1480 / 1464 per wavefront)
+  __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
+  occ_stage<LP>(occm, occ + ((int64_t)b * T + tpred) * L * L, L);
   // ---- the tile's patch of the low-resolution planes (2 L flow planes, L - 1 object masks)
   const int nob = isobj_lr != nullptr ? L - 1 : 0;
   LrPatch lq = lr_patch(y - (int)(threadIdx.x >> 6), x - (int)(threadIdx.x & (kWave - 1)), Hd, Wd, rscale, H, W);
@@ -190,13 +184,13 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   // layers: the flows, taps and LOADS of the chunk first (twelve eight-byte loads in flight per lane), then
   // its values -- taken two layers at a time (round 2) a wavefront waits L / 2 times for memory, and at
   // three waves per SIMD that wait is what the kernel's time was made of.  Two copies of the loop, one per
-  // source of the low-resolution taps (the direct one keeps two layers in flight: its taps are 12 loads a layer).
+  // source of the low-resolution taps.
   float a[LP], fx[LP], fy[LP];
   float dis = -INFINITY;
   const float* ap = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer min(l, L - 1), stepped
   auto layers = [&](auto from_lds) {
     constexpr bool LDS = decltype(from_lds)::value;
-    constexpr int CH = !LDS ? 2 : (LP < WALDO_FCW_CHUNK ? LP : WALDO_FCW_CHUNK);  // layers whose loads are in flight together
+    constexpr int CH = LP < WALDO_FCW_CHUNK ? LP : WALDO_FCW_CHUNK;  // layers whose loads are in flight together
 #pragma unroll
     for (int l0 = 0; l0 < LP; l0 += CH) {
       PairTaps pt[CH];
@@ -266,10 +260,12 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 #else
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(occm + i * G::kOccRow + j);
+      const f32x4_o o = occ_quad<LP, false>(occm, i, j);
       const f32x2_w ai = {a[i], a[i]};
-      prd[0] = prd[0] * ((f32x2_w){1.0f, 1.0f} - ai * (f32x2_w){o[0], o[1]});
-      if (j + 2 < LP) prd[1] = prd[1] * ((f32x2_w){1.0f, 1.0f} - ai * (f32x2_w){o[2], o[3]});
+      // 1 - a o in one rounding (v_pk_fma_f32): four packed operations per row instead of six
+      const f32x2_w one = {1.0f, 1.0f};
+      prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
+      if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
     }
 #endif

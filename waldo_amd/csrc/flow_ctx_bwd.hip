@@ -37,9 +37,11 @@ __device__ __forceinline__ float sgnf(float x) { return (x > 0.0f ? 1.0f : 0.0f)
 
 // d loss / d a_i and d loss / d occ[i][j] of  v_j = a_j prod_i (1 - a_i occ[i][j])  for one pixel;
 // gv[j] = d loss / d v_j.  The occ gradients go, reduced over the wave, into the wave's LDS row.
+// occm: the order in LDS (OccLds; column j is a row of the transposed copy).  A padding layer has a == 0:
+// its factor is exactly 1 and its occ gradient exactly 0, no guard needed; its ga is never stored.
 template <int LP>
 __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float (&gv)[LP],
-                                              const float* __restrict__ oc, int L, float (&ga)[LP],
+                                              const float* occm, int L, float (&ga)[LP],
                                               float* acc_row, int lane) {
 #pragma unroll
   for (int l = 0; l < LP; ++l) ga[l] = 0.0f;
@@ -49,10 +51,17 @@ __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float 
       float tf[LP], ex[LP];
       float pre = 1.0f;
 #pragma unroll
-      for (int i = 0; i < LP; ++i) {
-        tf[i] = (i < L) ? (1.0f - a[i] * oc[i * L + j]) : 1.0f;
-        ex[i] = pre;
-        pre *= tf[i];
+      for (int i0 = 0; i0 < LP; i0 += 4) {
+        const f32x4_o o = occ_quad<LP, true>(occm, j, i0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k < LP ? i0 + k : LP - 1;
+          if (i0 + k < LP) {
+            tf[i] = 1.0f - a[i] * o[k];
+            ex[i] = pre;
+            pre *= tf[i];
+          }
+        }
       }
       float suf = 1.0f;
 #pragma unroll
@@ -64,12 +73,15 @@ __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float 
       const float gaj = gv[j] * a[j];
       float gocc[LP];
 #pragma unroll
-      for (int i = 0; i < LP; ++i) {
-        if (i < L) {
-          ga[i] = fmaf(-gaj * oc[i * L + j], ex[i], ga[i]);
-          gocc[i] = -gaj * a[i] * ex[i];
-        } else {
-          gocc[i] = 0.0f;
+      for (int i0 = 0; i0 < LP; i0 += 4) {
+        const f32x4_o o = occ_quad<LP, true>(occm, j, i0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k < LP ? i0 + k : LP - 1;
+          if (i0 + k < LP) {
+            ga[i] = fmaf(-gaj * o[k], ex[i], ga[i]);
+            gocc[i] = -gaj * a[i] * ex[i];
+          }
         }
       }
       if (acc_row != nullptr) {
@@ -95,18 +107,24 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
   const int t0 = (blockIdx.x % groups) * tiles_per_block, t1 = min(tiles, t0 + tiles_per_block);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int No = L - 1;
-  __shared__ float sdist[(32 - 1) * kMaxCls];
+  __shared__ __attribute__((aligned(16))) float sdist[(LP - 1) * kMaxCls];
+  __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
   __shared__ float acc_o[4][LP * LP];
   __shared__ float acc_d[4][(LP - 1) * kMaxCls];
   const bool filt = dist != nullptr;
-  if (filt)
-    for (int i = threadIdx.x; i < No * Nl; i += kBlock) sdist[i] = dist[(int64_t)b * No * Nl + i];
+  if (filt) dist_stage<LP>(sdist, dist + (int64_t)b * No * Nl, L, Nl);
+  occ_stage<LP>(occm, occ + ((int64_t)b * T + t) * L * L, L);
   for (int e = lane; e < LP * LP; e += kWave) acc_o[wave][e] = 0.0f;
   for (int e = lane; e < (LP - 1) * kMaxCls; e += kWave) acc_d[wave][e] = 0.0f;
   __syncthreads();
-  const float* oc = occ + ((int64_t)b * T + t) * L * L;
 
   for (int tile = t0; tile < t1; ++tile) {
+    // the LDS tables do not change while the workgroup walks its tiles, and the compiler knows: it would hoist
+    // all their reads out of this loop, into ~600 registers it does not have.  An offset it cannot see through:
+    int fresh = 0;
+    asm volatile("" : "+v"(fresh));
+    const float* occm_t = occm + fresh;
+    const float* sdist_t = sdist + fresh;
     const int64_t p = (int64_t)tile * kBlock + threadIdx.x;
     const bool live = p < HWd;
     const int64_t pc = live ? p : HWd - 1;
@@ -137,18 +155,11 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
 #pragma unroll
       for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
 #pragma unroll
-      for (int l = 1; l < LP; ++l) {
-        const int lc = min(l, L - 1) - 1;
-        float d = 0.0f;
-#pragma unroll
-        for (int c = 0; c < kMaxCls; ++c)
-          if (c < Nl) d += fabsf(sdist[lc * Nl + c] - pr[c]);
-        f[l] = 1.0f - d / 2.0f;
-      }
+      for (int l = 1; l < LP; ++l) f[l] = 1.0f - dist_l1(sdist_t + (l - 1) * kMaxCls, pr, Nl) / 2.0f;
     }
 #pragma unroll
     for (int l = 0; l < LP; ++l) a[l] = aup[l] * f[l];
-    composite_bwd<LP>(a, gv, oc, L, ga, g_occ != nullptr ? acc_o[wave] : nullptr, lane);
+    composite_bwd<LP>(a, gv, occm_t, L, ga, g_occ != nullptr ? acc_o[wave] : nullptr, lane);
     if (live) {
 #pragma unroll
       for (int l = 0; l < LP; ++l)
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
           float vals[kMaxCls];
 #pragma unroll
           for (int c = 0; c < kMaxCls; ++c)
-            vals[c] = (c < Nl) ? gf * sgnf(sdist[(l - 1) * Nl + min(c, Nl - 1)] - pr[c]) : 0.0f;
+            vals[c] = (c < Nl) ? gf * sgnf(sdist_t[(l - 1) * kMaxCls + c] - pr[c]) : 0.0f;
           const float red = wave_transpose_reduce<kMaxCls>(vals, lane);
           const int c = bitrev6(lane);
           if (c < Nl) acc_d[wave][(l - 1) * kMaxCls + c] += red;
@@ -206,13 +217,19 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_WARP_WAVES) void flow_ctx_warp_bw
   const int t0 = (blockIdx.x % groups) * tiles_per_block, t1 = min(tiles, t0 + tiles_per_block);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   __shared__ float acc_o[4][LP * LP];
+  __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
   for (int e = lane; e < LP * LP; e += kWave) acc_o[wave][e] = 0.0f;
-  const int ts = (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1));
-  const int tpred = (int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1));
-  const float* oc = occ + ((int64_t)b * T + tpred) * L * L;
+  // (wave-uniform; through the vector path they land in VGPRs and so does every plane address)
+  const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1)));
+  const int tpred = __builtin_amdgcn_readfirstlane((int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1)));
+  occ_stage<LP>(occm, occ + ((int64_t)b * T + tpred) * L * L, L);
+  __syncthreads();
   const float hw = 0.5f * (float)Wd, hh = 0.5f * (float)Hd;
 
   for (int tile = t0; tile < t1; ++tile) {
+    int fresh = 0;  // (see flow_ctx_alpha_bwd_kernel: keeps the reads of the order inside the loop)
+    asm volatile("" : "+v"(fresh));
+    const float* occm_t = occm + fresh;
     const int64_t p = (int64_t)tile * kBlock + threadIdx.x;
     const bool live = p < HWd;
     const int64_t pc = live ? p : HWd - 1;
@@ -222,29 +239,27 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_WARP_WAVES) void flow_ctx_warp_bw
     identity_grid(x, y, Wd, Hd, gx0, gy0);
     const float gfx = (g_flow != nullptr && live) ? g_flow[((int64_t)m * 2) * HWd + pc] : 0.0f;
     const float gfy = (g_flow != nullptr && live) ? g_flow[((int64_t)m * 2 + 1) * HWd + pc] : 0.0f;
-    // ---- forward values: a_l = sample of the context alpha at (pixel + flow_l) times the ghost
-    // mask; its derivatives w.r.t. the (unnormalised) sample position; the disocclusion arg max
-    float a[LP], fx[LP], fy[LP], sdx[LP], sdy[LP], gv[LP], ga[LP];
+    // ---- forward values: a_l = sample of the context alpha at (pixel + flow_l) times the ghost mask, and the
+    // disocclusion arg max.  Only a[] and gv[] outlive this loop: the flows, the taps and the derivatives of
+    // the samples are computed AGAIN in the last loop, where they are used -- kept (five more arrays of L) the
+    // kernel wanted 210+ registers at L = 17 and spent its time on ~600 spilled dwords per tile.
+    float a[LP], gv[LP], ga[LP];
     float dis = -INFINITY;
     int amax = 0;
+    const float* ap = a01 + (((int64_t)b * Tw + ts) * L) * HWd;
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
       const int lc = min(l, L - 1);
       const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW;
       const float fxl = up_sample(fl, ut), fyl = up_sample(fl + HW, ut);
       const Taps t = make_taps(gx0 + fxl, gy0 + fyl, Hd, Wd);
-      float ddx, ddy;
-      float v = tap_sample_d(a01 + (((int64_t)b * Tw + ts) * L + lc) * HWd, t, ddx, ddy);
+      float v = tap_sample(ap + (int64_t)lc * HWd, t);
       float ghost = 1.0f;
       if (isobj_lr != nullptr && l >= 1)
         ghost = (up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(lc - 1, 0)) * HW, ut) > 0.9f) ? 1.0f : 0.0f;
       const bool real = l < L;
       v *= ghost;
       a[l] = real ? v : 0.0f;
-      fx[l] = real ? fxl : 0.0f;
-      fy[l] = real ? fyl : 0.0f;
-      sdx[l] = real ? ddx * ghost : 0.0f;
-      sdy[l] = real ? ddy * ghost : 0.0f;
       if (real && v > dis) {
         dis = v;
         amax = l;
@@ -253,50 +268,61 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_WARP_WAVES) void flow_ctx_warp_bw
       if (real && live && g_actx != nullptr) gv[l] = fmaf(2.0f, g_actx[((int64_t)m * L + lc) * HWd + pc], gv[l]);
       if ((l & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
-    // v_j (the composited alphas) are needed for d flow / d f_j: recompute them with the products
-    float vj[LP];
-#pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int jc = min(j, L - 1);
-      float prd = 1.0f;
-#pragma unroll
-      for (int i = 0; i < LP; ++i) prd *= (1.0f - a[i] * oc[min(i, L - 1) * L + jc]);
-      vj[j] = a[j] * prd;
-    }
-    composite_bwd<LP>(a, gv, oc, L, ga, g_occ != nullptr ? acc_o[wave] : nullptr, lane);
+    composite_bwd<LP>(a, gv, occm_t, L, ga, g_occ != nullptr ? acc_o[wave] : nullptr, lane);
     const float gd = (g_dis != nullptr && live) ? g_dis[(int64_t)m * HWd + pc] : 0.0f;
+    typedef float f32x2_w __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int l = 0; l < LP; ++l) {
-      if (l < L) {  // wave-uniform
-        const float gs = ga[l] + (l == amax ? gd : 0.0f);  // d loss / d a_l
-        // d / d flow_l: through the flow composite and through the sample position
-        const float gfxl = fmaf(gs * sdx[l], hw, vj[l] * gfx);
-        const float gfyl = fmaf(gs * sdy[l], hh, vj[l] * gfy);
-        if (live) {
-          g_fup[(((int64_t)m * L + l) * 2) * HWd + p] = gfxl;
-          g_fup[(((int64_t)m * L + l) * 2 + 1) * HWd + p] = gfyl;
-        }
-        // d / d a01: bilinear splat of gs * ghost (sdx carries the ghost factor; recompute it here
-        // from the taps' point of view: a ghosted layer has sdx == sdy == 0 and a == 0 ...)
-        if (g_a01 != nullptr) {
+    for (int j = 0; j < LP; j += 4) {
+      // v_j (the composited alphas) of four layers, as the forward kernel takes them (same bits) ...
+      f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const f32x4_o o = occ_quad<LP, false>(occm_t, i, j);
+        const f32x2_w ai = {a[i], a[i]}, one = {1.0f, 1.0f};
+        prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
+        if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
+      }
+      // ... and their part of the backward
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int l = j + k < LP ? j + k : LP - 1;
+        if (j + k < LP && l < L) {  // wave-uniform
+          const float vjl = a[l] * prd[k >> 1][k & 1];
+          const float* fl = flow_lr + (((int64_t)m * L + l) * 2) * HW;
+          const float fxl = up_sample(fl, ut), fyl = up_sample(fl + HW, ut);
           float ghost = 1.0f;
           if (isobj_lr != nullptr && l >= 1)
             ghost = (up_sample(isobj_lr + ((int64_t)m * (L - 1) + (l - 1)) * HW, ut) > 0.9f) ? 1.0f : 0.0f;
-          const float gsg = live ? gs * ghost : 0.0f;
-          if (gsg != 0.0f) {
-            const Taps t = make_taps(gx0 + fx[l], gy0 + fy[l], Hd, Wd);
-            float* gp = g_a01 + (((int64_t)b * Tw + ts) * L + l) * HWd;
-            // the lerp form's weights: (1-fx)(1-fy) v00 ... with the validity of each corner
-            const float wx0 = 1.0f - t.fx, wy0 = 1.0f - t.fy;
-            const float w00 = wx0 * wy0 * (t.vx0 * t.vy0), w01 = t.fx * wy0 * (t.vx1 * t.vy0);
-            const float w10 = wx0 * t.fy * (t.vx0 * t.vy1), w11 = t.fx * t.fy * (t.vx1 * t.vy1);
-            if (w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gsg * w00);
-            if (w01 != 0.0f) atomicAdd(gp + (t.o01 >> 2), gsg * w01);
-            if (w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gsg * w10);
-            if (w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gsg * w11);
+          const Taps t = make_taps(gx0 + fxl, gy0 + fyl, Hd, Wd);
+          float ddx, ddy;
+          (void)tap_sample_d(ap + (int64_t)l * HWd, t, ddx, ddy);
+          const float gs = ga[l] + (l == amax ? gd : 0.0f);  // d loss / d a_l
+          // d / d flow_l: through the flow composite and through the sample position
+          const float gfxl = fmaf(gs * (ddx * ghost), hw, vjl * gfx);
+          const float gfyl = fmaf(gs * (ddy * ghost), hh, vjl * gfy);
+          if (live) {
+            g_fup[(((int64_t)m * L + l) * 2) * HWd + p] = gfxl;
+            g_fup[(((int64_t)m * L + l) * 2 + 1) * HWd + p] = gfyl;
+          }
+          // d / d a01: bilinear splat of gs * ghost
+          if (g_a01 != nullptr) {
+            const float gsg = live ? gs * ghost : 0.0f;
+            if (gsg != 0.0f) {
+              float* gp = g_a01 + (((int64_t)b * Tw + ts) * L + l) * HWd;
+              // the lerp form's weights: (1-fx)(1-fy) v00 ... with the validity of each corner
+              const float wx0 = 1.0f - t.fx, wy0 = 1.0f - t.fy;
+              const float w00 = wx0 * wy0 * (t.vx0 * t.vy0), w01 = t.fx * wy0 * (t.vx1 * t.vy0);
+              const float w10 = wx0 * t.fy * (t.vx0 * t.vy1), w11 = t.fx * t.fy * (t.vx1 * t.vy1);
+              if (w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gsg * w00);
+              if (w01 != 0.0f) atomicAdd(gp + (t.o01 >> 2), gsg * w01);
+              if (w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gsg * w10);
+              if (w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gsg * w11);
+            }
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();

@@ -28,6 +28,7 @@ __device__ __forceinline__ UpTap up_tap(int dst, float rscale, int size) {
 struct UpTaps {
   uint32_t o00, o01, o10, o11;
   float lx0, lx1, ly0, ly1;
+  bool unit;  // scale factor 1 (uniform): the plane itself, as the reference's scale() returns it (lvd.py:175-179)
 };
 
 __device__ __forceinline__ UpTaps up_taps(int y, int x, float rscale, int H, int W) {
@@ -41,6 +42,7 @@ __device__ __forceinline__ UpTaps up_taps(int y, int x, float rscale, int H, int
   t.lx1 = tx.l1;
   t.ly0 = ty.l0;
   t.ly1 = ty.l1;
+  t.unit = rscale == 1.0f;
   return t;
 }
 
@@ -53,10 +55,76 @@ __device__ __forceinline__ float up_blend(const UpTaps& t, float v00, float v01,
 }
 
 __device__ __forceinline__ float up_sample(const float* __restrict__ plane, const UpTaps& t) {
+  // (at scale 1 the taps are i0 = the pixel with weight 1 and a neighbour with weight 0: one load, not four --
+  // the LVD recipe trains without a full-resolution raster and every upsampling of its step is this one)
+  if (t.unit) return ldb(plane, t.o00);
   return up_blend(t, ldb(plane, t.o00), ldb(plane, t.o01), ldb(plane, t.o10), ldb(plane, t.o11));
 }
 
 constexpr int kMaxCls = 32;
+
+// ---------------------------------------------------------------------------------------
+// The order (occlusion matrix) of one frame in LDS, padded to LP x LP: by rows ([i][j], row stride kRow)
+// and transposed ([j][i]).  A padding row / column repeats the last real one -- its layer's alpha is 0, so
+// its factor 1 - a occ is exactly 1 and nothing needs a guard.  The kernels used to read occ[i * L + j]
+// through the scalar cache: with the run-time stride that is ~7 SALU instructions per element and, what
+// costs more, an s_waitcnt per handful of loads (hoisting L x L of them runs out of SGPRs) -- at L = 17 the
+// backward kernels spent most of their 40 us per tile waiting for ~870 scalar loads in turn.  From LDS the
+// same values are broadcast ds_read_b128 with compile-time addresses, many in flight.
+// ---------------------------------------------------------------------------------------
+template <int LP>
+struct OccLds {
+  static constexpr int kRow = (LP + 3) & ~3;
+  static constexpr int kFloats = 2 * LP * kRow;
+};
+
+// block-wide; no barrier inside
+template <int LP>
+__device__ __forceinline__ void occ_stage(float* occm, const float* __restrict__ oc, int L) {
+  constexpr int R = OccLds<LP>::kRow;
+  for (int e = threadIdx.x; e < LP * R; e += kBlock) {
+    const int r = e / R, c = e - r * R;
+    const int rc = min(r, L - 1), cc = min(c, L - 1);
+    occm[e] = oc[rc * L + cc];           // [i = r][j = c]
+    occm[LP * R + e] = oc[cc * L + rc];  // [j = r][i = c]
+  }
+}
+
+typedef float f32x4_o __attribute__((ext_vector_type(4)));
+
+// The objects' class distributions of one batch entry in LDS: one row of kMaxCls floats per layer 1 .. LP - 1
+// (row l - 1 = object min(l, L - 1) - 1; zeros from class Nl on, and everywhere when there is no object), so
+// that a layer's row sits at a compile-time address and is read four classes at a time -- it was a branch, a
+// ds_read_b32 and a wait per (layer, class).  Block-wide; no barrier inside.
+template <int LP>
+__device__ __forceinline__ void dist_stage(float* sdist, const float* __restrict__ dist_b, int L, int Nl) {
+  const int No = L - 1;
+  for (int e = threadIdx.x; e < (LP - 1) * kMaxCls; e += kBlock) {
+    const int r = e / kMaxCls, c = e - r * kMaxCls;
+    sdist[e] = (c < Nl && No > 0) ? dist_b[min(r, No - 1) * Nl + c] : 0.0f;
+  }
+}
+
+// sum_c |dist[row][c] - pr[c]| over the Nl classes in ascending order (pr[c] == 0 from class Nl on: the
+// padding of a group of four adds exact zeros)
+__device__ __forceinline__ float dist_l1(const float* sdist_row, const float (&pr)[kMaxCls], int Nl) {
+  float d = 0.0f;
+#pragma unroll
+  for (int c = 0; c < kMaxCls; c += 4)
+    if (c < Nl) {  // uniform
+      const f32x4_o q = *reinterpret_cast<const f32x4_o*>(sdist_row + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d += fabsf(q[k] - pr[c + k]);
+    }
+  return d;
+}
+
+// elements [c0, c0 + 4) of row r of the row-major (T = false) or transposed (T = true) copy
+template <int LP, bool T>
+__device__ __forceinline__ f32x4_o occ_quad(const float* occm, int r, int c0) {
+  constexpr int R = OccLds<LP>::kRow;
+  return *reinterpret_cast<const f32x4_o*>(occm + (T ? LP * R : 0) + r * R + c0);
+}
 
 
 // texel centre (x, y) of the identity grid as get_grid() builds it: torch.linspace(start, end, n)

@@ -95,8 +95,8 @@ __device__ __forceinline__ TapCore tap_core(float gx, float gy, int Hi, int Wi) 
   float iy = unnormalize(gy, Hi);
   // keep the float->int conversion defined for wild / NaN coordinates; anything clamped here has
   // all four corners outside the image anyway
-  ix = fminf(fmaxf(ix, -2.0f), (float)Wi + 1.0f);
-  iy = fminf(fmaxf(iy, -2.0f), (float)Hi + 1.0f);
+  ix = __builtin_amdgcn_fmed3f(ix, -2.0f, (float)Wi + 1.0f);  // (NaN -> -2, as fminf(fmaxf()) gave)
+  iy = __builtin_amdgcn_fmed3f(iy, -2.0f, (float)Hi + 1.0f);
   const float x0f = floorf(ix), y0f = floorf(iy);
   TapCore c;
   c.fx = ix - x0f;
