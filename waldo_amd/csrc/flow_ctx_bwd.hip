@@ -130,10 +130,10 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
     const int64_t pc = live ? p : HWd - 1;
     const int y = (int)(pc / Wd), x = (int)(pc - (int64_t)y * Wd);
     const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
-    float aup[LP], f[LP], a[LP], gv[LP], ga[LP];
+    // (the upsampled rough alpha is not kept across the composite: it is one load to have again)
+    float f[LP], a[LP], gv[LP], ga[LP];
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
-      aup[l] = (l < L) ? up_sample(alpha_lr + ((int64_t)n * L + min(l, L - 1)) * HW, ut) : 0.0f;
       f[l] = 1.0f;
       gv[l] = (l < L && live) ? g_a01[((int64_t)n * L + min(l, L - 1)) * HWd + pc] : 0.0f;
     }
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
       for (int l = 1; l < LP; ++l) f[l] = 1.0f - dist_l1(sdist_t + (l - 1) * kMaxCls, pr, Nl) / 2.0f;
     }
 #pragma unroll
-    for (int l = 0; l < LP; ++l) a[l] = aup[l] * f[l];
+    for (int l = 0; l < LP; ++l)
+      a[l] = (l < L) ? up_sample(alpha_lr + ((int64_t)n * L + min(l, L - 1)) * HW, ut) * f[l] : 0.0f;
     composite_bwd<LP>(a, gv, occm_t, L, ga, g_occ != nullptr ? acc_o[wave] : nullptr, lane);
     if (live) {
 #pragma unroll
@@ -170,11 +171,16 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
 #pragma unroll
       for (int l = 1; l < LP; ++l) {
         if (l < L) {  // wave-uniform
-          const float gf = live ? -0.5f * ga[l] * aup[l] : 0.0f;
+          const float aup = up_sample(alpha_lr + ((int64_t)n * L + l) * HW, ut);
+          const float gf = live ? -0.5f * ga[l] * aup : 0.0f;
           float vals[kMaxCls];
 #pragma unroll
-          for (int c = 0; c < kMaxCls; ++c)
-            vals[c] = (c < Nl) ? gf * sgnf(sdist_t[(l - 1) * kMaxCls + c] - pr[c]) : 0.0f;
+          for (int c = 0; c < kMaxCls; ++c) {
+            // gf sign(d): gf with d's sign bit (v_bfi), or 0 where d == 0 -- four operations, not seven
+            // (classes from Nl on: dist and pr are both 0 there)
+            const float d = sdist_t[(l - 1) * kMaxCls + c] - pr[c];
+            vals[c] = d == 0.0f ? 0.0f : gf * __builtin_copysignf(1.0f, d);
+          }
           const float red = wave_transpose_reduce<kMaxCls>(vals, lane);
           const int c = bitrev6(lane);
           if (c < Nl) acc_d[wave][(l - 1) * kMaxCls + c] += red;
