@@ -363,6 +363,25 @@ int waldo_wif_fuse_bwd(const float* vid, const float* net, const float* out, con
                        float* grad_vid, float* grad_net, int64_t N, int Tc, int C, int Co,
                        int64_t HW, int ab, waldo_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * A8. gather_time (models/nets/lvd.py:462-467) with the frame arithmetic of the flow synthesis
+ * (lvd.py:660-668, 780-787) on a clip's grids x (B,T,P,2) -- P pairs per frame:
+ *   subtract != 0:  out[b,tc,tp] = x[b, ctx_ts[b,tc,tp]] - x[b, pred_ts[tp]]   (layer-space flow)
+ *   subtract == 0:  out[b,tc,tp] = x[b, ctx_ts[b,tc,tp]]  (gather_time), or, with ctx_ts == NULL,
+ *                   x[b, pred_ts[tp]] repeated over the Tc contexts (the `[:, pred_ts].unsqueeze(1).expand`)
+ *   HW > 0 (a divisor of P): out is written channel-first, (B,Tc,Tp,P/HW,2,HW) -- the
+ *   permute(..., 6, 4, 5) + reshape of lvd.py:662-664; HW == 0: (B,Tc,Tp,P,2).
+ * ctx_ts (B,Tc,Tp) / pred_ts (Tp) int64 on the device, clamped to [0,T).
+ * Backward: grad_x (B,T,P,2) is OVERWRITTEN with the sum over the output frames that read each input
+ * frame (a gather: deterministic, no atomics, no zero fill needed).
+ * ------------------------------------------------------------------------------------- */
+int waldo_time_gather_fwd(const float* x, const int64_t* ctx_ts, const int64_t* pred_ts, float* out,
+                          int B, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
+                          waldo_stream_t stream);
+int waldo_time_gather_bwd(const float* grad_out, const int64_t* ctx_ts, const int64_t* pred_ts,
+                          float* grad_x, int B, int T, int Tc, int Tp, int64_t P, int64_t HW,
+                          int subtract, waldo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

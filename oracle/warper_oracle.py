@@ -81,6 +81,19 @@ def gather_time(t, ts):
     return out.reshape(b, tc, tp, *t.shape[2:])
 
 
+def layer_flows(grid, ctx_ts, pred_ts):
+    """The layer-space flows and the predicted frames' grids as ``Warper.grid_to_flow[_ctx]`` spells them
+    (lvd.py:660-668 / 779-787), the expressions ``waldo_time_gather_*`` replaces:
+    (obj_flow (B,Tc,Tp,No,2,Ho,Wo), bg_flow (B,Tc,Tp,2,H,W), sgo (B,Tc,Tp,No,H,W,2), sgb (B,Tc,Tp,H,W,2))."""
+    tgo, sgo, tgb, sgb = grid
+    tc = ctx_ts.shape[1]
+    obj_flow = (gather_time(tgo, ctx_ts) - tgo[:, pred_ts].unsqueeze(1)).permute(0, 1, 2, 3, 6, 4, 5)
+    bg_flow = (gather_time(tgb, ctx_ts) - tgb[:, pred_ts].unsqueeze(1)).permute(0, 1, 2, 5, 3, 4)
+    sgo_p = sgo[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1, -1)
+    sgb_p = sgb[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1)
+    return obj_flow, bg_flow, sgo_p, sgb_p
+
+
 # --------------------------------------------------------------------------------------
 # A13: the four grids
 # --------------------------------------------------------------------------------------

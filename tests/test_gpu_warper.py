@@ -455,6 +455,45 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 3, 4, 3, 6, 5, 7), (1, 3, 1, 1, 1, 2, 2, 3), (2, 4, 5, 2, 2, 8, 16, 8)])
+def test_time_gather_against_the_spelled_out_expressions(dev, shape):
+    """waldo_time_gather_* against gather_time / [:, pred_ts] / subtract / permute / expand as the reference
+    writes them (oracle.layer_flows): values bit for bit (a subtraction and copies), gradients -- sums over
+    the output frames that read an input frame, repeated indices included -- against autograd's."""
+    from waldo_amd import functional as WF
+    from waldo_amd._lib import WaldoHipError
+    b, t, tc, tp, no, ho, h, w = shape
+    g = torch.Generator().manual_seed(b * 100 + t)
+    grid = [torch.randn(b, t, no, ho, ho + 1, 2, generator=g), torch.randn(b, t, no, h, w, 2, generator=g),
+            torch.randn(b, t, h, w, 2, generator=g), torch.randn(b, t, h, w, 2, generator=g)]
+    ctx_ts = torch.randint(0, t, (b, tc, tp), generator=g)   # repeats on purpose
+    pred_ts = torch.randint(0, t, (tp,), generator=g)
+    ref_in = [x.clone().requires_grad_() for x in grid]
+    ref = WO.layer_flows(ref_in, ctx_ts, pred_ts)
+    hip_in = [x.to(dev).requires_grad_() for x in grid]
+    cd, pd = ctx_ts.to(dev), pred_ts.to(dev)
+    hip = (WF.time_gather(hip_in[0], cd, pd, subtract=True, channel_first=True),
+           WF.time_gather(hip_in[2].unsqueeze(2), cd, pd, subtract=True, channel_first=True).squeeze(3),
+           WF.time_gather(hip_in[1], None, pd, num_ctx=tc), WF.time_gather(hip_in[3], None, pd, num_ctx=tc))
+    ws = [torch.randn(r.shape, generator=g) for r in ref]
+    for r, o in zip(ref, hip):
+        assert tuple(o.shape) == tuple(r.shape)
+        assert torch.equal(o.detach().cpu(), r.detach())
+    sum((r * wt).sum() for r, wt in zip(ref, ws)).backward()
+    sum((o * wt.to(dev)).sum() for o, wt in zip(hip, ws)).backward()
+    for name, r, o in zip(("tgt_grid_obj", "src_grid_obj", "tgt_grid_bg", "src_grid_bg"), ref_in, hip_in):
+        close(o.grad.cpu(), r.grad, 1e-5, what=f"grad {name}")
+    # plain gather_time, and the index checks the reference's gather() makes
+    out = WF.time_gather(hip_in[3].detach(), cd, pd)
+    assert torch.equal(out.cpu(), WO.gather_time(grid[3], ctx_ts))
+    with pytest.raises(WaldoHipError):
+        WF.time_gather(hip_in[3].detach(), cd + t, pd)
+    with pytest.raises(WaldoHipError):
+        WF.time_gather(hip_in[3].detach(), None, pd, subtract=True)
+    empty = WF.time_gather(hip_in[3].detach()[:0], cd[:0], pd)
+    assert tuple(empty.shape) == (0, tc, tp, h, w, 2)
+
+
 def test_time_indices_outside_the_window_are_refused(dev):
     """gather_time (lvd.py:462-467) raises for an index outside the time axis; the fused kernels index
     with ctx_ts / pred_ts directly, so the wrappers validate them instead of clamping silently."""

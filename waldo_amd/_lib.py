@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1004
+ABI_VERSION = 1005
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -55,6 +55,8 @@ SIGNATURES = {
     "waldo_wif_fuse_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _stream],
     "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
                            _stream],
+    "waldo_time_gather_fwd": [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _i64, _i64, _int, _stream],
+    "waldo_time_gather_bwd": [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _i64, _i64, _int, _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
                                  _flt, _stream],
     "waldo_warp_composite_pts_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,

@@ -4,6 +4,7 @@ Every function here launches hand-written gfx950 kernels on the caller's current
 function has a CPU or eager-PyTorch fallback (``_lib.check_cuda`` raises on CPU tensors).
 PyTorch is used for memory (output allocation), streams and autograd bookkeeping only.
 """
+import math
 import weakref
 
 import torch
@@ -713,6 +714,74 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
             f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
     _check_time_index("frame_warp_fuse", "ctx_ts", ctx_ts, t)
     return _FrameWarpFuse.apply(input, flow, alpha, ctx_ts, bool(include_self), eps)
+
+
+# --------------------------------------------------------------------------------------
+# A8: gather_time and the frame arithmetic built on it
+# --------------------------------------------------------------------------------------
+class _TimeGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ctx_ts, pred_ts, tc, hw, subtract):
+        b, t = x.shape[:2]
+        p = math.prod(x.shape[2:]) // 2
+        tp = pred_ts.numel()
+        out = x.new_empty(b, tc, tp, *((p // hw, 2, hw) if hw else (p, 2)))
+        with torch.cuda.device(x.device):
+            _lib.call("waldo_time_gather_fwd", _lib.ptr(x), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(out),
+                      b, t, tc, tp, p, hw, int(subtract), _lib.current_stream(x.device))
+        ctx.save_for_backward(ctx_ts, pred_ts)
+        ctx.cfg = (tuple(x.shape), tc, hw, subtract)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx_ts, pred_ts = ctx.saved_tensors
+        shape, tc, hw, subtract = ctx.cfg
+        grad_out = _c(grad_out)
+        gx = grad_out.new_empty(shape)
+        b, t = shape[:2]
+        with torch.cuda.device(grad_out.device):
+            _lib.call("waldo_time_gather_bwd", _lib.ptr(grad_out), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(gx),
+                      b, t, tc, pred_ts.numel(), math.prod(shape[2:]) // 2, hw, int(subtract),
+                      _lib.current_stream(grad_out.device))
+        return gx, None, None, None, None, None
+
+
+def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=False):
+    """``gather_time`` (models/nets/lvd.py:462-467) and the frame arithmetic of the flow synthesis
+    (lvd.py:660-668, 780-787) on a clip's grids ``x`` (B, T, ..., 2):
+
+    - ``subtract``: ``gather_time(x, ctx_ts) - x[:, pred_ts].unsqueeze(1)``            -> (B, Tc, Tp, ..., 2)
+    - ``ctx_ts is None``: ``x[:, pred_ts].unsqueeze(1).expand(-1, num_ctx, ...)``     -> (B, num_ctx, Tp, ..., 2)
+    - otherwise ``gather_time(x, ctx_ts)``.
+
+    ``channel_first``: x is (B, T, N, H, W, 2) and the result (B, Tc, Tp, N, 2, H, W) -- the
+    ``permute(0, 1, 2, 3, 6, 4, 5)`` of lvd.py:662.  Differentiable w.r.t. ``x``."""
+    _lib.check_cuda(x)
+    if x.ndim < 3 or x.shape[-1] != 2 or (channel_first and x.ndim != 6):
+        raise _lib.WaldoHipError(f"time_gather: x {tuple(x.shape)} is not a clip of grids (B, T, ..., 2)")
+    if not pred_ts.is_cuda or (ctx_ts is not None and not ctx_ts.is_cuda):
+        raise _lib.WaldoHipError("time_gather: frame indices must be on the GPU")
+    x = _c(x.float())
+    pred_ts = _c(pred_ts.long())
+    b, t = x.shape[:2]
+    if ctx_ts is not None:
+        ctx_ts = _c(ctx_ts.long())
+        if ctx_ts.ndim != 3 or ctx_ts.shape[0] != b or ctx_ts.shape[2] != pred_ts.numel():
+            raise _lib.WaldoHipError(f"time_gather: ctx_ts {tuple(ctx_ts.shape)} against B={b}, Tp={pred_ts.numel()}")
+        tc = ctx_ts.shape[1]
+        _check_time_index("time_gather", "ctx_ts", ctx_ts, t)
+    else:
+        if subtract or num_ctx is None:
+            raise _lib.WaldoHipError("time_gather: without ctx_ts give num_ctx (and no difference)")
+        tc = int(num_ctx)
+    _check_time_index("time_gather", "pred_ts", pred_ts, t)
+    hw = x.shape[3] * x.shape[4] if channel_first else 0
+    out = _TimeGather.apply(x, ctx_ts, pred_ts, tc, hw, bool(subtract))
+    tp = pred_ts.numel()
+    if channel_first:
+        return out.view(b, tc, tp, x.shape[2], 2, x.shape[3], x.shape[4])
+    return out.view(b, tc, tp, *x.shape[2:])
 
 
 # --------------------------------------------------------------------------------------

@@ -261,6 +261,28 @@ class Warper(nn.Module):
                 and self.src_shape_hd[0] == self.src_shape[0] * int(s)
                 and self.src_shape_hd[1] == self.src_shape[1] * int(s))
 
+    def _layer_flows(self, grid, ctx_ts, pred_ts):
+        """The layer-space flows between the context and the predicted frames and the predicted frames'
+        source grids repeated over the contexts (lvd.py:660-668 / 780-787):
+
+            obj_flow = gather_time(tgt_grid_obj, ctx_ts) - tgt_grid_obj[:, pred_ts].unsqueeze(1)
+            obj_flow = obj_flow.permute(0, 1, 2, 3, 6, 4, 5).view(B * Tc, Tp, No, 2, Ho, Wo)     (bg alike)
+            src_grid_obj[:, pred_ts].unsqueeze(1).expand(-1, Tc, ...).view(B * Tc, Tp, No, H, W, 2)
+
+        each as one ``waldo_time_gather`` launch (forward and backward) instead of the gather /
+        advanced-index / subtract / permute / copy kernels of the spelled-out form."""
+        tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
+        b, _, no = src_grid_obj.shape[:3]
+        tc, tp = ctx_ts.size(1), pred_ts.size(0)
+        h, w = self.src_shape
+        ho, wo = self.tgt_shape
+        obj_flow = WF.time_gather(tgt_grid_obj, ctx_ts, pred_ts, subtract=True, channel_first=True)
+        bg_flow = WF.time_gather(tgt_grid_bg.unsqueeze(2), ctx_ts, pred_ts, subtract=True, channel_first=True)
+        sgo = WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=tc)
+        sgb = WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=tc)
+        return (obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w),
+                sgo.reshape(b * tc, tp, no, h, w, 2), sgb.reshape(b * tc, tp, h, w, 2))
+
     def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
         """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
         the low resolution goes through the same per-op kernels as the unfused path."""
@@ -282,12 +304,7 @@ class Warper(nn.Module):
         occ = occ.reshape(b, t, nl, nl)
         a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ, tw, 3, s)
 
-        obj_flow = gather_time(tgt_grid_obj, ctx_ts) - tgt_grid_obj[:, pred_ts].unsqueeze(1)
-        obj_flow = obj_flow.permute(0, 1, 2, 3, 6, 4, 5).reshape(b * tc, tp, no, 2, ho, wo)
-        bg_flow = gather_time(tgt_grid_bg, ctx_ts) - tgt_grid_bg[:, pred_ts].unsqueeze(1)
-        bg_flow = bg_flow.permute(0, 1, 2, 5, 3, 4).reshape(b * tc, tp, 2, h, w)
-        sgo = src_grid_obj[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1, -1).reshape(b * tc, tp, no, h, w, 2)
-        sgb = src_grid_bg[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1).reshape(b * tc, tp, h, w, 2)
+        obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
         is_obj = None
         if ctx_only and not self.allow_ghost:
@@ -329,12 +346,7 @@ class Warper(nn.Module):
         alpha_unflt = alpha
 
         # per-layer flow in layer space between context and predicted frames, warped to the image
-        obj_flow = gather_time(tgt_grid_obj, ctx_ts) - tgt_grid_obj[:, pred_ts].unsqueeze(1)
-        obj_flow = obj_flow.permute(0, 1, 2, 3, 6, 4, 5).reshape(b * tc, tp, no, 2, ho, wo)
-        bg_flow = gather_time(tgt_grid_bg, ctx_ts) - tgt_grid_bg[:, pred_ts].unsqueeze(1)
-        bg_flow = bg_flow.permute(0, 1, 2, 5, 3, 4).reshape(b * tc, tp, 2, h, w)
-        sgo = src_grid_obj[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1, -1).reshape(b * tc, tp, no, h, w, 2)
-        sgb = src_grid_bg[:, pred_ts].unsqueeze(1).expand(-1, tc, -1, -1, -1, -1).reshape(b * tc, tp, h, w, 2)
+        obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
         is_obj = 1
         if ctx_only and not self.allow_ghost:
