@@ -21,6 +21,8 @@ ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--dim', type=int, default=128)
 ap.add_argument('--scale', type=int, default=4)
 ap.add_argument('--layers', type=int, default=12)
+ap.add_argument('--amp', type=float, default=0.02, help='flow amplitude in grid units (0.02 = 10 px at 1024)')
+ap.add_argument('--coarse', type=int, default=32, help='the flow is smooth over this many pixels')
 ap.add_argument('libs', nargs='+')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -31,7 +33,7 @@ h, w, s = a.dim, 2 * a.dim, a.scale
 hd, wd = h * s, w * s
 inp = torch.randn(b, t, c, hd, wd, generator=g, device=dev)
 # smooth flows of a few pixels (grid units), like the composited TPS flows of the chain
-lo = 0.02 * torch.randn(b * tc * tp, 2, hd // 32, wd // 32, generator=g, device=dev)
+lo = a.amp * torch.randn(b * tc * tp, 2, hd // a.coarse, wd // a.coarse, generator=g, device=dev)
 flow = torch.nn.functional.interpolate(lo, size=(hd, wd), mode='bilinear').view(b, tc, tp, 2, hd, wd).contiguous()
 alpha = torch.rand(b, tc, tp, nl, hd, wd, generator=g, device=dev) * 2 - 1
 ctx_ts = torch.arange(tc, device=dev).view(1, tc, 1).expand(b, tc, tp).contiguous()
