@@ -299,6 +299,9 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 // of a pixel stay in registers and every input channel is sampled, written to `raw` and fused
 // into `out` in one pass.
 
+#ifndef WALDO_FWF_TILE_COLS
+#define WALDO_FWF_TILE_COLS 32  // workgroup tile = 8 rows x 32 columns (HdTile); measured below
+#endif
 #ifndef WALDO_FWF_NT
 #define WALDO_FWF_NT 1  // non-temporal stores for out / raw (read next by another kernel, far larger than any cache): -3.5 %
 #endif
@@ -310,6 +313,12 @@ __device__ __forceinline__ void fwf_store(float* p, float v) {
 #endif
 }
 
+// Tile shape (tools_dev/ab_hd.py --amp, C5 size, ms at flow amplitudes of 10 / 25 / 50 / 150 px over 32-pixel
+// cells): 4 x 64 (a wavefront = one 64-pixel row segment, as the other kernels of this file) 3.86 / 4.89 / 6.53
+// / 14.4; 8 x 32 (a wavefront = two rows of 32) 3.64 / 4.11 / 4.89 / 11.3; 16 x 16: 4.56 / 4.93 / 5.55 / 10.7.
+// Under a sheared flow the footprint of a long row segment crosses many image rows and every 8-byte pair
+// pulls a line of its own; the squarer wavefront keeps the footprint compact, and at 32 columns the stores
+// are still whole 128-byte lines.
 template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     int Tp, int C, int L, int Hd, int Wd, int include_self, float eps, int units, int tiles, int nbands) {
   const int64_t HWd = (int64_t)Hd * Wd;
   int n, x, y;  // n = (b, tp)
-  if (!hd_pixel(units, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
+  if (!HdTile<WALDO_FWF_TILE_COLS>::pixel(units, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
   const int b = n / Tp, tp = n % Tp;
   const int64_t p = (int64_t)y * Wd + x;
   float gx0, gy0;
@@ -553,7 +562,7 @@ extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, 
     return WALDO_EINVAL;
   }
   const int64_t units = (int64_t)B * Tp;
-  const HdGeom geom = hd_geom(units, Hd, Wd);
+  const HdGeom geom = HdTile<WALDO_FWF_TILE_COLS>::geom(units, Hd, Wd);
   if (hd_grid(units, geom) > 2147483647) {
     set_error("waldo_frame_warp_fuse_fwd: problem too large for one launch");
     return WALDO_EINVAL;

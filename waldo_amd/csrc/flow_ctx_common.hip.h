@@ -175,6 +175,30 @@ __device__ __forceinline__ bool hd_pixel(int units, int Hd, int Wd, int tiles, i
   return true;
 }
 
+// The same with a workgroup of (256 / TC) x TC pixels, a wavefront covering 64 / TC rows of TC columns
+// (frame_warp_fuse: WALDO_FWF_TILE_COLS).
+template <int TC>
+struct HdTile {
+  static constexpr int kCols = TC, kRows = kBlock / TC;
+  static_assert(TC == 16 || TC == 32 || TC == 64, "tile width");
+  static HdGeom geom(int64_t units, int Hd, int Wd) {
+    HdGeom g;
+    g.tiles = ((Hd + kRows - 1) / kRows) * ((Wd + kCols - 1) / kCols);
+    g.nbands = xcd_bands((int)(units % 8 == 0 ? 8 : units % 8));
+    return g;
+  }
+  __device__ static __forceinline__ bool pixel(int units, int Hd, int Wd, int tiles, int nbands, int& unit, int& x,
+                                               int& y) {
+    int tile, rest_;
+    if (!xcd_decode_banded(blockIdx.x, units, nbands, tiles, 1, unit, tile, rest_)) return false;
+    const int ntx = (Wd + kCols - 1) / kCols;
+    const int ty = tile / ntx;
+    x = (tile - ty * ntx) * kCols + (int)(threadIdx.x & (kCols - 1));
+    y = ty * kRows + (int)(threadIdx.x / kCols);
+    return true;
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // Low-resolution planes of a tile, staged in LDS.  A 4 x 64 tile of the x S raster reads an
 // (4 / S + 2) x (64 / S + 2) patch of every low-resolution plane it upsamples; taken tap by tap from
