@@ -83,8 +83,58 @@ __global__ __launch_bounds__(kBlock) void tps_grid_fwd_kernel(const float* __res
   }
 }
 
+// The same with the workgroup's kGridNB mappings staged in LDS ([k][map][xy]: the 16 floats of a k are four
+// broadcast ds_read_b128).  Read through the scalar cache -- mapping + ((b0 + i) * K3 + k) * 2 with K3 in a
+// register -- they were 2 K3 kGridNB scalar loads per wavefront with their address arithmetic: at the LVD
+// recipe's background (K3 = 131) 1578 scalar against 989 vector instructions per wave, 43 us for a 17 MB
+// stream.  Same fma chain per output: same bits.
+constexpr int kGridLdsMaxK = 768;  // 48 KB of LDS
+
+__global__ __launch_bounds__(kBlock) void tps_grid_fwd_lds_kernel(const float* __restrict__ basis_t,
+                                                                  const float* __restrict__ mapping,
+                                                                  float* __restrict__ grid, int64_t B,
+                                                                  int64_t HW, int K3) {
+  typedef float f32x4_g __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smap[];  // [K3][kGridNB][2]
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = p < HW;
+  const int64_t pc = live ? p : HW - 1;
+  const int64_t b0 = (int64_t)blockIdx.y * kGridNB;
+  const int nb = (int)min((int64_t)kGridNB, B - b0);
+  for (int e = threadIdx.x; e < K3 * kGridNB * 2; e += kBlock) {
+    const int k = e / (kGridNB * 2), r = e - k * (kGridNB * 2), i = r >> 1;
+    smap[e] = i < nb ? mapping[((b0 + i) * K3 + k) * 2 + (r & 1)] : 0.0f;
+  }
+  __syncthreads();
+  f32x4_g acc[kGridNB / 2];  // {x, y} of two maps each
+#pragma unroll
+  for (int i = 0; i < kGridNB / 2; ++i) acc[i] = (f32x4_g){0.0f, 0.0f, 0.0f, 0.0f};
+  const float* bp = basis_t + pc;
+#pragma unroll 8  // eight basis loads in flight
+  for (int k = 0; k < K3; ++k) {
+    const float bv = bp[(int64_t)k * HW];
+    const f32x4_g* m = reinterpret_cast<const f32x4_g*>(smap + k * (kGridNB * 2));
+#pragma unroll
+    for (int i = 0; i < kGridNB / 2; ++i) {
+      const f32x4_g mv = m[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = fmaf(bv, mv[c], acc[i][c]);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < kGridNB; ++i) {
+      if (i < nb) {
+        float2* o = reinterpret_cast<float2*>(grid + ((b0 + i) * HW + p) * 2);
+        *o = make_float2(acc[i >> 1][2 * (i & 1)], acc[i >> 1][2 * (i & 1) + 1]);
+      }
+    }
+  }
+}
+
 constexpr int kGradNB = 4;    // maps per workgroup
 constexpr int kGradPPT = 4;   // pixels per thread and chunk (summed in registers before the wave reduce)
+constexpr int kGradKB = 4;    // basis functions per wave reduction
 constexpr int kGradMaxK = 136;  // K3 values whose partial sums fit the workgroup's LDS table
 
 // grad_mapping[b][k][c] = sum_p basis_t[k][p] * grad_grid[b][p][c]: a skinny contraction over the
@@ -123,24 +173,32 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
         }
       }
     }
-#pragma unroll 4  // four k-steps' basis loads in flight (unconditional: past the raster the gradient is 0)
-    for (int k = 0; k < K3; ++k) {
-      float part[kGradNB * 2];
+    // kGradKB basis functions per wave reduction: one transpose-reduce of 32 partial sums instead of four of
+    // 8 (half the shuffles, a quarter of the dependent reduction chains: at K3 = 131 those chains, one per k,
+    // were what the kernel's 68 us were made of); their sixteen basis loads are in flight together
+    // (unconditional: past the raster the gradient is 0).  Each partial sum is the same fma chain as before.
+    for (int k0 = 0; k0 < K3; k0 += kGradKB) {
+      float part[kGradKB * kGradNB * 2];
 #pragma unroll
-      for (int i = 0; i < kGradNB * 2; ++i) part[i] = 0.0f;
+      for (int i = 0; i < kGradKB * kGradNB * 2; ++i) part[i] = 0.0f;
 #pragma unroll
-      for (int q = 0; q < kGradPPT; ++q) {
-        const int64_t p = pbase + q;
-        const float bv = basis_t[(int64_t)k * HW + (p < HW ? p : HW - 1)];
+      for (int kk = 0; kk < kGradKB; ++kk) {
+        const int k = min(k0 + kk, K3 - 1);  // (a repeated k past the end is computed and dropped)
 #pragma unroll
-        for (int i = 0; i < kGradNB; ++i) {
-          part[2 * i] = fmaf(bv, g[q][i][0], part[2 * i]);
-          part[2 * i + 1] = fmaf(bv, g[q][i][1], part[2 * i + 1]);
+        for (int q = 0; q < kGradPPT; ++q) {
+          const int64_t p = pbase + q;
+          const float bv = basis_t[(int64_t)k * HW + (p < HW ? p : HW - 1)];
+#pragma unroll
+          for (int i = 0; i < kGradNB; ++i) {
+            part[kk * kGradNB * 2 + 2 * i] = fmaf(bv, g[q][i][0], part[kk * kGradNB * 2 + 2 * i]);
+            part[kk * kGradNB * 2 + 2 * i + 1] = fmaf(bv, g[q][i][1], part[kk * kGradNB * 2 + 2 * i + 1]);
+          }
         }
       }
-      const float red = wave_transpose_reduce<kGradNB * 2>(part, lane);
-      const int idx = bitrev6(lane);
-      if (idx < nb * 2) {
+      const float red = wave_transpose_reduce<kGradKB * kGradNB * 2>(part, lane);
+      const int e = bitrev6(lane);
+      const int k = k0 + e / (kGradNB * 2), idx = e % (kGradNB * 2);
+      if (e < kGradKB * kGradNB * 2 && k < K3 && idx < nb * 2) {
         if (table)
           acc[wave][k * kGradNB * 2 + idx] += red;  // one lane per entry: plain read-modify-write
         else
@@ -214,8 +272,12 @@ extern "C" int waldo_tps_grid_fwd(const float* basis_t, const float* mapping, fl
     return WALDO_EINVAL;
   }
   dim3 g((unsigned)((HW + kBlock - 1) / kBlock), (unsigned)((B + kGridNB - 1) / kGridNB));
-  hipLaunchKernelGGL(tps_grid_fwd_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, basis_t,
-                     mapping, grid, B, HW, K3);
+  if (K3 <= kGridLdsMaxK)
+    hipLaunchKernelGGL(tps_grid_fwd_lds_kernel, g, dim3(kBlock), sizeof(float) * K3 * kGridNB * 2,
+                       (hipStream_t)stream, basis_t, mapping, grid, B, HW, K3);
+  else
+    hipLaunchKernelGGL(tps_grid_fwd_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, basis_t,
+                       mapping, grid, B, HW, K3);
   return launch_status("waldo_tps_grid_fwd");
 }
 
