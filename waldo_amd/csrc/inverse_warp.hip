@@ -248,66 +248,113 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   for (int i = 0; i < 9; ++i) k9[i] = kern[i];
 
   // ---- load: winners' (negated) displacement, fill state 0 / 255, kOut outside
+  // Eight cells per thread and trip, in three sweeps: all the winners, then all the displacements, then the
+  // LDS stores -- unconditional loads at clamped addresses, issued back to back (as one loop every cell was two
+  // dependent memory round trips behind the previous cell's stores).
   int any_filled = 0;
-  for (int c = threadIdx.x; c < cells; c += kBlock) {
-    const int i = c / RW, j = c - i * RW;
-    const int yp = oy + i, xp = ox + j;
-    float vx = 0.0f, vy = 0.0f;
-    unsigned char st = kOut;
-    if (i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp) {
-      st = 255;
+  constexpr int kLB = 8;
+  for (int c0 = threadIdx.x; c0 < cells; c0 += kBlock * kLB) {
+    int wv[kLB];
+    unsigned char stv[kLB];
+    bool img[kLB];
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      const int c = min(c0 + u * kBlock, cells - 1);
+      const int i = c / RW, j = c - i * RW;
+      const int yp = oy + i, xp = ox + j;
+      const bool inside = i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp;
       const int y = yp - pad, x = xp - pad;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const int w = winner[b * HW + y * W + x];
-        if (w != kNoWinner) {
-          vx = -dxy[(b * 2 + 0) * HW + w];
-          vy = -dxy[(b * 2 + 1) * HW + w];
-          st = 0;
-        }
+      img[u] = inside && y >= 0 && y < H && x >= 0 && x < W;
+      stv[u] = inside ? 255 : kOut;
+      wv[u] = winner[b * HW + (img[u] ? y * W + x : 0)];
+    }
+    float vxv[kLB], vyv[kLB];
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      const bool has = img[u] && wv[u] != kNoWinner;
+      const int w = has ? wv[u] : 0;
+      vxv[u] = dxy[(b * 2 + 0) * HW + w];
+      vyv[u] = dxy[(b * 2 + 1) * HW + w];
+      if (has) stv[u] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      const int c = c0 + u * kBlock;
+      if (c < cells) {
+        const bool has = stv[u] == 0;
+        fx[c] = has ? -vxv[u] : 0.0f;
+        fy[c] = has ? -vyv[u] : 0.0f;
+        fi[c] = stv[u];
+        any_filled |= has;
       }
     }
-    fx[c] = vx;
-    fy[c] = vy;
-    fi[c] = st;
-    any_filled |= st == 0;
   }
   // a region without a single winner stays empty through every pass (objects cover a few percent of
   // their canvas: most tiles): skip straight to the outputs
   const int n_pass = __syncthreads_or(any_filled) ? niter : 0;
-  // ---- Jacobi fill passes
+  // ---- Jacobi fill passes.  The cells a pass fills (unfilled, with a 4-neighbour filled earlier) are few and
+  // scattered -- a few hundred of the region's ~2900 -- so they are first COLLECTED into a list in LDS and the
+  // 3 x 3 sums then run over the list with every lane busy.  Walking all cells with a branch around the sum,
+  // a wave executed the sum's 27 LDS reads in every trip in which ANY of its lanes had such a cell: the LDS
+  // pipe carried ~10x the reads needed and a full-coverage tile (the background's) took 60 us (timing
+  // ablation: 96 of the kernel's 160 us were this loop).  Order inside a pass is free: a pass reads only cells
+  // filled before it and writes only cells it fills; states change after the barrier.
+  // (the two mask buffers, 2 * cells bytes, are not in use yet; fewer than cells - 1 cells can be on a ring)
+  unsigned short* ring_list = reinterpret_cast<unsigned short*>(m0 + ((size_t)(m0 - smem) & 1));
+  __shared__ int ring_count;
   for (int it = 1; it <= n_pass; ++it) {
+    if (threadIdx.x == 0) ring_count = 0;
     __syncthreads();
-    unsigned long long marks = 0;
-    int q = 0;
-    for (int c = threadIdx.x; c < cells; c += kBlock, ++q) {
-      if (fi[c] != 255) continue;
-      // 4-neighbour ring of the set filled before this pass
-      if (!(fi[c - RW] < it || fi[c + RW] < it || fi[c - 1] < it || fi[c + 1] < it)) continue;
+    for (int c0 = threadIdx.x; c0 < cells; c0 += kBlock * kLB) {
+      unsigned char s0[kLB], sn[kLB][4];
+#pragma unroll
+      for (int u = 0; u < kLB; ++u) s0[u] = fi[min(c0 + u * kBlock, cells - 1)];
+#pragma unroll
+      for (int u = 0; u < kLB; ++u) {
+        const int c = min(c0 + u * kBlock, cells - 1);
+        sn[u][0] = fi[max(c - RW, 0)];
+        sn[u][1] = fi[min(c + RW, cells - 1)];
+        sn[u][2] = fi[max(c - 1, 0)];
+        sn[u][3] = fi[min(c + 1, cells - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < kLB; ++u) {
+        // (an unfilled cell, state 255, is never on the region's one-cell border: its neighbours exist)
+        const bool on = c0 + u * kBlock < cells && s0[u] == 255 &&
+                        (sn[u][0] < it || sn[u][1] < it || sn[u][2] < it || sn[u][3] < it);
+        if (on) ring_list[atomicAdd(&ring_count, 1)] = (unsigned short)(c0 + u * kBlock);
+      }
+    }
+    __syncthreads();
+    const int nring = ring_count;
+    for (int e = threadIdx.x; e < nring; e += kBlock) {
+      const int c = ring_list[e];
+      unsigned char nf[9];
+      float nx[9], ny[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int n = c + (k / 3 - 1) * RW + (k % 3 - 1);
+        nf[k] = fi[n];
+        nx[k] = fx[n];
+        ny[k] = fy[n];
+      }
       float sx = 0.0f, sy = 0.0f, sm = 0.0f;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int n = c + dy * RW + dx;
-          if (fi[n] < it) {  // unfilled cells hold 0 and contribute nothing
-            const float k = k9[(dy + 1) * 3 + (dx + 1)];
-            sx = fmaf(k, fx[n], sx);
-            sy = fmaf(k, fy[n], sy);
-            sm += k;
-          }
-        }
+      for (int k = 0; k < 9; ++k) {
+        const bool on = nf[k] < it;  // unfilled cells hold 0 and contribute nothing
+        sx = on ? fmaf(k9[k], nx[k], sx) : sx;
+        sy = on ? fmaf(k9[k], ny[k], sy) : sy;
+        sm = on ? sm + k9[k] : sm;
+      }
       fx[c] = sx / sm;
       fy[c] = sy / sm;
-      marks |= 1ull << q;
       const int i = c / RW, j = c - i * RW;
       const int yp = oy + i, xp = ox + j;
       if (yp >= ty0 && yp < ty0 + kFusedTH && xp >= tx0 && xp < tx0 + kFusedTW)
         denom[b * HWp + yp * Wp + xp] = sm;  // this workgroup's own cells (inside the raster: state 255)
     }
     __syncthreads();
-    q = 0;
-    for (int c = threadIdx.x; c < cells; c += kBlock, ++q)
-      if (marks & (1ull << q)) fi[c] = (unsigned char)it;
+    for (int e = threadIdx.x; e < nring; e += kBlock) fi[ring_list[e]] = (unsigned char)it;
   }
   __syncthreads();
   // ---- mask (1 = filled), erosion passes; kOut counts as filled (it is not part of the raster)
@@ -432,27 +479,43 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fused_kernel(
 #pragma unroll
   for (int i = 0; i < 9; ++i) k9[i] = kern[i];
   // ---- load (= iw_bwd_init_kernel on the region): gradient of the masked image cells, fill states
+  // (eight cells per thread and trip, every load unconditional at a clamped address and issued before the
+  // first LDS store: see iw_fused_kernel)
   int any = 0;
-  for (int c = threadIdx.x; c < cells; c += kBlock) {
-    const int i = c / RW, j = c - i * RW;
-    const int yp = oy + i, xp = ox + j;
-    float vx = 0.0f, vy = 0.0f, d = 1.0f;
-    unsigned char st = 255;  // never a source (fi == it) nor a sink (fi < it) of any pass
-    if (i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp) {
-      const int e = yp * Wp + xp;
-      st = fill_iter[b * HWp + e];
+  constexpr int kLB = 8;
+  for (int c0 = threadIdx.x; c0 < cells; c0 += kBlock * kLB) {
+    unsigned char stv[kLB], mk[kLB];
+    float2 gv[kLB];
+    float dv[kLB];
+    bool inside[kLB], img[kLB];
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      const int c = min(c0 + u * kBlock, cells - 1);
+      const int i = c / RW, j = c - i * RW;
+      const int yp = oy + i, xp = ox + j;
+      inside[u] = i > 0 && i < RH - 1 && j > 0 && j < RW - 1 && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp;
+      const int e = inside[u] ? yp * Wp + xp : 0;
       const int y = yp - pad, x = xp - pad;
-      if (y >= 0 && y < H && x >= 0 && x < W && mask[b * HWp + e]) {
-        vx = gout[(b * HW + y * W + x) * 2 + 0] * 2.0f / (float)W;
-        vy = gout[(b * HW + y * W + x) * 2 + 1] * 2.0f / (float)H;
-      }
-      if (st >= 1 && st <= niter) d = denom[b * HWp + e];
+      img[u] = inside[u] && y >= 0 && y < H && x >= 0 && x < W;
+      stv[u] = fill_iter[b * HWp + e];
+      mk[u] = mask[b * HWp + e];
+      dv[u] = denom[b * HWp + e];
+      gv[u] = *reinterpret_cast<const float2*>(gout + (b * HW + (img[u] ? y * W + x : 0)) * 2);
     }
-    gx[c] = vx;
-    gy[c] = vy;
-    rd[c] = d;
-    fi[c] = st;
-    any |= (st >= 1 && st <= niter);
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      const int c = c0 + u * kBlock;
+      if (c < cells) {
+        // outside: state 255, never a source (fi == it) nor a sink (fi < it) of any pass
+        const unsigned char st = inside[u] ? stv[u] : (unsigned char)255;
+        const bool g = img[u] && mk[u];
+        gx[c] = g ? gv[u].x * 2.0f / (float)W : 0.0f;
+        gy[c] = g ? gv[u].y * 2.0f / (float)H : 0.0f;
+        rd[c] = (st >= 1 && st <= niter) ? dv[u] : 1.0f;
+        fi[c] = st;
+        any |= (st >= 1 && st <= niter);
+      }
+    }
   }
   // a region without a single filled cell: nothing moves
   const int n_pass = __syncthreads_or(any) ? niter : 0;
