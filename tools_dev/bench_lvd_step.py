@@ -23,8 +23,9 @@ if "--lib" in sys.argv:  # A/B runs: another build of the library (tools_dev/run
     _i = sys.argv.index("--lib")
     _lib.use_library(sys.argv[_i + 1])
     del sys.argv[_i:_i + 2]
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+b = int(_pos[0]) if len(_pos) > 0 else 2
+iters = int(_pos[1]) if len(_pos) > 1 else 10
 t, no, nl, lo, lb = 5, 16, 20, 16, 128
 opt = types.SimpleNamespace(latent_shape=[8, 16], obj_shape=[4, 4], time_dropout=0.0, num_obj=no, patch_size=16,
                             scale_factor=1, dim=128, aspect_ratio=2, load_dim=0, num_perm_grid=1,
@@ -62,14 +63,32 @@ def step():
     return loss
 
 
+graph = "--graph" in sys.argv
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+if graph:
+    # the whole step -- forward, loss, backward -- captured once and replayed (the library launches on the
+    # current stream and never synchronises; its host-side index checks are skipped during capture)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        loss = step()
+    run = g_.replay
+else:
+    run = step
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(iters):
-    loss = step()
+    out_ = run()
+    loss = out_ if out_ is not None else loss
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / iters * 1e3
-print(json.dumps({"config": f"LVD recipe step: B={b} T={t} L={no + 1} Nl={nl} 128x256, ctx prev + include_self",
+print(json.dumps({"config": f"LVD recipe step: B={b} T={t} L={no + 1} Nl={nl} 128x256, ctx prev + include_self" + (", one HIP graph" if graph else ""),
                   "ms_per_step": round(ms, 3), "loss": float(loss),
                   "grads_finite": all(bool(torch.isfinite(x.grad).all()) for x in leaves)}))
