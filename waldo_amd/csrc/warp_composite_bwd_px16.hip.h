@@ -346,8 +346,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           a[l] = 0.0f;
           G[l] = 0.0f;
           if constexpr (kPark) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) park[(4 * l + d) * PP1 + pix] = 0.0f;
+            reinterpret_cast<f32x4*>(park)[l * kBlock + pix] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
           } else {
             dxr[l] = dxa[l] = dyr[l] = dya[l] = 0.0f;
           }
@@ -425,10 +424,9 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         const float vxr = fmaf(g2, sx[2], fmaf(g1, sx[1], g0 * sx[0]));
         const float vyr = fmaf(g2, sy[2], fmaf(g1, sy[1], g0 * sy[0]));
         if constexpr (kPark) {
-          park[(4 * l + 0) * PP1 + pix] = vxr;
-          park[(4 * l + 1) * PP1 + pix] = sx[3];
-          park[(4 * l + 2) * PP1 + pix] = vyr;
-          park[(4 * l + 3) * PP1 + pix] = sy[3];
+          // one 16-byte texel per (layer, pixel): ONE ds_write_b128 here and one ds_read_b128 in phase (G)
+          // instead of four 4-byte accesses each way (8 of K1's 26 LDS instructions per pixel-layer)
+          reinterpret_cast<f32x4*>(park)[l * kBlock + pix] = (f32x4){vxr, sx[3], vyr, sy[3]};
         } else {
           dxr[l] = vxr;
           dxa[l] = sx[3];
@@ -532,10 +530,11 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
         const float gsa = (l >= 1 && !pad) ? 0.5f * ga[l] : 0.0f;
         float vxr, vxa, vyr, vya;
         if constexpr (kPark) {
-          vxr = park[(4 * l + 0) * PP1 + pix];
-          vxa = park[(4 * l + 1) * PP1 + pix];
-          vyr = park[(4 * l + 2) * PP1 + pix];
-          vya = park[(4 * l + 3) * PP1 + pix];
+          const f32x4 pk = reinterpret_cast<const f32x4*>(park)[l * kBlock + pix];
+          vxr = pk[0];
+          vxa = pk[1];
+          vyr = pk[2];
+          vya = pk[3];
         } else {
           vxr = dxr[l];
           vxa = dxa[l];
@@ -562,7 +561,9 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
         for (int l = 0; l < LP; ++l) wbound[wave * LP + l] = eb[l];
       }
-      // this thread's column of gg: with parking it overwrites the thread's own parked values
+      // this thread's column of gg.  With parking gg overlays the parked texels -- other threads' too (the
+      // texels are [layer][pixel], gg is [column][pixel]): every thread has to be done reading them first
+      if constexpr (kPark) lds_barrier();
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
         gg[(2 * l) * PP1 + pix] = ggx[l];
