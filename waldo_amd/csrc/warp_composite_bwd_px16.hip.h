@@ -55,12 +55,15 @@ struct Px16Cfg {
   // rows would leave ONE workgroup per CU, and at one wave per SIMD hipcc 7.2 allocates AGPRs as
   // extra registers and reads MFMA results back wrong through them (see warp_composite_fwd_lds.hip.h)
   static constexpr bool kPark = LP <= 8;
-  static constexpr int PP1 = kBlock + 1;         // pitch of the per-pixel columns (gg, park)
-  static constexpr int BP = 21;                  // pitch of the transposed basis [pixel][k]
-  static constexpr int kBtFloats = kWave * BP;   // one wave's slice of it
+  static constexpr int PP1 = kBlock + 1;         // pitch of the per-pixel columns (park rows; sizing only)
+  // Operands of phase (H) in LDS, per wave: [row][kk = pixel & 3][s = pixel >> 2] with a row pitch of 68
+  // floats -- the sixteen values a lane feeds to the sixteen MFMA steps are CONTIGUOUS (four ds_read_b128
+  // instead of sixteen ds_read_b32; 68 = 64 + 4: the 16 lanes of a read hit 64 different banks)
+  static constexpr int OP = 68;                  // row pitch of an operand table
+  static constexpr int kBtFloats = 20 * OP;      // one wave's basis table: rows k = 0 .. 19
   static constexpr int kImgFloats = 2 * kImgBufFloats;           // two buffers of float4 texels
   static constexpr int kTFloats = 4 * kWave * TP;                // transposition slices of the grid
-  static constexpr int kGgFloats = GGC * PP1;                    // grid gradients (MFMA B operand)
+  static constexpr int kGgFloats = 4 * GGC * OP;                 // grid gradients (MFMA B operand), one table per wave
   static constexpr int kAccFloats = 4 * 2 * NT * 256;            // per-wave MFMA accumulators
   static constexpr int kParkRows = 4 * LP > GGC ? 4 * LP : GGC;
   static constexpr int kPark0 = kParkRows * PP1 > kAccFloats ? kParkRows * PP1 : kAccFloats;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     int ncx, int ncells, float delta) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   using C = Px16Cfg<LP>;
-  constexpr int K3 = C::K3, KS = C::KS, NT = C::NT, GGC = C::GGC, TP = C::TP, PP1 = C::PP1, BP = C::BP;
+  constexpr int K3 = C::K3, KS = C::KS, NT = C::NT, GGC = C::GGC, TP = C::TP, OP = C::OP;
   constexpr bool kPark = C::kPark;
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
@@ -564,13 +567,15 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       // this thread's column of gg.  With parking gg overlays the parked texels -- other threads' too (the
       // texels are [layer][pixel], gg is [column][pixel]): every thread has to be done reading them first
       if constexpr (kPark) lds_barrier();
+      // (operand table of this wave, Px16Cfg::OP: column c of pixel `lane` at [c][lane & 3][lane >> 2])
+      float* ggw = gg + wave * GGC * OP + (lane & 3) * 16 + (lane >> 2);
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
-        gg[(2 * l) * PP1 + pix] = ggx[l];
-        gg[(2 * l + 1) * PP1 + pix] = ggy[l];
+        ggw[(2 * l) * OP] = ggx[l];
+        ggw[(2 * l + 1) * OP] = ggy[l];
       }
 #pragma unroll
-      for (int c = 2 * LP; c < GGC; ++c) gg[c * PP1 + pix] = 0.0f;
+      for (int c = 2 * LP; c < GGC; ++c) ggw[c * OP] = 0.0f;
     }
     __syncthreads();  // gg rows and the waves' bounds are complete
     WALDO_STAMP(13);
@@ -601,7 +606,8 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) Bw[(16 * g + arow) * BP + 4 * ks + kk] = av[g][ks];
+        for (int ks = 0; ks < KS; ++ks)  // basis[k = 4 ks + kk] of the wave's pixel 16 g + arow
+          Bw[(4 * ks + kk) * OP + (arow & 3) * 16 + 4 * g + (arow >> 2)] = av[g][ks];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       f32x4 macc[2][NT];
@@ -609,16 +615,32 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) macc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      // step s4 contracts the wave's pixels 4 s4 + kk: a lane's operands of all sixteen steps are 16
+      // contiguous floats of its table row (same pairs, same order as one 4-byte read per step: same bits)
+      f32x4 a0[4], a1[4], bq[NT][4];
+      {
+        const f32x4* r0 = reinterpret_cast<const f32x4*>(Bw + arow * OP + kk * 16);                  // k = arow
+        const f32x4* r1 = reinterpret_cast<const f32x4*>(Bw + (16 + min(arow, 3)) * OP + kk * 16);  // k = 16 + arow
 #pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        const int pl = 4 * s4 + kk;  // lane index of the contracted pixel inside this wave
-        const int px = wave * kWave + pl;
-        float ah[2];
-        ah[0] = Bw[pl * BP + arow];                                     // k = arow
-        ah[1] = (arow < 4) ? Bw[pl * BP + 16 + min(arow, 3)] : 0.0f;    // k = 16 + arow (19 is the zero pad)
+        for (int q = 0; q < 4; ++q) {
+          a0[q] = r0[q];
+          a1[q] = r1[q];
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const float bv = gg[(nt * 16 + arow) * PP1 + px];  // dead pixels carry gg == 0
+          const f32x4* rb = reinterpret_cast<const f32x4*>(gg + (wave * GGC + nt * 16 + arow) * OP + kk * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[nt][q] = rb[q];  // dead pixels carry gg == 0
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) {
+        float ah[2];
+        ah[0] = a0[s4 >> 2][s4 & 3];
+        ah[1] = (arow < 4) ? a1[s4 >> 2][s4 & 3] : 0.0f;  // (k = 19 is the zero pad)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv = bq[nt][s4 >> 2][s4 & 3];
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
             macc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bv, macc[mt][nt], 0, 0, 0);
