@@ -382,6 +382,15 @@ int waldo_time_gather_bwd(const float* grad_out, const int64_t* ctx_ts, const in
                           float* grad_x, int B, int T, int Tc, int Tp, int64_t P, int64_t HW,
                           int subtract, waldo_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * A7. scale(input[:, :Tw, c0:], 1 / S) (models/nets/lvd.py:611 / 716 through scale(), lvd.py:175-179):
+ * F.interpolate(bilinear, align_corners=False, scale_factor=1/S) of the channel slice, S a power of two >= 2
+ * (1 / S exact).   input (B,T,C,H*S,W*S)  ->  out (B,Tw,C-c0,H,W); the same bits as F.interpolate's device kernel
+ * (its CPU kernel associates the four terms differently: last-ulp differences).  The frames are data: no backward.
+ * ------------------------------------------------------------------------------------- */
+int waldo_downscale_frames_fwd(const float* input, float* out, int B, int T, int Tw, int C, int c0, int H,
+                               int W, int S, waldo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,6 +494,26 @@ def test_time_gather_against_the_spelled_out_expressions(dev, shape):
     assert tuple(empty.shape) == (0, tc, tp, h, w, 2)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 7, 16, 32, 2, 2, 3), (1, 2, 23, 32, 64, 4, 2, 3), (1, 1, 4, 8, 8, 8, 1, 0)])
+def test_downscale_frames_matches_interpolate(dev, shape):
+    """waldo_downscale_frames_fwd == scale(input[:, :Tw, c0:], 1 / S) (lvd.py:611 through lvd.py:175-179), bit for bit."""
+    from waldo_amd import functional as WF
+    from waldo_amd._lib import WaldoHipError
+    b, t, c, hd, wd, s, tw, c0 = shape
+    g = torch.Generator().manual_seed(c * 10 + s)
+    inp = torch.randn(b, t, c, hd, wd, generator=g)
+    ref = WO.rescale(inp[:, :tw, c0:], 1 / s)
+    out = WF.downscale_frames(inp.to(dev), tw, c0, s)
+    assert tuple(out.shape) == tuple(ref.shape) == (b, tw, c - c0, hd // s, wd // s)
+    close(out, ref, 1e-6, what="vs the oracle's F.interpolate")  # (the CPU kernel associates the four terms differently)
+    # the launches it replaces -- the framework's copy of the slice + its bilinear kernel on the device -- bit for bit
+    per_op = torch.nn.functional.interpolate(inp.to(dev)[:, :tw, c0:].reshape(-1, c - c0, hd, wd), scale_factor=1 / s,
+                                             mode="bilinear").view(out.shape)
+    assert torch.equal(out, per_op)
+    with pytest.raises(WaldoHipError):
+        WF.downscale_frames(inp.to(dev), tw, c0, 3)
+
+
 def test_time_indices_outside_the_window_are_refused(dev):
     """gather_time (lvd.py:462-467) raises for an index outside the time axis; the fused kernels index
     with ctx_ts / pred_ts directly, so the wrappers validate them instead of clamping silently."""

@@ -74,6 +74,34 @@ __global__ __launch_bounds__(kBlock) void time_gather_bwd_kernel(
   }
 }
 
+// A7: scale(input[:, :Tw, c0:], 1 / S) of Warper.grid_to_flow[_ctx] (lvd.py:611, 716 with scale() of lvd.py:175-179):
+// the low-resolution copy of the layout channels the class-distribution filter reads.  F.interpolate(bilinear,
+// align_corners=False) by 1 / S, S a power of two: the source position of a pixel is S dst + S / 2 - 1/2, i.e.
+// the mean of the 2 x 2 texels in the middle of its S x S block, 0.5 (0.5 a + 0.5 b) + 0.5 (0.5 c + 0.5 d) in
+// F.interpolate's association (halving is exact: the same bits whether or not its products are fused).  The
+// framework spelled it as a contiguous copy of the channel slice (the slice is strided) and the interpolation
+// over that copy: three passes over the 20 full-resolution layout planes of every frame; this reads the two
+// middle rows of every block once.
+__global__ __launch_bounds__(kBlock) void downscale_frames_kernel(const float* __restrict__ input,
+                                                                  float* __restrict__ out, int T, int Tw, int C,
+                                                                  int c0, int H, int W, int S, int64_t total) {
+  typedef float f32x2_d __attribute__((ext_vector_type(2)));
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W);
+  const int y = (int)((e / W) % H);
+  const int64_t pl = e / ((int64_t)W * H);  // (b, t, c) of the output
+  const int Cs = C - c0;
+  const int c = (int)(pl % Cs);
+  const int t = (int)((pl / Cs) % Tw);
+  const int64_t b = pl / ((int64_t)Cs * Tw);
+  const int64_t Wd = (int64_t)W * S, Hd = (int64_t)H * S;
+  const float* src = input + (((b * T + t) * C + c0 + c) * Hd + ((int64_t)y * S + S / 2 - 1)) * Wd + (int64_t)x * S + S / 2 - 1;
+  const f32x2_d r0 = *reinterpret_cast<const f32x2_d*>(src);
+  const f32x2_d r1 = *reinterpret_cast<const f32x2_d*>(src + Wd);
+  out[e] = 0.5f * (0.5f * r0[0] + 0.5f * r0[1]) + 0.5f * (0.5f * r1[0] + 0.5f * r1[1]);
+}
+
 static int check_time_gather(const char* fn, const void* x, const void* pred_ts, const void* out, int B, int T,
                              int Tc, int Tp, int64_t P, int64_t HW, int subtract, const void* ctx_ts) {
   if (B < 0 || T < 1 || Tc < 0 || Tp < 0 || P < 0 || HW < 0 || (HW > 0 && P % HW != 0) ||
@@ -140,4 +168,27 @@ extern "C" int waldo_time_gather_bwd(const float* grad_out, const int64_t* ctx_t
   time_gather_bwd_kernel<<<dim3((unsigned)(frames * bpf)), dim3(kBlock), 0, (hipStream_t)stream>>>(
       grad_out, ctx_ts, pred_ts, grad_x, T, Tc, Tp, P, HW, subtract, bpf);
   return launch_status("waldo_time_gather_bwd");
+}
+
+extern "C" int waldo_downscale_frames_fwd(const float* input, float* out, int B, int T, int Tw, int C, int c0, int H,
+                                          int W, int S, waldo_stream_t stream) {
+  if (B < 0 || T < 1 || Tw < 0 || Tw > T || C < 1 || c0 < 0 || c0 >= C || H < 1 || W < 1 || S < 2 || (S & (S - 1)) ||
+      (int64_t)H * S > 32767 || (int64_t)W * S > 32767) {
+    set_error("waldo_downscale_frames_fwd: bad shape B=%d T=%d Tw=%d C=%d c0=%d H=%d W=%d S=%d (S: a power of two >= 2)",
+              B, T, Tw, C, c0, H, W, S);
+    return WALDO_EINVAL;
+  }
+  const int64_t total = (int64_t)B * Tw * (C - c0) * H * W;
+  if (total == 0) return WALDO_OK;
+  if (!input || !out) {
+    set_error("waldo_downscale_frames_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  if ((total + kBlock - 1) / kBlock > 2147483647) {
+    set_error("waldo_downscale_frames_fwd: problem too large for one launch");
+    return WALDO_EINVAL;
+  }
+  downscale_frames_kernel<<<dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+      input, out, T, Tw, C, c0, H, W, S, total);
+  return launch_status("waldo_downscale_frames_fwd");
 }

@@ -784,6 +784,24 @@ def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=
     return out.view(b, tc, tp, *x.shape[2:])
 
 
+def downscale_frames(input, num_frames, first_channel, factor):
+    """``scale(input[:, :num_frames, first_channel:], 1 / factor)`` of ``Warper.grid_to_flow[_ctx]``
+    (models/nets/lvd.py:611 / 716): the low-resolution copy of the layout channels, the same bits as
+    ``F.interpolate(..., scale_factor=1 / factor, mode="bilinear")`` on the device for a power-of-two ``factor``.
+    The frames are data: the result carries no gradient."""
+    _lib.check_cuda(input)
+    b, t, c, hd, wd = input.shape
+    s = int(factor)
+    if s < 2 or s & (s - 1) or hd % s or wd % s:
+        raise _lib.WaldoHipError(f"downscale_frames: factor {factor} on {hd} x {wd} frames (a power of two that divides both)")
+    x = _c(input.detach().float())
+    out = x.new_empty(b, int(num_frames), c - int(first_channel), hd // s, wd // s)
+    with torch.cuda.device(x.device):
+        _lib.call("waldo_downscale_frames_fwd", _lib.ptr(x), _lib.ptr(out), b, t, int(num_frames), c,
+                  int(first_channel), hd // s, wd // s, s, _lib.current_stream(x.device))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # fused hot path
 # --------------------------------------------------------------------------------------

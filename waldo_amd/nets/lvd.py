@@ -299,7 +299,10 @@ class Warper(nn.Module):
         alpha = alpha[:, :tw]                                                   # B Tw L 1 H W
         dist = None
         if ctx_only or not self.no_filter:
-            lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
+            if s >= 2 and s & (s - 1) == 0 and input.is_cuda and hd % s == 0 and wd % s == 0:
+                lyt = WF.downscale_frames(input, tw, 3, s)  # the same bits in one pass (waldo_downscale_frames_fwd)
+            else:
+                lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
             dist = self._lyt_dist(alpha, lyt, cls)
         occ = occ.reshape(b, t, nl, nl)
         a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ, tw, 3, s)
