@@ -124,8 +124,8 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
                                        bg_pose.view(b, nt, 1, lb, 2), occ_score, obj_alpha_mask=mask)
 
     def disocc(alpha_ctx):  # synthesizer.py:447-450
-        mx = alpha_ctx.max(dim=3)[0]
-        dmax, dmin = mx.max(dim=1)[0], mx.min(dim=1)[0]
+        mx = alpha_ctx.amax(dim=3)  # (values only: max(dim)[0] also computes the arg max, twice the time on 5 GB)
+        dmax, dmin = mx.amax(dim=1), mx.amin(dim=1)
         dmax = dmax.clone()
         dmax[dmax - dmin > 1] = 0
         return dmax.unsqueeze(2)
