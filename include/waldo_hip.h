@@ -110,10 +110,15 @@ int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3, const i
  *   input (Nin,C,Hi,Wi), grid (N,Ho,Wo,2), output (N,C,Ho,Wo).
  *   Input batch broadcast (the reference's .expand over T, lvd.py:544,555):
  *       n_in = (n / outer_div) * inner + (n % inner);  pass outer_div = inner = N for identity.
+ *   Forward only: the same map for the GRID, n_grid = (n / grid_outer_div) * grid_inner + n % grid_inner,
+ *       grid (N_grid,Ho,Wo,2) -- the predicted frames' grids repeated over the Tc contexts
+ *       (`[:, pred_ts].unsqueeze(1).expand(-1, Tc, ...)`, lvd.py:665-668) without the Tc copies;
+ *       grid_outer_div = grid_inner = N for one grid per output.
  * ------------------------------------------------------------------------------------- */
 int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output, int64_t N,
                             int C, int Hi, int Wi, int Ho, int Wo, float delta,
-                            int64_t outer_div, int64_t inner, waldo_stream_t stream);
+                            int64_t outer_div, int64_t inner, int64_t grid_outer_div,
+                            int64_t grid_inner, waldo_stream_t stream);
 /* grad_input (Nin,C,Hi,Wi) must be ZERO-FILLED by the caller (accumulated with atomics; may be
  * NULL to skip); grad_grid (N,Ho,Wo,2) is overwritten (may be NULL to skip). */
 int waldo_grid_sample2d_bwd(const float* input, const float* grid, const float* grad_output,

@@ -63,7 +63,7 @@ def test_argument_validation_needs_no_gpu(lib_path):
     rc = lib.waldo_warp_composite_fwd(None, None, None, None, None, None, 1, 99, 8, 8, 19, 0.0, None)
     assert rc == -1
     assert b"unsupported shape" in lib.waldo_last_error_string()
-    rc = lib.waldo_grid_sample2d_fwd(None, None, None, 1, 0, 4, 4, 4, 4, 0.0, 1, 1, None)
+    rc = lib.waldo_grid_sample2d_fwd(None, None, None, 1, 0, 4, 4, 4, 4, 0.0, 1, 1, 1, 1, None)
     assert rc == -1
 
 

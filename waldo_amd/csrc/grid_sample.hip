@@ -15,11 +15,11 @@ __device__ __forceinline__ int64_t in_index(int64_t n, int64_t outer_div, int64_
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta, int64_t outer_div,
-    int64_t inner) {
+    int64_t inner, int64_t g_outer_div, int64_t g_inner) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   if (p >= HWo) return;
-  const float2 g = *reinterpret_cast<const float2*>(grid + (n * HWo + p) * 2);
+  const float2 g = *reinterpret_cast<const float2*>(grid + (in_index(n, g_outer_div, g_inner) * HWo + p) * 2);
   const Taps t = make_taps(g.x, g.y, Hi, Wi);
   const int64_t HWi = (int64_t)Hi * Wi;
   const float* in = input + in_index(n, outer_div, inner) * C * HWi;
@@ -82,11 +82,11 @@ typedef float f32x4_gs __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta, int64_t outer_div,
-    int64_t inner) {
+    int64_t inner, int64_t g_outer_div, int64_t g_inner) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = ((int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x) * 4;
   if (p >= HWo) return;
-  const f32x4_gs* gp = reinterpret_cast<const f32x4_gs*>(grid + (n * HWo + p) * 2);
+  const f32x4_gs* gp = reinterpret_cast<const f32x4_gs*>(grid + (in_index(n, g_outer_div, g_inner) * HWo + p) * 2);
   const f32x4_gs g0 = gp[0], g1 = gp[1];
   Taps t[4];
   t[0] = make_taps(g0[0], g0[1], Hi, Wi);
@@ -132,9 +132,13 @@ using namespace waldo;
 extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output,
                                        int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
                                        float delta, int64_t outer_div, int64_t inner,
-                                       waldo_stream_t stream) {
+                                       int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
   int rc = check_gs("waldo_grid_sample2d_fwd", N, C, Hi, Wi, Ho, Wo, outer_div, inner);
   if (rc) return rc;
+  if (grid_outer_div < 1 || grid_inner < 1) {
+    set_error("waldo_grid_sample2d_fwd: bad grid broadcast (%lld, %lld)", (long long)grid_outer_div, (long long)grid_inner);
+    return WALDO_EINVAL;
+  }
   if (N == 0) return WALDO_OK;
   if (!input || !grid || !output) {
     set_error("waldo_grid_sample2d_fwd: null pointer");
@@ -144,13 +148,14 @@ extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, fl
   if (HWo % 4 == 0) {
     const int tiles4 = (int)((HWo / 4 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(grid_sample2d_fwd4_kernel, dim3((unsigned)(N * tiles4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner);
+                       (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner, grid_outer_div,
+                       grid_inner);
     return launch_status("waldo_grid_sample2d_fwd");
   }
   const int tiles = (int)((HWo + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(grid_sample2d_fwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
                      (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles, delta,
-                     outer_div, inner);
+                     outer_div, inner, grid_outer_div, grid_inner);
   return launch_status("waldo_grid_sample2d_fwd");
 }
 

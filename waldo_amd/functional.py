@@ -218,7 +218,7 @@ class _GridSample(torch.autograd.Function):
         out = inp.new_empty(n, c, ho, wo)
         with torch.cuda.device(inp.device):
             _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
-                      c, hi, wi, ho, wo, float(delta), outer_div, inner,
+                      c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
                       _lib.current_stream(inp.device))
         ctx.save_for_backward(inp, grid)
         ctx.cfg = (float(delta), outer_div, inner)
@@ -240,13 +240,34 @@ class _GridSample(torch.autograd.Function):
         return gi, gg, None, None, None
 
 
-def grid_sample(inp, grid, delta=0.0, broadcast=None):
+def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None):
     """``F.grid_sample(inp + delta, grid) - delta`` with the PyTorch defaults (bilinear, zeros,
     align_corners=False).  inp (Nin, C, Hi, Wi), grid (N, Ho, Wo, 2) -> (N, C, Ho, Wo).
 
     broadcast=(outer_div, inner): input map used by output n is
     ``(n // outer_div) * inner + n % inner`` -- the reference's ``.expand`` over time
-    (models/nets/lvd.py:544,555) without materialising the copies."""
+    (models/nets/lvd.py:544,555) without materialising the copies.
+
+    grid_repeat=(n_out, outer_div, inner): the same map for the GRID -- ``grid`` holds (Ng, Ho, Wo, 2) maps and
+    output n of ``n_out`` reads map ``(n // outer_div) * inner + n % inner``: the predicted frames' grids
+    repeated over the contexts (lvd.py:665-668) without the copies.  Inference only (no gradient)."""
+    if grid_repeat is not None:
+        n_out, god, gin = (int(v) for v in grid_repeat)
+        if torch.is_grad_enabled() and (inp.requires_grad or grid.requires_grad):
+            raise _lib.WaldoHipError("grid_sample: grid_repeat is forward only; expand the grid for a gradient")
+        _lib.check_cuda(inp, grid)
+        inp, grid = _c(inp.detach()), _c(grid.detach())
+        nin, c, hi, wi = inp.shape
+        ng, ho, wo, _ = grid.shape
+        od, inn = broadcast if broadcast is not None else (max(n_out, 1), max(n_out, 1))
+        if god < 1 or gin < 1 or (n_out > 0 and ((n_out - 1) // god) * gin + min(gin, n_out) > ng) or \
+                (broadcast is None and nin != n_out):
+            raise _lib.WaldoHipError(f"grid_sample: grid_repeat {grid_repeat} against {ng} grids / {nin} inputs")
+        out = inp.new_empty(n_out, c, ho, wo)
+        with torch.cuda.device(inp.device):
+            _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n_out, c, hi, wi,
+                      ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
+        return out
     od, inn = broadcast if broadcast is not None else (None, None)
     return _GridSample.apply(inp, grid, delta, od, inn)
 

@@ -74,6 +74,16 @@ def scale(tensor, scale_factor, mode="bilinear"):
     return out.reshape(*lead, *out.shape[-3:])
 
 
+class TimeRepeat:
+    """A clip of grids (B, Tp, ...) standing for its copies over Tc contexts, (B * Tc, Tp, ...) -- what
+    ``x[:, pred_ts].unsqueeze(1).expand(-1, Tc, ...).reshape(B * Tc, Tp, ...)`` (lvd.py:665-668) materialises.
+    ``obj_to_output`` / ``bg_to_output`` read it through the grid map of ``waldo_grid_sample2d_fwd`` instead
+    (forward only: with a gradient in play ``Warper._layer_flows`` hands out the expanded tensors)."""
+
+    def __init__(self, grid, repeat):
+        self.grid, self.repeat = grid, int(repeat)
+
+
 def gather_time(tensor, ts):
     """Reference ``gather_time`` (lvd.py:462-467): tensor (B, T, ...), ts (B, Tc, Tp)."""
     b, tc, tp = ts.shape
@@ -153,10 +163,16 @@ class Warper(nn.Module):
 
     def obj_to_output(self, obj, grid, delta_obj=1):
         src_grid_obj = grid[1]
-        b, t, no = src_grid_obj.shape[:3]
         c1 = obj.size(-3)
         ho, wo = self.tgt_shape
         h, w = self.src_shape
+        if isinstance(src_grid_obj, TimeRepeat):  # grids (B, Tp, No, ...) for outputs (B * Tc, Tp, No, ...)
+            rep, sg = src_grid_obj.repeat, src_grid_obj.grid
+            b0, t, no = sg.shape[:3]
+            out = WF.grid_sample(obj.reshape(b0 * rep * t * no, c1, ho, wo), sg.reshape(b0 * t * no, h, w, 2),
+                                 delta=delta_obj, grid_repeat=(b0 * rep * t * no, rep * t * no, t * no))
+            return out.view(b0 * rep, t, no, c1, h, w)
+        b, t, no = src_grid_obj.shape[:3]
         g = src_grid_obj.reshape(b * t * no, h, w, 2)
         if obj.ndim == 5:  # (B, No, C+1, Ho, Wo) shared over time (lvd.py:544): n_in = b*No + o
             out = WF.grid_sample(obj.reshape(b * no, c1, ho, wo), g, delta=delta_obj, broadcast=(t * no, no))
@@ -166,9 +182,15 @@ class Warper(nn.Module):
 
     def bg_to_output(self, bg, grid, delta_bg=1, eps=1e-6):
         src_grid_bg = grid[3]
-        b, t = src_grid_bg.shape[:2]
         c1 = bg.size(-3)
         h, w = self.src_shape
+        if isinstance(src_grid_bg, TimeRepeat):
+            rep, sg = src_grid_bg.repeat, src_grid_bg.grid
+            b0, t = sg.shape[:2]
+            out = WF.grid_sample(bg.reshape(b0 * rep * t, c1, h, w), sg.reshape(b0 * t, h, w, 2), delta=delta_bg,
+                                 grid_repeat=(b0 * rep * t, rep * t, t))
+            return out.view(b0 * rep, t, 1, c1, h, w)
+        b, t = src_grid_bg.shape[:2]
         g = src_grid_bg.reshape(b * t, h, w, 2)
         if bg.ndim == 4:  # (B, C+1, H, W) shared over time (lvd.py:555): n_in = b
             out = WF.grid_sample(bg.reshape(b, c1, h, w), g, delta=delta_bg, broadcast=(t, 1))
@@ -278,10 +300,14 @@ class Warper(nn.Module):
         ho, wo = self.tgt_shape
         obj_flow = WF.time_gather(tgt_grid_obj, ctx_ts, pred_ts, subtract=True, channel_first=True)
         bg_flow = WF.time_gather(tgt_grid_bg.unsqueeze(2), ctx_ts, pred_ts, subtract=True, channel_first=True)
-        sgo = WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=tc)
-        sgb = WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=tc)
-        return (obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w),
-                sgo.reshape(b * tc, tp, no, h, w, 2), sgb.reshape(b * tc, tp, h, w, 2))
+        if torch.is_grad_enabled() and (src_grid_obj.requires_grad or src_grid_bg.requires_grad or
+                                        tgt_grid_obj.requires_grad or tgt_grid_bg.requires_grad):
+            sgo = WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=tc).reshape(b * tc, tp, no, h, w, 2)
+            sgb = WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=tc).reshape(b * tc, tp, h, w, 2)
+        else:  # inference: the Tc copies are never made (TimeRepeat)
+            sgo = TimeRepeat(WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=1).reshape(b, tp, no, h, w, 2), tc)
+            sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1).reshape(b, tp, h, w, 2), tc)
+        return obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w), sgo, sgb
 
     def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
         """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
