@@ -204,10 +204,13 @@ int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const fl
                              const float* occ, float* a01, float* alpha_out, int B, int T, int Tw,
                              int L, int Nl, int C, int chan_off, int H, int W, int scale,
                              waldo_stream_t stream);
+/* alpha_max (M,Hd,Wd), optional (NULL to skip): max over the layers of alpha_ctx -- what
+ * Synthesizer.predict's disocclusion test takes from it (models/synthesizer.py:447, `alpha_ctx.max(dim=3)[0]`:
+ * a pass over the largest tensor but one of the pipeline, here a by-product of writing it). */
 int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                             const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                            float* flow, float* alpha_ctx, float* disocc, int B, int T, int Tw,
-                            int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
+                            float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B, int T,
+                            int Tw, int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A10: Warper.input_to_output (models/nets/lvd.py:830-853): warp of the context frames

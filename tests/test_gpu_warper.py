@@ -292,8 +292,16 @@ def test_flow_ctx_fused_passes(dev, over, ctx_only):
         fn_h = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
         assert wp.fuse_hd and wp._fused_ok(list(args[:1]), cfg.num_obj + 1, nl)
         rf = fn_h(*args)
+        assert wp.alpha_ctx_max is None
+        # the by-product Synthesizer.predict's disocclusion test asks for: max over the layers of alpha_ctx
+        wp.keep_alpha_ctx_max = True
+        rf2 = fn_h(*args)
+        assert all(torch.equal(x, y) for x, y in zip(rf, rf2) if x is not None)
+        assert torch.equal(wp.alpha_ctx_max, rf[3].amax(dim=3))
+        close(wp.alpha_ctx_max, ro[3].amax(dim=3), what="alpha_ctx_max vs oracle")
         wp.fuse_hd = False
         ru = fn_h(*args)
+        assert wp.alpha_ctx_max is None
     for x, y, z, name in zip(rf, ro, ru, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
         close(x, y, what="fused vs oracle:" + name)
         close(x, z, what="fused vs unfused:" + name)

@@ -71,7 +71,7 @@ def fwf(lib):
 
 def fcw(lib):
     assert lib.waldo_flow_ctx_warp_fwd(ptr(flow_lr), None, ptr(a01), ptr(ctx_ts), ptr(pred_ts), ptr(occ), ptr(oflow),
-                                       ptr(oactx), ptr(odis), b, t, tc, tc, tp, nl, h, w, s, st) == 0
+                                       ptr(oactx), ptr(odis), None, b, t, tc, tc, tp, nl, h, w, s, st) == 0
 
 
 def timeit(fn, n):

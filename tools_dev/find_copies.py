@@ -1,43 +1,36 @@
-"""dev: which host lines of the C5 / C4 pipeline make a COPY (contiguous() / reshape() of a non-contiguous tensor)?"""
+"""dev: which host lines of the C5 / C4 pipeline launch the framework's copy / fill / reduce kernels?
+(torch profiler, grouped by the innermost waldo_amd source line on the stack)"""
 import collections
 import sys
-import traceback
 
 import torch
+from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, '.')
 from waldo_amd.tools import pipeline  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C5"
-pipe = pipeline.Pipeline(name, 2, torch.device("cuda:0"))
-pipe()
-hits = collections.Counter()
-orig_c, orig_r = torch.Tensor.contiguous, torch.Tensor.reshape
-
-
-def where():
-    for fr in reversed(traceback.extract_stack()[:-2]):
-        if "waldo_amd" in fr.filename:
-            return f"{fr.filename.split('waldo_amd/')[-1]}:{fr.lineno} {fr.line}"
-    return "?"
-
-
-def contiguous(self, *a, **k):
-    if not self.is_contiguous():
-        hits[("contiguous", where())] += self.numel() * 4
-    return orig_c(self, *a, **k)
-
-
-def reshape(self, *shape):
-    out = orig_r(self, *shape)
-    if out.data_ptr() != self.data_ptr() or (not self.is_contiguous() and out._base is None and out.numel() > 0 and out is not self):
-        if not self.is_contiguous() and out._base is None:
-            hits[("reshape", where())] += self.numel() * 4
-    return out
-
-
-torch.Tensor.contiguous, torch.Tensor.reshape = contiguous, reshape
+pipe = pipeline.Pipeline(name, 4 if name == "C5" else 8, torch.device("cuda:0"))
 with torch.no_grad():
     pipe()
-for (kind, w), nbytes in hits.most_common(25):
-    print(f"{nbytes / 1e6:10.1f} MB  {kind:10s} {w}")
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+        pipe()
+        torch.cuda.synchronize()
+agg = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_time_total <= 0 or not ev.name.startswith("aten::"):
+        continue
+    if ev.name not in ("aten::copy_", "aten::fill_", "aten::amax", "aten::amin", "aten::cat", "aten::clone",
+                       "aten::add", "aten::add_", "aten::masked_fill_", "aten::index_put_", "aten::gt", "aten::sub"):
+        continue
+    where = "?"
+    for fr in ev.stack:
+        if "waldo_amd" in fr:
+            where = fr.split("waldo_amd/")[-1]
+            break
+    k = (ev.name, where)
+    agg[k][0] += 1
+    agg[k][1] += ev.device_time_total / 1e3
+for (n, w), (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print(f"{ms:8.3f} ms  x{c:<3d} {n:18s} {w}")

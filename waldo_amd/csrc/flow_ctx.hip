@@ -122,8 +122,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
-    float* __restrict__ alpha_ctx, float* __restrict__ disocc, int T, int Tw, int Tc, int Tp, int L,
-    int H, int W, int scale, int units, int tiles, int nbands) {
+    float* __restrict__ alpha_ctx, float* __restrict__ disocc, float* __restrict__ alpha_max, int T, int Tw,
+    int Tc, int Tp, int L, int H, int W, int scale, int units, int tiles, int nbands) {
   using G = FcwLds<LP>;
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   else layers(std::false_type{});
   disocc[(int64_t)m * HWd + p] = dis;
   float ox = 0.0f, oy = 0.0f;
+  float amax = -INFINITY;  // max over the layers of the composited alpha (Synthesizer.predict's disocclusion test)
   float* ac = alpha_ctx + (int64_t)m * L * HWd;
   // four columns j of the order per step, two and two on the packed-fp32 pipe (the product of every column
   // runs over i in the same order as in the other kernels of the path)
@@ -277,8 +278,10 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
       oy += v * fy[j + k];
 #ifndef WALDO_ABL_FCW_NOSTORE
       if (j + k < L) {
-        ac[p] = v * 2.0f - 1.0f;
+        const float av = v * 2.0f - 1.0f;
+        ac[p] = av;
         ac += HWd;
+        amax = fmaxf(amax, av);
       }
 #endif
     }
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   }
   flow[((int64_t)m * 2) * HWd + p] = ox;
   flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
+  if (alpha_max != nullptr) alpha_max[(int64_t)m * HWd + p] = amax;
 }
 
 // A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward: warp of the context frames by
@@ -518,8 +522,8 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 
 extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                        const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                                       float* flow, float* alpha_ctx, float* disocc, int B, int T,
-                                       int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B,
+                                       int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
                                        waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tc * Tp;
   int rc = check_flow_ctx("waldo_flow_ctx_warp_fwd", N, L, H, W, scale);
@@ -536,12 +540,12 @@ extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_
   hipStream_t st = (hipStream_t)stream;
   const HdGeom geom = hd_geom(N, H * scale, W * scale);
   switch (flow_ctx_pad_l(L)) {
-    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
   }
   return launch_status("waldo_flow_ctx_warp_fwd");
 }

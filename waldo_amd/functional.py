@@ -608,7 +608,7 @@ def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale):
 
 class _FlowCtxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
+    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max):
         m, nl, _, h, w = flow_lr.shape
         b, tc, tp = ctx_ts.shape
         t = occ.shape[1]
@@ -616,16 +616,19 @@ class _FlowCtxWarp(torch.autograd.Function):
         flow = flow_lr.new_empty(m, 2, hd, wd)
         alpha_ctx = flow_lr.new_empty(m, nl, hd, wd)
         disocc = flow_lr.new_empty(m, hd, wd)
+        amax = flow_lr.new_empty(m, hd, wd) if layer_max else flow_lr.new_empty(0)
         with torch.cuda.device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
-                      _lib.ptr(disocc), b, t, tw, tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
+                      _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, b, t, tw, tc, tp, nl, h, w, scale,
+                      _lib.current_stream(flow_lr.device))
         ctx.save_for_backward(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ)
         ctx.cfg = (tw, scale)
-        return flow, alpha_ctx, disocc
+        ctx.mark_non_differentiable(amax)
+        return flow, alpha_ctx, disocc, amax
 
     @staticmethod
-    def backward(ctx, g_flow, g_actx, g_dis):
+    def backward(ctx, g_flow, g_actx, g_dis, _g_amax):
         flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = ctx.saved_tensors
         tw, scale = ctx.cfg
         m, nl, _, h, w = flow_lr.shape
@@ -644,16 +647,18 @@ class _FlowCtxWarp(torch.autograd.Function):
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(g_flow), _lib.ptr(g_actx),
                       _lib.ptr(g_dis), _lib.ptr(g_lr), _lib.ptr(g_a01), _lib.ptr(g_occ), _lib.ptr(ws), b, t, tw,
                       tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
-        return g_lr, None, g_a01, None, None, g_occ, None, None
+        return g_lr, None, g_a01, None, None, g_occ, None, None, None
 
 
-def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
+def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False):
     """Context-alpha warp + ghost mask + disocclusion + second occlusion product + flow compositing
     (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
     a01 (B*Tw, L, Hd, Wd) from flow_ctx_alpha; ctx_ts (B, Tc, Tp) long; pred_ts (Tp) long;
     occ (B, T, L, L).  Returns flow (M, 2, Hd, Wd), alpha_ctx (M, L, Hd, Wd) in [-1, 1],
     disocc (M, Hd, Wd).  Differentiable w.r.t. flow_lr, a01 and occ (the thresholded ghost mask
-    carries no gradient, as in the reference)."""
+    carries no gradient, as in the reference).  ``layer_max``: a fourth result, ``alpha_ctx.amax(dim=1)``
+    (M, Hd, Wd) -- what Synthesizer.predict's disocclusion test computes from alpha_ctx (synthesizer.py:447) --
+    as a by-product (no gradient)."""
     _lib.check_cuda(flow_lr, a01, occ)
     if not (ctx_ts.is_cuda and pred_ts.is_cuda):
         raise _lib.WaldoHipError("flow_ctx_warp: ctx_ts / pred_ts must be on the GPU")
@@ -674,7 +679,9 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
         isobj_lr = _c(isobj_lr.detach())
         if tuple(isobj_lr.shape) != (m, nl - 1, h, w):
             raise _lib.WaldoHipError(f"flow_ctx_warp: isobj_lr {tuple(isobj_lr.shape)} is not (M, L-1, H, W)")
-    return _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale)
+    flow, alpha_ctx, disocc, amax = _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale,
+                                                       bool(layer_max))
+    return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
 
 
 MAX_FUSE_CTX = 8

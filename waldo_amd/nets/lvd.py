@@ -128,6 +128,9 @@ class Warper(nn.Module):
         self.invert_bg = InverseWarp(*self.src_shape, *self.src_shape, num_perm=opt.num_perm_grid)
         self.no_filter = opt.no_filter
         self.allow_ghost = opt.allow_ghost
+        # ask the fused flow pass for max_l alpha_ctx as a by-product (read it from .alpha_ctx_max after the call)
+        self.keep_alpha_ctx_max = False
+        self.alpha_ctx_max = None
         self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused
 
     # ------------------------------------------------------------------ image -> layer space
@@ -340,8 +343,11 @@ class Warper(nn.Module):
             ones = torch.ones(b * tc, tp, no, 1, ho, wo, device=input.device, dtype=input.dtype)
             is_obj = self.obj_to_output(ones, gridp, delta_obj=0).reshape(b * tc * tp, no, h, w)
         flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
-        flow, alpha_ctx, disocc = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01,
-                                                   ctx_ts, pred_ts, occ, tw, s)
+        res = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts, occ, tw, s,
+                               layer_max=self.keep_alpha_ctx_max)
+        flow, alpha_ctx, disocc = res[:3]
+        # by-product for Synthesizer.predict's disocclusion test (synthesizer.py:447: alpha_ctx.max(dim=3)[0])
+        self.alpha_ctx_max = res[3].view(b, tc, tp, hd, wd) if self.keep_alpha_ctx_max else None
         alpha_out = alpha_out.view(b, tw, nl, hd, wd)
         return (flow.view(b, tc, tp, 2, hd, wd), (alpha_out if self.fast else None), alpha_out,
                 alpha_ctx.view(b, tc, tp, nl, hd, wd), disocc.view(b, tc, tp, 1, hd, wd))
@@ -350,6 +356,7 @@ class Warper(nn.Module):
         if self.fuse_hd and self._fused_ok([input, occ, obj_alpha, bg_alpha, cls, *grid],
                                            grid[1].shape[2] + 1, input.size(2) - 3):
             return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only)
+        self.alpha_ctx_max = None  # (only the fused pass produces it)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
         tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)

@@ -123,8 +123,12 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
         return estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(b, nt, no, lo, 2),
                                        bg_pose.view(b, nt, 1, lb, 2), occ_score, obj_alpha_mask=mask)
 
+    warper.keep_alpha_ctx_max = True  # max_l alpha_ctx comes out of the fused flow pass as a by-product
+
     def disocc(alpha_ctx):  # synthesizer.py:447-450
-        mx = alpha_ctx.amax(dim=3)  # (values only: max(dim)[0] also computes the arg max, twice the time on 5 GB)
+        mx = warper.alpha_ctx_max  # == alpha_ctx.max(dim=3)[0], without the pass over alpha_ctx
+        if mx is None:
+            mx = alpha_ctx.amax(dim=3)
         dmax, dmin = mx.amax(dim=1), mx.amin(dim=1)
         dmax = dmax.clone()
         dmax[dmax - dmin > 1] = 0
