@@ -75,7 +75,7 @@ class Pipeline:
             m = b * tc * tp
             add = {
                 "waldo_flow_ctx_alpha_fwd": 4 * (b * tc * nl * hw + b * tc * ncls * hwd + 2 * b * tc * nl * hwd),
-                "waldo_flow_ctx_warp_fwd": 4 * (m * nl * 2 * hw + m * nl * hwd + m * (2 + nl + 1) * hwd),
+                "waldo_flow_ctx_warp_fwd": 4 * (m * nl * 2 * hw + m * nl * hwd + m * (2 + nl + 1 + 1) * hwd),  # + alpha_max
                 "waldo_frame_warp_fuse_fwd": 4 * (m * (c + 2 + nl) * hwd + b * tp * (c + 1) * hwd + m * (c + nl) * hwd),
                 # the fusion reads channels 0-2 and 4 of the raw frames and the UNet's four outputs (wif.py:49-54)
                 "waldo_wif_fuse_fwd": 4 * (m * 4 * hwd + m * 4 * hwd + b * tp * 3 * hwd),
