@@ -170,6 +170,22 @@ CONFIGS = {
 }
 
 
+def spawn_ranks(n):
+    """One process per GPU, as the reference's launch scripts do (scripts/cityscapes/demo.sh:6-12: torchrun around
+    the helper; tools/engine.py:28-35 reads the rank from the environment): the same command line under
+    ``python -m torch.distributed.run`` on 127.0.0.1 with a free port.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / tensor sharing between the ranks
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +209,10 @@ def main():
                     help="C4 / C5 only: the whole chain of Synthesizer.predict around the path (producers -> "
                          "Warper.forward -> decode_output -> WIF fusion) on whole clips, instead of the synthetic "
                          "fused forward (waldo_amd/tools/pipeline.py)")
+    ap.add_argument("--motion", choices=["calibrated", "wild"], default="calibrated",
+                    help="--pipeline: background motion of the stand-in pose heads (waldo_amd/tools/demo.py:BG_MOTION); "
+                         "'wild' is the folded warp rounds 1-3 benchmarked on, 'calibrated' keeps the local stretch of "
+                         "the warp within what optical flow of the reference's demo clips shows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -206,6 +226,11 @@ def main():
     mode = args.mode or c_mode
     custom = (clips, fpc, nl, h, w, mode) != CONFIGS[args.config] or args.sigma != 0.05
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves.  Nothing has touched
+        # the GPU yet (importing torch does not), so a CHILD process is safe; this process only waits, forwards the
+        # child's output and exits with its code (never exec: the pool forbids replacing a process image).
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -408,7 +433,7 @@ def run_pipeline(args, clips, world, rank, device, dist):
     from waldo_amd import _lib
     from waldo_amd.dist import all_gather_frames
     from waldo_amd.tools.pipeline import Pipeline
-    pipe = Pipeline(args.config, clips, device, seed=rank)
+    pipe = Pipeline(args.config, clips, device, seed=rank, motion=args.motion)
     t, hd, wd = pipe.frames, pipe.vid.shape[-2], pipe.vid.shape[-1]
 
     def step():
@@ -446,7 +471,7 @@ def run_pipeline(args, clips, world, rank, device, dist):
                 row["frac"] = round(row["GBps"] / HBM_PEAK_GBS, 4)
             table[name] = row
         in_lib = sum(r["ms_per_step"] for r in table.values())
-        dom = max(alg, key=lambda k: table[k]["ms_per_step"])
+        dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
         o = pipe.opt
         out = {
             "metric": f"WIF inference frames/sec at {hd}x{wd}, {o.num_obj + 1} layers, {t}-frame clips; full "
@@ -459,7 +484,7 @@ def run_pipeline(args, clips, world, rank, device, dist):
                                    f"{o.num_obj} objects + background, {o.num_lyt} layout classes; "
                                    f"Synthesizer.predict's call order: reconstruction of all {t} frames and prediction "
                                    f"of the last {t - pipe.ctx_len}; networks outside the path replaced by seeded "
-                                   f"stand-ins (UNet stand-in costs nothing)",
+                                   f"stand-ins (UNet stand-in costs nothing), background motion '{pipe.motion}'",
                        "frames_per_gpu": clips * t, "layers": o.num_obj + 1, "height": hd, "width": wd,
                        "parallelism": f"clips sharded x{world}, one all-gather of the inpainted predicted frames"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,

@@ -43,7 +43,11 @@ int waldo_max_layers(void);
 #define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
 #define WALDO_DEBUG_BWD_GENERIC 2 /* fused backward: the generic per-tap-atomics kernel for every shape
                                      (waldo_warp_composite_bwd_workspace_bytes answers 0) */
-#define WALDO_DEBUG_COUNT 3
+#define WALDO_DEBUG_FWD_ROLLING 3 /* fused forward, short launches: the rolling-window staged kernel instead of
+                                     the all-layers-staged one (same bits; tests compare the two) */
+#define WALDO_DEBUG_FWF_GATHER 4  /* Warper.input_to_output: per-tap gathers for every tile instead of staged
+                                     footprint boxes (same bits) */
+#define WALDO_DEBUG_COUNT 5
 int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------
@@ -211,6 +215,19 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
                             const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
                             float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B, int T,
                             int Tw, int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
+/* The same pass for a caller that runs waldo_frame_warp_fuse_raw_fwd next (LVD.forward(mode="decode_output"),
+ * lvd.py:141-153, without autograd): the composited context alphas are written straight into the slots they
+ * occupy in A10's `raw` tensor, raw[b, tp, tc, C + l] (lvd.py:846: `raw_output = cat(output, alpha)`), instead of
+ * into a tensor of their own that the frame warp would read and copy there (L planes read + L written per
+ * (b, tc, tp) and full-resolution pixel: 29 % of that kernel's traffic at the Cityscapes recipe), and
+ *   score (M,Hd,Wd) = sum_l (alpha_ctx_l + 1) / 2   (lvd.py:841), summed in layer order from the stored values,
+ * comes out beside them.  raw (B,Tp,Tc',C+L,Hd,Wd) as A10 lays it out, Tc' = Tc or Tc + 1; only the alpha slots
+ * of contexts 0 .. Tc-1 are written.  The reference's alpha_ctx (B,Tc,Tp,L,Hd,Wd) is a strided view of raw. */
+int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                                const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
+                                float* raw, float* score, float* disocc, float* alpha_max, int B, int T, int Tw,
+                                int Tc, int Tp, int L, int H, int W, int scale, int C, int Tcx,
+                                waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A10: Warper.input_to_output (models/nets/lvd.py:830-853): warp of the context frames
@@ -228,6 +245,14 @@ int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float
                               const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
                               int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
                               waldo_stream_t stream);
+/* A10 behind waldo_flow_ctx_warp_raw_fwd: the alpha slots of `raw` are filled already and `score` (B,Tc,Tp,Hd,Wd)
+ * holds their per-context sums; this call reads one score plane per context instead of L alpha planes, writes the C
+ * warped channels of every context (and, with include_self, the whole self slot) and `out`.  Same values, bit
+ * for bit, as waldo_frame_warp_fuse_fwd on the contiguous alpha tensor. */
+int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const float* score,
+                                  const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc, int Tp,
+                                  int C, int L, int Hd, int Wd, int include_self, float eps,
+                                  waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Backward of A9 / A10 (csrc/flow_ctx_bwd.hip): the reference's live backward path in LVD training

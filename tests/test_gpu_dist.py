@@ -107,3 +107,26 @@ def test_rccl_all_gather_runs_on_one_gpu(dev):
     assert equal, "frames changed on their way through the collective"
     assert rccl_mapped, "librccl is not mapped: the collective did not go through RCCL"
     assert hip_mapped
+
+
+@pytest.mark.parametrize("extra", [["--config", "C3", "--clips", "1"], ["--config", "C4", "--pipeline", "--clips", "1"]])
+def test_bench_starts_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with NO launcher around it (as the driver calls `--gpus 1`): bench.py starts
+    `python -m torch.distributed.run` itself as a child before anything touches the GPU, the two ranks share this
+    box's one GPU (gloo rendezvous on 127.0.0.1, as the test above), and ONE JSON line with n_gpus = 2 comes back.
+    Run from a fresh child process; this process's GPU state is not inherited."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    per_rank = out["config"]["frames_per_gpu"]
+    assert abs(out["value"] - 2 * per_rank / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]  # whole-job aggregate

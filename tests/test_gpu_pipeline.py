@@ -23,5 +23,5 @@ def test_c4_pipeline_one_clip(dev):
     for k in ("inp_pred_vid", "inp_rec_vid", "pred_flow"):
         assert torch.equal(out[k], again[k]), k
     alg = pipe.hd_algorithmic_bytes()
-    assert set(alg) == {"waldo_flow_ctx_alpha_fwd", "waldo_flow_ctx_warp_fwd", "waldo_frame_warp_fuse_fwd",
-                        "waldo_wif_fuse_fwd"} and all(v > 0 for v in alg.values())
+    assert {"waldo_flow_ctx_alpha_fwd", "waldo_flow_ctx_warp_raw_fwd", "waldo_frame_warp_fuse_raw_fwd",
+            "waldo_wif_fuse_fwd"} <= set(alg) and all(v > 0 for v in alg.values())

@@ -463,6 +463,92 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
+@pytest.mark.parametrize("amp_px", [10.0, 50.0])
+def test_frame_warp_fuse_at_256x512(dev, amp_px):
+    """input_to_output at a 256 x 512 raster with smooth flows of 10 and 50 px amplitude (the regimes the C4 / C5
+    pipelines operate in; the small-raster test above cannot leave a tile's neighbourhood): forward against the
+    oracle in fp32 and fp64, backward (flow and alpha gradients) against the oracle's autograd."""
+    from waldo_amd import functional as WF
+    b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 2, 5, 3, 256, 512
+    opt = opt_ns(num_obj=nl - 1, dim=hd, aspect_ratio=2.0, load_dim=hd)
+    cfg = WO.WarperCfg.from_opt(opt)
+    g = torch.Generator().manual_seed(int(amp_px))
+    lo = torch.randn(b * t, c, hd // 4, wd // 4, generator=g)
+    inp = torch.nn.functional.interpolate(lo, size=(hd, wd), mode="bilinear").view(b, t, c, hd, wd)
+    # grid units: amp_px pixels of the 512-wide raster, smooth over 32-pixel cells, plus a shear across the frame
+    fl = (amp_px * 2 / wd) * torch.randn(b * tc * tp, 2, hd // 32, wd // 32, generator=g)
+    flow = torch.nn.functional.interpolate(fl, size=(hd, wd), mode="bilinear").view(b, tc, tp, 2, hd, wd)
+    flow = flow + (amp_px * 2 / wd) * torch.linspace(-1, 1, hd).view(1, 1, 1, 1, hd, 1)
+    alpha = torch.rand(b, tc, tp, nl, hd, wd, generator=g) * 2 - 1
+    ctx_ts = torch.randint(0, t, (b, tc, tp), generator=g)
+    w_out = torch.randn(b, tp, c + 1, hd, wd, generator=g)
+    w_raw = torch.randn(b, tc, tp, c + nl, hd, wd, generator=g)
+
+    def ref(dtype):
+        f, a = flow.clone().to(dtype).requires_grad_(), alpha.clone().to(dtype).requires_grad_()
+        out, raw = WO.input_to_output(cfg, inp.to(dtype), a, f, ctx_ts)
+        ((out * w_out.to(dtype)).sum() + (raw * w_raw.to(dtype)).sum()).backward()
+        return out.detach(), raw.detach(), f.grad, a.grad
+
+    r32, r64 = ref(torch.float32), ref(torch.float64)
+    f, a = flow.to(dev).requires_grad_(), alpha.to(dev).requires_grad_()
+    out, raw = WF.frame_warp_fuse(inp.to(dev), f, a, ctx_ts.to(dev))
+    close(out, r32[0], what=f"{amp_px} px: out", exact=r64[0])
+    close(raw, r32[1], what=f"{amp_px} px: raw", exact=r64[1])
+    ((out * w_out.to(dev)).sum() + (raw * w_raw.to(dev)).sum()).backward()
+    close(f.grad, r32[2], rel=True, what=f"{amp_px} px: grad_flow", exact=r64[2])
+    close(a.grad, r32[3], rel=True, what=f"{amp_px} px: grad_alpha", exact=r64[3])
+
+
+@pytest.mark.parametrize("include_self", [False, True])
+@pytest.mark.parametrize("shape", [(2, 3, 2, 2, 7, 5, 4, 16, 32, 2, True), (1, 4, 4, 3, 23, 12, 8, 32, 4, 4, False),
+                                   (1, 2, 5, 1, 4, 3, 8, 16, 1, 1, True)])
+def test_alpha_ctx_written_into_raw_slots(dev, include_self, shape):
+    """waldo_flow_ctx_warp_raw_fwd + waldo_frame_warp_fuse_raw_fwd (the context alphas composited straight into
+    raw_output's slots, one score plane per context) == waldo_flow_ctx_warp_fwd + waldo_frame_warp_fuse_fwd,
+    bit for bit, for every output; a write to the alpha view between the two calls falls back to the long way."""
+    from waldo_amd import functional as WF
+    b, t, tc, tp, c, nl, h, w, s, tw, ghost = shape
+    if include_self:
+        tp = t
+    hd, wd = h * s, w * s
+    g = torch.Generator(device=dev).manual_seed(nl * 10 + tc)
+    m = b * tc * tp
+    flow_lr = 0.1 * torch.randn(m, nl, 2, h, w, generator=g, device=dev)
+    isobj = torch.rand(m, nl - 1, h, w, generator=g, device=dev) * 1.2 if ghost else None
+    a01 = torch.rand(b * tw, nl, hd, wd, generator=g, device=dev)
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    ctx_ts = torch.randint(0, tw, (b, tc, tp), generator=g, device=dev)
+    pred_ts = torch.randint(0, t, (tp,), generator=g, device=dev)
+    inp = torch.randn(b, t, c, hd, wd, generator=g, device=dev)
+    with torch.no_grad():
+        flow, actx, dis, amax = WF.flow_ctx_warp(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True)
+        out, raw = WF.frame_warp_fuse(inp, flow.view(b, tc, tp, 2, hd, wd), actx.view(b, tc, tp, nl, hd, wd), ctx_ts,
+                                      include_self=include_self)
+        flow2, actx2, dis2, amax2 = WF.flow_ctx_warp_into_raw(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, c,
+                                                              include_self, layer_max=True)
+        assert tuple(actx2.shape) == (b, tc, tp, nl, hd, wd) and not actx2.is_contiguous()
+        slots = actx2._waldo_raw
+        out2, raw2 = WF.frame_warp_fuse(inp, flow2.view(b, tc, tp, 2, hd, wd), actx2, ctx_ts, include_self=include_self)
+        assert raw2.data_ptr() == slots.raw.data_ptr()  # the short way: raw is the tensor the alphas went into
+        for x, y, name in ((flow, flow2, "flow"), (actx.view(b, tc, tp, nl, hd, wd), actx2, "alpha_ctx"), (dis, dis2, "disocc"),
+                           (amax, amax2, "alpha max"), (out, out2, "out"), (raw, raw2, "raw")):
+            assert torch.equal(x, y), name
+        # the score plane is what frame_warp_fuse would have summed
+        sc = ((actx.view(b, tc, tp, nl, hd, wd)[:, :, :, 0] + 1) / 2)
+        for l in range(1, nl):
+            sc = sc + (actx.view(b, tc, tp, nl, hd, wd)[:, :, :, l] + 1) / 2
+        assert torch.equal(slots.score, sc)
+        # a caller that edits the view in place gets the long way (and the edited values)
+        actx2[:, 0, 0, 0] = 0.25
+        out3, raw3 = WF.frame_warp_fuse(inp, flow2.view(b, tc, tp, 2, hd, wd), actx2, ctx_ts, include_self=include_self)
+        assert raw3.data_ptr() != slots.raw.data_ptr()
+        ref = actx.view(b, tc, tp, nl, hd, wd).clone()
+        ref[:, 0, 0, 0] = 0.25
+        out4, raw4 = WF.frame_warp_fuse(inp, flow.view(b, tc, tp, 2, hd, wd), ref, ctx_ts, include_self=include_self)
+        assert torch.equal(out3, out4) and torch.equal(raw3, raw4)
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 3, 4, 3, 6, 5, 7), (1, 3, 1, 1, 1, 2, 2, 3), (2, 4, 5, 2, 2, 8, 16, 8)])
 def test_time_gather_against_the_spelled_out_expressions(dev, shape):
     """waldo_time_gather_* against gather_time / [:, pred_ts] / subtract / permute / expand as the reference
@@ -544,6 +630,45 @@ def test_time_indices_outside_the_window_are_refused(dev):
         WF.flow_ctx_warp(flow_lr, None, a01, ok, pred, occ, 2, 1)
     with pytest.raises(_lib.WaldoHipError, match="valid range"):
         WF.flow_ctx_warp(flow_lr, None, a01, torch.tensor([[[0], [1]]], device=dev), torch.tensor([3], device=dev), occ, 2, 1)
+
+
+def test_index_validation_under_inference_mode(dev):
+    """Tensors made under torch.inference_mode() have no version counter (reading ``_version`` raises): the
+    index validation must work there -- every call re-reads a caller's inference tensor, Warper's own
+    normalised copy is read once -- and still refuse bad indices.  The whole decode runs under it."""
+    from waldo_amd import _lib, functional as WF
+    from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
+    b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 1, 4, 3, 8, 16
+    with torch.inference_mode():
+        inp = torch.randn(b, t, c, hd, wd, device=dev)
+        flow = torch.zeros(b, tc, tp, 2, hd, wd, device=dev)
+        alpha = torch.zeros(b, tc, tp, nl, hd, wd, device=dev)
+        ok = torch.arange(tc, device=dev).view(1, tc, 1)  # an inference tensor
+        assert ok.is_inference()
+        WF.frame_warp_fuse(inp, flow, alpha, ok)
+        ok.fill_(t)  # written in place, unseen by any version counter: the next call must notice
+        with pytest.raises(_lib.WaldoHipError, match="valid range"):
+            WF.frame_warp_fuse(inp, flow, alpha, ok)
+        priv = WF.normalise_time_index(torch.arange(tc, device=dev).view(1, tc, 1).expand(b, tc, tp))
+        assert priv.is_contiguous() and priv.dtype == torch.int64
+        WF.frame_warp_fuse(inp, flow, alpha, priv)
+    # the chain of test_decode_output_glue under inference mode == under no_grad, bit for bit
+    opt = opt_ns()
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    bb, tt, nll = 2, 3, 5
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, bb, tt, nll, seed=8)
+    occ_score = torch.randn(bb, tt, cfg.num_obj, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for mode in (torch.no_grad, torch.inference_mode):
+        with mode():
+            ctx_ts = torch.arange(2, device=dev).view(1, 2, 1).expand(bb, 2, tt)  # expanded view, as synthesizer.py:438
+            pred_ts = torch.arange(tt, device=dev)
+            occ_d, oa, ba, grid = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev), obj_pose.to(dev),
+                                                          bg_pose.to(dev), occ_score.to(dev))
+            outs.append(decode_output(wp, inp.to(dev), grid, occ_d, oa, ba, cls.to(dev), ctx_ts, pred_ts))
+    for x, y in zip(*outs):
+        assert (x is None and y is None) or torch.equal(x, y)
 
 
 @pytest.mark.parametrize("restrict,use_disocc,include_self", [(True, False, False), (True, True, False),

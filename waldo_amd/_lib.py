@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1008
+ABI_VERSION = 1009
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -47,6 +47,8 @@ SIGNATURES = {
     "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_fwd": [_c_f] * 10 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
+    "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 11 + [_int] * 11 + [_stream],
+    "waldo_frame_warp_fuse_raw_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
     "waldo_flow_ctx_alpha_bwd": [_c_f] * 9 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_bwd": [_c_f] * 8 + [_int] * 9 + [_flt, _stream],
@@ -76,6 +78,8 @@ PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
 DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
 DEBUG_BWD_GENERIC = 2
+DEBUG_FWD_ROLLING = 3
+DEBUG_FWF_GATHER = 4
 
 _lock = threading.Lock()
 _lib = None

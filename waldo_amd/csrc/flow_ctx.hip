@@ -117,13 +117,29 @@ struct FcwLds {
   static constexpr int kCap = LP <= 12 ? 7168 : 8192;  // floats: 136 cells (x 2 upsampling) up to L = 12
 };
 
-template <int LP>
+// where the L planes of alpha_ctx[b, tc, tp] go: element strides of the three unit indices from `alpha_ctx` (the
+// planes of one unit are always Hd * Wd apart).  Contiguous (M, L, Hd, Wd): (Tc Tp L, Tp L, L) Hd Wd; inside the
+// `raw` tensor of Warper.input_to_output, (B, Tp, Tc', C + L, Hd, Wd), behind the C frame channels of every
+// context: base raw + C Hd Wd, strides (Tp Tc' (C + L), C + L, Tc' (C + L)) Hd Wd.
+struct ActxLayout {
+  int64_t sb, stc, stp;
+};
+
+// torch.max / amax return NaN when any element is NaN (lvd.py:803 `alpha_ctx.max(dim=3)[0]`, synthesizer.py:447);
+// v_max_f32 returns the other operand.  llvm.maximum = IEEE 754-2019 maximum: v_maximum3_f32 on gfx950, two
+// layers per instruction.
+__device__ __forceinline__ float nan_max(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+
+// SCORE: also write score[m] = sum_l (alpha_ctx_l + 1) / 2, summed as frame_warp_fuse sums it from the stored
+// values (lvd.py:841) -- the frame warp then reads ONE plane per context instead of L.
+template <int LP, bool SCORE>
 __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
-    float* __restrict__ alpha_ctx, float* __restrict__ disocc, float* __restrict__ alpha_max, int T, int Tw,
-    int Tc, int Tp, int L, int H, int W, int scale, int units, int tiles, int nbands) {
+    float* __restrict__ alpha_ctx, ActxLayout lay, float* __restrict__ score, float* __restrict__ disocc,
+    float* __restrict__ alpha_max, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, int units,
+    int tiles, int nbands) {
   using G = FcwLds<LP>;
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
         // compiler sinks this arithmetic to the first use of a[] after the loop -- keeping the taps and loaded
         // pairs of EVERY layer alive to the end (216 registers at L = 12)
         asm volatile("" : "+v"(v));
-        dis = fmaxf(dis, v);  // (a padding layer repeats a real one: the maximum does not notice)
+        dis = nan_max(dis, v);  // (a padding layer repeats a real one: the maximum does not notice)
         a[l] = l < L ? v : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);  // one chunk's loads at a time
@@ -250,7 +266,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   disocc[(int64_t)m * HWd + p] = dis;
   float ox = 0.0f, oy = 0.0f;
   float amax = -INFINITY;  // max over the layers of the composited alpha (Synthesizer.predict's disocclusion test)
-  float* ac = alpha_ctx + (int64_t)m * L * HWd;
+  float* ac = alpha_ctx + b * lay.sb + ((m / Tp) % Tc) * lay.stc + tp * lay.stp;
+  float ssum = 0.0f;
   // four columns j of the order per step, two and two on the packed-fp32 pipe (the product of every column
   // runs over i in the same order as in the other kernels of the path)
 #pragma unroll
@@ -281,7 +298,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
         const float av = v * 2.0f - 1.0f;
         ac[p] = av;
         ac += HWd;
-        amax = fmaxf(amax, av);
+        amax = nan_max(amax, av);
+        if (SCORE) ssum += (av + 1.0f) / 2.0f;
       }
 #endif
     }
@@ -290,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   flow[((int64_t)m * 2) * HWd + p] = ox;
   flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
   if (alpha_max != nullptr) alpha_max[(int64_t)m * HWd + p] = amax;
+  if (SCORE) score[(int64_t)m * HWd + p] = ssum;
 }
 
 // A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward: warp of the context frames by
@@ -326,8 +345,9 @@ __device__ __forceinline__ void fwf_store(float* p, float v) {
 template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
-    const int64_t* __restrict__ ctx_ts, float* __restrict__ out, float* __restrict__ raw, int T, int Tc,
-    int Tp, int C, int L, int Hd, int Wd, int include_self, float eps, int units, int tiles, int nbands) {
+    const float* __restrict__ score, const int64_t* __restrict__ ctx_ts, float* __restrict__ out,
+    float* __restrict__ raw, int T, int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+    int units, int tiles, int nbands) {
   const int64_t HWd = (int64_t)Hd * Wd;
   int n, x, y;  // n = (b, tp)
   if (!HdTile<WALDO_FWF_TILE_COLS>::pixel(units, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
@@ -372,13 +392,19 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     w11[tc] = t.w11;
     const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)));  // wave-uniform
     frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
-    const float* al = alpha + m * L * HWd + p;
-    float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + tcc) * (C + L) + C) * HWd + p;
     float s = 0.0f;
-    for (int l = 0; l < L; ++l) {
-      const float av = al[(int64_t)l * HWd];
-      s += (av + 1.0f) / 2.0f;
-      if (real) fwf_store(rw + (int64_t)l * HWd, av);
+    if (score != nullptr) {
+      // the alphas already sit in `raw` (waldo_flow_ctx_warp_raw_fwd wrote them there) and their sum came with
+      // them: one plane per context instead of L read and L copied
+      s = score[m * HWd + p];
+    } else {
+      const float* al = alpha + m * L * HWd + p;
+      float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + tcc) * (C + L) + C) * HWd + p;
+      for (int l = 0; l < L; ++l) {
+        const float av = al[(int64_t)l * HWd];
+        s += (av + 1.0f) / 2.0f;
+        if (real) fwf_store(rw + (int64_t)l * HWd, av);
+      }
     }
     sc[tc] = s;
     ssum += real ? fabsf(s + eps) : 0.0f;
@@ -466,9 +492,10 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
 }
 
 static int check_flow_ctx(const char* fn, int64_t N, int L, int H, int W, int scale) {
-  if (N < 0 || L < 1 || L > 32 || H < 1 || W < 1 || scale < 1 || scale > 64 ||
+  // (W * scale >= 2: the gathers read the two taps of a row as one 8-byte pair inside the row, pair_taps())
+  if (N < 0 || L < 1 || L > 32 || H < 1 || W < 1 || scale < 1 || scale > 64 || (int64_t)W * scale < 2 ||
       (int64_t)H * scale > 32767 || (int64_t)W * scale > 32767) {
-    set_error("%s: bad shape N=%lld L=%d H=%d W=%d scale=%d (need 1<=L<=32, integer scale, HD side < 32768)",
+    set_error("%s: bad shape N=%lld L=%d H=%d W=%d scale=%d (need 1<=L<=32, integer scale, 2 <= HD width, HD side < 32768)",
               fn, (long long)N, L, H, W, scale);
     return WALDO_EINVAL;
   }
@@ -520,68 +547,132 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   return launch_status("waldo_flow_ctx_alpha_fwd");
 }
 
-extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
-                                       const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B,
-                                       int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
-                                       waldo_stream_t stream) {
+#define WALDO_FCW_CASE(LPV)                                                                                   \
+  case LPV:                                                                                                  \
+    if (score != nullptr)                                                                                    \
+      hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, true>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,  \
+                         flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc,  \
+                         alpha_max, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands);         \
+    else                                                                                                     \
+      hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, false>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st, \
+                         flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc,  \
+                         alpha_max, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands);         \
+    break;
+
+static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const float* isobj_lr, const float* a01,
+                                const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
+                                float* alpha_ctx, ActxLayout lay, float* score, float* disocc, float* alpha_max,
+                                int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tc * Tp;
-  int rc = check_flow_ctx("waldo_flow_ctx_warp_fwd", N, L, H, W, scale);
+  int rc = check_flow_ctx(fn, N, L, H, W, scale);
   if (rc) return rc;
   if (B < 0 || T < 1 || Tw < 1 || Tw > T || Tc < 0 || Tp < 0) {
-    set_error("waldo_flow_ctx_warp_fwd: bad frame counts T=%d Tw=%d Tc=%d Tp=%d", T, Tw, Tc, Tp);
+    set_error("%s: bad frame counts T=%d Tw=%d Tc=%d Tp=%d", fn, T, Tw, Tc, Tp);
     return WALDO_EINVAL;
   }
   if (N == 0) return WALDO_OK;
   if (!flow_lr || !a01 || !ctx_ts || !pred_ts || !occ || !flow || !alpha_ctx || !disocc) {
-    set_error("waldo_flow_ctx_warp_fwd: null pointer");
+    set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
   const HdGeom geom = hd_geom(N, H * scale, W * scale);
   switch (flow_ctx_pad_l(L)) {
-    WALDO_FC_CASE(4, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(8, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(12, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(17, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(24, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
-    WALDO_FC_CASE(32, flow_ctx_warp_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, disocc, alpha_max, T, Tw, Tc, Tp, L, H, W, scale)
+    WALDO_FCW_CASE(4)
+    WALDO_FCW_CASE(8)
+    WALDO_FCW_CASE(12)
+    WALDO_FCW_CASE(17)
+    WALDO_FCW_CASE(24)
+    WALDO_FCW_CASE(32)
   }
-  return launch_status("waldo_flow_ctx_warp_fwd");
+  return launch_status(fn);
+}
+
+extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                                       const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
+                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B,
+                                       int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                       waldo_stream_t stream) {
+  const int64_t plane = (int64_t)H * scale * W * scale;
+  const ActxLayout lay = {(int64_t)Tc * Tp * L * plane, (int64_t)Tp * L * plane, (int64_t)L * plane};
+  return flow_ctx_warp_launch("waldo_flow_ctx_warp_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
+                              alpha_ctx, lay, nullptr, disocc, alpha_max, B, T, Tw, Tc, Tp, L, H, W, scale, stream);
+}
+
+extern "C" int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
+                                           const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
+                                           float* flow, float* raw, float* score, float* disocc,
+                                           float* alpha_max, int B, int T, int Tw, int Tc, int Tp, int L, int H,
+                                           int W, int scale, int C, int Tcx, waldo_stream_t stream) {
+  if (C < 1 || Tcx < Tc || Tcx > Tc + 1 || !raw || !score) {
+    set_error("waldo_flow_ctx_warp_raw_fwd: bad raw layout C=%d Tc'=%d for Tc=%d (need C >= 1, Tc <= Tc' <= Tc + 1, "
+              "raw and score)", C, Tcx, Tc);
+    return WALDO_EINVAL;
+  }
+  const int64_t plane = (int64_t)H * scale * W * scale, ctx = (int64_t)(C + L) * plane;
+  const ActxLayout lay = {(int64_t)Tp * Tcx * ctx, ctx, (int64_t)Tcx * ctx};
+  return flow_ctx_warp_launch("waldo_flow_ctx_warp_raw_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
+                              raw + (int64_t)C * plane, lay, score, disocc, alpha_max, B, T, Tw, Tc, Tp, L, H, W,
+                              scale, stream);
+}
+
+static int frame_warp_fuse_launch(const char* fn, const float* input, const float* flow, const float* alpha,
+                                  const float* score, const int64_t* ctx_ts, float* out, float* raw, int B, int T,
+                                  int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+                                  waldo_stream_t stream) {
+  if (B < 0 || T < 1 || Tc < 1 || Tc + (include_self ? 1 : 0) > kFwMaxCtx || Tp < 1 || C < 1 || L < 1 ||
+      Hd < 1 || Wd < 1 || Hd > 32767 || Wd > 32767 || (include_self && Tp != T)) {
+    set_error("%s: bad shape B=%d T=%d Tc=%d Tp=%d C=%d L=%d Hd=%d Wd=%d include_self=%d "
+              "(at most %d contexts incl. self; include_self needs Tp == T)", fn, B, T, Tc, Tp, C, L, Hd, Wd,
+              include_self, kFwMaxCtx);
+    return WALDO_EINVAL;
+  }
+  if (Wd < 2 || Hd < 1) {
+    set_error("%s: frames of %d x %d (need at least two columns)", fn, Hd, Wd);
+    return WALDO_EINVAL;
+  }
+  const int64_t units = (int64_t)B * Tp;
+  const HdGeom geom = HdTile<WALDO_FWF_TILE_COLS>::geom(units, Hd, Wd);
+  if (hd_grid(units, geom) > 2147483647) {
+    set_error("%s: problem too large for one launch", fn);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!input || !flow || (!alpha && !score) || !ctx_ts || !out || !raw) {
+    set_error("%s: null pointer", fn);
+    return WALDO_EINVAL;
+  }
+  const dim3 grid((unsigned)hd_grid(units, geom));
+  if (Tc <= 4)
+    hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+  else
+    hipLaunchKernelGGL(frame_warp_fuse_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+  return launch_status(fn);
 }
 
 extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
                                          const int64_t* ctx_ts, float* out, float* raw, int B, int T,
                                          int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self,
                                          float eps, waldo_stream_t stream) {
-  if (B < 0 || T < 1 || Tc < 1 || Tc + (include_self ? 1 : 0) > kFwMaxCtx || Tp < 1 || C < 1 || L < 1 ||
-      Hd < 1 || Wd < 1 || Hd > 32767 || Wd > 32767 || (include_self && Tp != T)) {
-    set_error("waldo_frame_warp_fuse_fwd: bad shape B=%d T=%d Tc=%d Tp=%d C=%d L=%d Hd=%d Wd=%d include_self=%d "
-              "(at most %d contexts incl. self; include_self needs Tp == T)", B, T, Tc, Tp, C, L, Hd, Wd,
-              include_self, kFwMaxCtx);
-    return WALDO_EINVAL;
-  }
-  if (Wd < 2 || Hd < 1) {
-    set_error("waldo_frame_warp_fuse_fwd: frames of %d x %d (need at least two columns)", Hd, Wd);
-    return WALDO_EINVAL;
-  }
-  const int64_t units = (int64_t)B * Tp;
-  const HdGeom geom = HdTile<WALDO_FWF_TILE_COLS>::geom(units, Hd, Wd);
-  if (hd_grid(units, geom) > 2147483647) {
-    set_error("waldo_frame_warp_fuse_fwd: problem too large for one launch");
-    return WALDO_EINVAL;
-  }
-  if (B == 0) return WALDO_OK;
-  if (!input || !flow || !alpha || !ctx_ts || !out || !raw) {
+  if (B > 0 && !alpha) {
     set_error("waldo_frame_warp_fuse_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  const dim3 grid((unsigned)hd_grid(units, geom));
-  if (Tc <= 4)
-    hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
-  else
-    hipLaunchKernelGGL(frame_warp_fuse_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
-  return launch_status("waldo_frame_warp_fuse_fwd");
+  return frame_warp_fuse_launch("waldo_frame_warp_fuse_fwd", input, flow, alpha, nullptr, ctx_ts, out, raw, B, T, Tc,
+                                Tp, C, L, Hd, Wd, include_self, eps, stream);
+}
+
+extern "C" int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const float* score,
+                                             const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
+                                             int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+                                             waldo_stream_t stream) {
+  if (B > 0 && !score) {
+    set_error("waldo_frame_warp_fuse_raw_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  return frame_warp_fuse_launch("waldo_frame_warp_fuse_raw_fwd", input, flow, nullptr, score, ctx_ts, out, raw, B, T,
+                                Tc, Tp, C, L, Hd, Wd, include_self, eps, stream);
 }

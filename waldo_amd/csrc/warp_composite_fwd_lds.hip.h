@@ -175,8 +175,14 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // tps_mapping_fwd_kernel (bit-identical values), one frame ahead, into an LDS table -- the
 // forward-only path then is ONE kernel (at 8 frames of 128 x 128 the separate mapping kernel and
 // its launch gap were a quarter of the call).
-template <int LP, bool EXL, bool FOLD>
-__global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
+// ALLS ("all layers staged": the shape for SHORT launches, a few hundred tile-frames -- BASELINE config C2 is 512):
+// the chip is not full, so nothing hides the latency of a workgroup's own dependent chain, and the rolling window
+// above is L barrier-separated steps of load -> LDS -> taps (~1.2 us each).  Here the box loads of ALL layers are
+// issued at once (LP x 8 registers), all images are written to LDS (LP x 8 KB), ONE barrier, then every layer is
+// sampled: one exposed memory round trip and one barrier per tile-frame instead of L.  Same arithmetic on the same
+// operands: bit-identical output.
+template <int LP, bool EXL, bool FOLD, bool ALLS = false>
+__global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
     const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of float4 texels
+  constexpr int kImgFloats = (ALLS ? LP : 2) * kImgBufFloats;   // two buffers of float4 texels (ALLS: one per layer)
   constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
     // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
     // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
     // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
-    constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
+    constexpr int kAhead = (ALLS || LP < WALDO_STAGE_AHEAD) ? LP : WALDO_STAGE_AHEAD;
     static_assert(kStageCap / 2 == kBlock, "one box item per lane");
     int item_l = threadIdx.x;
     asm volatile("" : "+v"(item_l));
@@ -399,6 +405,15 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
+    if constexpr (ALLS) {
+#pragma unroll
+      for (int l = 0; l < LP; ++l) {
+        if (!EXL && l >= L) continue;
+        if (bh[l] * bw[l] <= kStageCap && item_l < bh[l] * (bw[l] >> 1))
+          stage_store(img + l * kImgBufFloats, item_l, stg[l]);
+      }
+      __syncthreads();  // every layer's image complete
+    }
     {
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
@@ -408,16 +423,18 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
           continue;
         }
         const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
-        if (fits) {
-          const int n = bh[l] * (bw[l] >> 1);
-          if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
-            stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
+        if constexpr (!ALLS) {
+          if (fits) {
+            const int n = bh[l] * (bw[l] >> 1);
+            if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
+              stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
+          }
+          if (l + kAhead < LP) issue(l + kAhead);
+          __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         }
-        if (l + kAhead < LP) issue(l + kAhead);
-        __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
           const TapCore tc = tap_core_px(gx[l], gy[l], H, W);
-          const float* b0 = img + (l & 1) * kImgBufFloats;
+          const float* b0 = img + (ALLS ? l : (l & 1)) * kImgBufFloats;
           f32x2_t sv[2];
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1

@@ -98,6 +98,7 @@ constexpr int kDump = kImgWords;                       // + lane
 typedef float f32x2_k2 __attribute__((ext_vector_type(2)));
 constexpr int kSubRows = 8, kSubCols = 16;                       // sub-blocks that carry their own scales
 constexpr int kSubX = kSrcCols / kSubCols, kSubY = kSrcRows / kSubRows, kSubs = kSubX * kSubY;
+static_assert(kSubs <= 16, "the uniform-scale verdict is one DPP row of 16 lanes, one lane per sub-block (group16_pk_min)");
 static_assert(kSubX * kSubCols == kSrcCols && kSubY * kSubRows == kSrcRows, "sub-blocks tile S");
 
 // MIXED: the corners take the scales of the sub-blocks they land in (a table read per corner); else

@@ -16,16 +16,57 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_INDEX_CHECKED = {}  # id(index tensor) -> (weak reference to it, {(version, limit)} already validated)
+_INDEX_RANGE = {}  # id(index tensor) -> (weak reference to it, {version: (lowest, highest) index it holds})
 
 
-def _checked_set(ts):
+def _index_entry(ts):
     key = id(ts)
-    ent = _INDEX_CHECKED.get(key)
+    ent = _INDEX_RANGE.get(key)
     if ent is None or ent[0]() is not ts:  # (tensors compare element-wise: identity, not ==)
-        ent = (weakref.ref(ts, lambda _ref, k=key: _INDEX_CHECKED.pop(k, None)), set())
-        _INDEX_CHECKED[key] = ent
+        ent = (weakref.ref(ts, lambda _ref, k=key: _INDEX_RANGE.pop(k, None)), {})
+        _INDEX_RANGE[key] = ent
     return ent[1]
+
+
+def _index_version(ts):
+    """Version counter of ``ts``, or None for a tensor without one (made under ``torch.inference_mode()``:
+    reading ``_version`` raises there)."""
+    if ts.is_inference():
+        return None
+    return ts._version
+
+
+def _index_range(ts, private=False):
+    """(lowest, highest) index in ``ts``: ONE device -> host read per distinct (tensor, version), whatever
+    limits it is checked against afterwards.  A tensor without a version counter (inference mode) is read on
+    every call -- its owner could have written to it in place unseen -- unless it is ``private``: a copy
+    ``normalise_time_index`` made and nobody else holds."""
+    seen = _index_entry(ts)
+    ver = _index_version(ts)
+    key = ver if ver is not None else ("private" if (private or "private" in seen) else None)
+    if key is not None and key in seen:
+        return seen[key]
+    rng = tuple(int(v) for v in torch.aminmax(ts))
+    if key is not None:
+        seen[key] = rng
+    return rng
+
+
+def normalise_time_index(ts):
+    """``ctx_ts`` / ``pred_ts`` as the kernels take them (int64, contiguous), made ONCE per decode by the
+    caller (``Warper``) and handed to every op of the chain: the ops then find the same tensor object and its
+    range in the cache instead of converting an expanded view (synthesizer.py:438) into a fresh temporary --
+    and reading it back -- per op.  Under ``torch.inference_mode()`` the result is always a private copy."""
+    out = _c(ts.long())
+    if out.numel() == 0 or torch.cuda.is_current_stream_capturing():
+        return out
+    if out.is_inference():
+        if out is ts:
+            out = ts.clone()
+        _index_range(out, private=True)
+    else:
+        _index_range(out)
+    return out
 
 
 def _check_time_index(fn, name, ts, limit):
@@ -35,14 +76,9 @@ def _check_time_index(fn, name, ts, limit):
     reuses its index tensors pays it once -- and nothing while a HIP graph is being captured."""
     if ts.numel() == 0 or torch.cuda.is_current_stream_capturing():
         return
-    seen = _checked_set(ts)
-    key = (ts._version, int(limit))
-    if key in seen:
-        return
-    lo, hi = (int(v) for v in torch.aminmax(ts))
+    lo, hi = _index_range(ts)
     if lo < 0 or hi >= limit:
         raise _lib.WaldoHipError(f"{fn}: {name} holds indices in [{lo}, {hi}], valid range is [0, {int(limit) - 1}]")
-    seen.add(key)
 
 
 # --------------------------------------------------------------------------------------
@@ -650,6 +686,30 @@ class _FlowCtxWarp(torch.autograd.Function):
         return g_lr, None, g_a01, None, None, g_occ, None, None, None
 
 
+def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
+    _lib.check_cuda(flow_lr, a01, occ)
+    if not (ctx_ts.is_cuda and pred_ts.is_cuda):
+        raise _lib.WaldoHipError(f"{fn}: ctx_ts / pred_ts must be on the GPU")
+    flow_lr, a01, occ = _c(flow_lr), _c(a01), _c(occ)
+    ctx_ts, pred_ts = _c(ctx_ts.long()), _c(pred_ts.long())
+    m, nl, _, h, w = flow_lr.shape
+    b, tc, tp = ctx_ts.shape
+    t = occ.shape[1]
+    if m != b * tc * tp or pred_ts.numel() != tp or tuple(a01.shape) != (b * tw, nl, h * scale, w * scale) \
+            or tuple(occ.shape) != (b, t, nl, nl):
+        raise _lib.WaldoHipError(
+            f"{fn}: inconsistent shapes flow_lr={tuple(flow_lr.shape)} a01={tuple(a01.shape)} "
+            f"ctx_ts={tuple(ctx_ts.shape)} pred_ts={tuple(pred_ts.shape)} occ={tuple(occ.shape)}")
+    _check_time_index(fn, "ctx_ts", ctx_ts, tw)
+    _check_time_index(fn, "pred_ts", pred_ts, t)
+    if isobj_lr is not None:
+        _lib.check_cuda(isobj_lr)
+        isobj_lr = _c(isobj_lr.detach())
+        if tuple(isobj_lr.shape) != (m, nl - 1, h, w):
+            raise _lib.WaldoHipError(f"{fn}: isobj_lr {tuple(isobj_lr.shape)} is not (M, L-1, H, W)")
+    return flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ
+
+
 def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False):
     """Context-alpha warp + ghost mask + disocclusion + second occlusion product + flow compositing
     (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
@@ -659,28 +719,63 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer
     carries no gradient, as in the reference).  ``layer_max``: a fourth result, ``alpha_ctx.amax(dim=1)``
     (M, Hd, Wd) -- what Synthesizer.predict's disocclusion test computes from alpha_ctx (synthesizer.py:447) --
     as a by-product (no gradient)."""
-    _lib.check_cuda(flow_lr, a01, occ)
-    if not (ctx_ts.is_cuda and pred_ts.is_cuda):
-        raise _lib.WaldoHipError("flow_ctx_warp: ctx_ts / pred_ts must be on the GPU")
-    flow_lr, a01, occ = _c(flow_lr), _c(a01), _c(occ)
-    ctx_ts, pred_ts = _c(ctx_ts.long()), _c(pred_ts.long())
+    flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = _flow_ctx_warp_args("flow_ctx_warp", flow_lr, isobj_lr, a01, ctx_ts,
+                                                                       pred_ts, occ, tw, scale)
+    flow, alpha_ctx, disocc, amax = _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale,
+                                                       bool(layer_max))
+    return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
+
+
+class RawSlots:
+    """What ``flow_ctx_warp_into_raw`` leaves for ``frame_warp_fuse``: the ``raw`` tensor of
+    Warper.input_to_output, (B, Tp, Tc', C + L, Hd, Wd), with the alpha slots of its Tc contexts filled, and
+    ``score`` (B, Tc, Tp, Hd, Wd) = the per-context sums of (alpha + 1) / 2 (lvd.py:841).  It rides on the
+    ``alpha_ctx`` view as the attribute ``_waldo_raw``: only that very tensor object, unmodified, takes the
+    short way through ``frame_warp_fuse``."""
+
+    def __init__(self, raw, score, channels, include_self, alpha_view):
+        self.raw, self.score, self.channels, self.include_self = raw, score, channels, include_self
+        self.version = _index_version(alpha_view)
+        self.ptr, self.strides = alpha_view.data_ptr(), alpha_view.stride()
+
+    def still_describes(self, alpha):
+        """``alpha`` is the view this was made for and nobody wrote to it since (a write went into ``raw``
+        as well, but the sums in ``score`` would be stale).  Inference tensors have no version counter: the one
+        caller that asks for this path, ``decode_output``, removes the attribute before it hands the view out."""
+        return (alpha.data_ptr() == self.ptr and alpha.stride() == self.strides
+                and _index_version(alpha) == self.version)
+
+
+def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self,
+                           layer_max=False):
+    """``flow_ctx_warp`` for the caller that runs ``frame_warp_fuse`` on the result next
+    (LVD.forward(mode="decode_output"), lvd.py:141-153), WITHOUT autograd: ``alpha_ctx`` is written straight
+    into the alpha slots of input_to_output's ``raw`` tensor (lvd.py:846) and returned as a strided
+    (B*Tc*Tp -> B, Tc, Tp, L, Hd, Wd) view of it.  ``channels`` = C of the frames that will be warped,
+    ``include_self``: whether ``raw`` gets the extra self context.  Returns (flow, alpha_ctx view (B, Tc, Tp, L,
+    Hd, Wd), disocc[, amax]); the view carries a ``RawSlots`` as ``_waldo_raw``."""
+    if torch.is_grad_enabled() and any(x is not None and x.requires_grad for x in (flow_lr, a01, occ)):
+        raise _lib.WaldoHipError("flow_ctx_warp_into_raw: no gradient flows through the raw-slot path; use flow_ctx_warp")
+    flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = _flow_ctx_warp_args("flow_ctx_warp_into_raw", flow_lr, isobj_lr, a01,
+                                                                       ctx_ts, pred_ts, occ, tw, scale)
     m, nl, _, h, w = flow_lr.shape
     b, tc, tp = ctx_ts.shape
     t = occ.shape[1]
-    if m != b * tc * tp or pred_ts.numel() != tp or tuple(a01.shape) != (b * tw, nl, h * scale, w * scale) \
-            or tuple(occ.shape) != (b, t, nl, nl):
-        raise _lib.WaldoHipError(
-            f"flow_ctx_warp: inconsistent shapes flow_lr={tuple(flow_lr.shape)} a01={tuple(a01.shape)} "
-            f"ctx_ts={tuple(ctx_ts.shape)} pred_ts={tuple(pred_ts.shape)} occ={tuple(occ.shape)}")
-    _check_time_index("flow_ctx_warp", "ctx_ts", ctx_ts, tw)
-    _check_time_index("flow_ctx_warp", "pred_ts", pred_ts, t)
-    if isobj_lr is not None:
-        _lib.check_cuda(isobj_lr)
-        isobj_lr = _c(isobj_lr.detach())
-        if tuple(isobj_lr.shape) != (m, nl - 1, h, w):
-            raise _lib.WaldoHipError(f"flow_ctx_warp: isobj_lr {tuple(isobj_lr.shape)} is not (M, L-1, H, W)")
-    flow, alpha_ctx, disocc, amax = _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale,
-                                                       bool(layer_max))
+    hd, wd = a01.shape[-2:]
+    tcx = tc + (1 if include_self else 0)
+    with torch.no_grad():
+        flow = flow_lr.new_empty(m, 2, hd, wd)
+        raw = flow_lr.new_empty(b, tp, tcx, channels + nl, hd, wd)
+        score = flow_lr.new_empty(b, tc, tp, hd, wd)
+        disocc = flow_lr.new_empty(m, hd, wd)
+        amax = flow_lr.new_empty(m, hd, wd) if layer_max else None
+        with torch.cuda.device(flow_lr.device):
+            _lib.call("waldo_flow_ctx_warp_raw_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
+                      _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(raw),
+                      _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax), b, t, tw, tc, tp, nl, h, w, scale,
+                      int(channels), tcx, _lib.current_stream(flow_lr.device))
+        alpha_ctx = raw[:, :, :tc, channels:].permute(0, 2, 1, 3, 4, 5)  # (B, Tc, Tp, L, Hd, Wd), strided
+    alpha_ctx._waldo_raw = RawSlots(raw, score, int(channels), bool(include_self), alpha_ctx)
     return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
 
 
@@ -727,11 +822,13 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
     """Warper.input_to_output (models/nets/lvd.py:830-853).  input (B,T,C,Hd,Wd);
     flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1]; ctx_ts (B,Tc,Tp) long.
     Returns (out (B,Tp,C+1,Hd,Wd), raw (B,Tc',Tp,C+L,Hd,Wd)).  Differentiable w.r.t. flow and alpha;
-    the frames in ``input`` are data (no gradient is produced for them)."""
+    the frames in ``input`` are data (no gradient is produced for them).  An ``alpha`` that
+    ``flow_ctx_warp_into_raw`` produced already sits in ``raw``: it is neither read nor copied."""
     _lib.check_cuda(input, flow, alpha)
     if not ctx_ts.is_cuda:
         raise _lib.WaldoHipError("frame_warp_fuse: ctx_ts must be on the GPU")
-    input, flow, alpha = _c(input.detach()), _c(flow), _c(alpha)
+    slots = getattr(alpha, "_waldo_raw", None)
+    input, flow = _c(input.detach()), _c(flow)
     ctx_ts = _c(ctx_ts.long())
     b, t, c, hd, wd = input.shape
     _, tc, tp, nl = alpha.shape[:4]
@@ -741,7 +838,15 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
             f"frame_warp_fuse: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
             f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
     _check_time_index("frame_warp_fuse", "ctx_ts", ctx_ts, t)
-    return _FrameWarpFuse.apply(input, flow, alpha, ctx_ts, bool(include_self), eps)
+    if slots is not None and slots.channels == c and slots.include_self == bool(include_self) \
+            and slots.still_describes(alpha) and not (torch.is_grad_enabled() and flow.requires_grad):
+        raw, out = slots.raw, input.new_empty(b, tp, c + 1, hd, wd)
+        with torch.no_grad(), torch.cuda.device(input.device):
+            _lib.call("waldo_frame_warp_fuse_raw_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(slots.score),
+                      _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
+                      1 if include_self else 0, float(eps), _lib.current_stream(input.device))
+        return out, raw.permute(0, 2, 1, 3, 4, 5)
+    return _FrameWarpFuse.apply(input, flow, _c(alpha), ctx_ts, bool(include_self), eps)
 
 
 # --------------------------------------------------------------------------------------

@@ -259,6 +259,9 @@ class Warper(nn.Module):
         return WF.lyt_dist(alpha.squeeze(3), lyt, cls if self.weight_cls else None, self.min_cls, first_obj=1)
 
     def _lyt_dist_torch(self, alpha_obj, lyt, cls):
+        """The same distribution as a framework expression, differentiable w.r.t. the layout as the reference's
+        is (lvd.py:737-744); checked against the kernel and the CPU restatement's layout gradient in
+        tests/test_gpu_warper.py::test_lyt_dist_layout_gradient_branch."""
         win = alpha_obj.squeeze(3) + 1e-6                                       # B Tw No H W
         if self.weight_cls:
             win = win * torch.einsum("bon,btnhw->btohw", cls + self.min_cls, lyt.softmax(dim=2))
@@ -312,9 +315,11 @@ class Warper(nn.Module):
             sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1).reshape(b, tp, h, w, 2), tc)
         return obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w), sgo, sgb
 
-    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
+    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=False):
         """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
-        the low resolution goes through the same per-op kernels as the unfused path."""
+        the low resolution goes through the same per-op kernels as the unfused path.  ``into_raw``
+        (decode_output, no autograd): alpha_ctx is written into the slots it will occupy in
+        input_to_output's ``raw`` tensor and comes back as a view of it (WF.flow_ctx_warp_into_raw)."""
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
         tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
@@ -343,19 +348,30 @@ class Warper(nn.Module):
             ones = torch.ones(b * tc, tp, no, 1, ho, wo, device=input.device, dtype=input.dtype)
             is_obj = self.obj_to_output(ones, gridp, delta_obj=0).reshape(b * tc * tp, no, h, w)
         flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
-        res = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts, occ, tw, s,
-                               layer_max=self.keep_alpha_ctx_max)
+        if into_raw:
+            res = WF.flow_ctx_warp_into_raw(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts,
+                                            occ, tw, s, input.size(2), self.include_self and tp == t,
+                                            layer_max=self.keep_alpha_ctx_max)
+        else:
+            res = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts, occ, tw, s,
+                                   layer_max=self.keep_alpha_ctx_max)
         flow, alpha_ctx, disocc = res[:3]
         # by-product for Synthesizer.predict's disocclusion test (synthesizer.py:447: alpha_ctx.max(dim=3)[0])
         self.alpha_ctx_max = res[3].view(b, tc, tp, hd, wd) if self.keep_alpha_ctx_max else None
         alpha_out = alpha_out.view(b, tw, nl, hd, wd)
         return (flow.view(b, tc, tp, 2, hd, wd), (alpha_out if self.fast else None), alpha_out,
-                alpha_ctx.view(b, tc, tp, nl, hd, wd), disocc.view(b, tc, tp, 1, hd, wd))
+                (alpha_ctx if into_raw else alpha_ctx.view(b, tc, tp, nl, hd, wd)), disocc.view(b, tc, tp, 1, hd, wd))
 
-    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only):
+    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=False):
+        # int64 + contiguous ONCE: every op below finds the same tensor object (and its validated range)
+        ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)
         if self.fuse_hd and self._fused_ok([input, occ, obj_alpha, bg_alpha, cls, *grid],
                                            grid[1].shape[2] + 1, input.size(2) - 3):
-            return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only)
+            no_grad = not (torch.is_grad_enabled() and any(
+                x is not None and x.requires_grad for x in (occ, obj_alpha, bg_alpha, cls, *grid)))
+            return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only,
+                                    into_raw=into_raw and no_grad and self._frame_warp_fused(input, ctx_ts.size(1),
+                                                                                             pred_ts.size(0)))
         self.alpha_ctx_max = None  # (only the fused pass produces it)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
@@ -415,12 +431,18 @@ class Warper(nn.Module):
         """Reference lvd.py:707-828 (restrict_to_ctx inference path)."""
         return self._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, True)
 
+    def _frame_warp_fused(self, input, tc, tp):
+        """input_to_output runs as the fused kernel (csrc/flow_ctx.hip:frame_warp_fuse_kernel)."""
+        self_slot = self.include_self and tp == input.size(1)
+        return self.fuse_hd and tc + int(self_slot) <= WF.MAX_FUSE_CTX and \
+            not (torch.is_grad_enabled() and input.requires_grad)
+
     def input_to_output(self, input, alpha, flow, ctx_ts, eps=1e-6):
         """Reference lvd.py:830-853."""
         b, tc, tp = flow.shape[:3]
+        ctx_ts = WF.normalise_time_index(ctx_ts)
         self_slot = self.include_self and tp == input.size(1)
-        if self.fuse_hd and tc + int(self_slot) <= WF.MAX_FUSE_CTX and \
-                not (torch.is_grad_enabled() and input.requires_grad):
+        if self._frame_warp_fused(input, tc, tp):
             return WF.frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=self_slot, eps=eps)
         hd, wd = self.src_shape_hd
         c = input.size(-3)
@@ -476,9 +498,13 @@ def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pr
     """``LVD.forward(mode="decode_output")`` (lvd.py:141-153): flow / alpha synthesis, frame warp and
     temporal fusion, the ``use_disocc`` concatenation (lvd.py:148-151) and the split of the score
     channel.  Returns ``(output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx)``."""
-    fn = warper.grid_to_flow_ctx if restrict_to_ctx else warper.grid_to_flow
-    flow, alpha_unflt, alpha, alpha_ctx, disocc = fn(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+    ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)  # shared by both calls
+    # (without autograd the context alphas are composited straight into raw_output's slots: into_raw)
+    flow, alpha_unflt, alpha, alpha_ctx, disocc = warper._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts,
+                                                                      pred_ts, restrict_to_ctx, into_raw=True)
     output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
+    if hasattr(alpha_ctx, "_waldo_raw"):
+        del alpha_ctx._waldo_raw  # the view goes to the caller as a plain tensor
     raw_alpha = output[:, :, -1:]
     if use_disocc:
         if warper.include_self:

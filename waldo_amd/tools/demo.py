@@ -47,7 +47,22 @@ class UniformFusionUNet(nn.Module):
         return x.new_zeros(x.shape[0], 4, *x.shape[-2:])
 
 
-def synthetic_network_outputs(opt, b, t, ctx_len, seed=0, device="cpu"):
+# Background motion of the stand-ins, as (drift of the 2 x 2 affine part, of the translation, of the per-point
+# deltas) per frame step, in the pose heads' units.
+#   "wild"        every one of the 6 + 2 Lb background pose values drifts independently (0.02 randn per frame):
+#                 with Lb = 128 lattice points 1/8 of the frame apart, neighbouring control points end up a whole
+#                 lattice cell apart after ten frames -- a folded warp (local stretch |d ix / dx| of the composited
+#                 flow at 512 x 1024: median 1, 90 % quantile 7, 99 % quantile 30).  The stress case; rounds 1-3
+#                 benchmarked the C4 / C5 pipelines on it.
+#   "calibrated"  the same amplitudes for the rigid part and a tenth of them for the per-point deltas: the local
+#                 stretch of the warp stays within what optical flow of real driving footage shows (RAFT flows of
+#                 the reference's demo clips, datasets/demo_cityscapes/*_raft_128: |d ix / dx| 10 % / 99 % quantiles
+#                 0.92 / 1.04 per frame step, mean |flow| 2.4 px of 256 and max 16 px per step; measured with
+#                 tools_dev/flo_stats.py), accumulated over the 4 .. 13 frame steps a clip spans.
+BG_MOTION = {"wild": (0.02, 0.02, 0.02), "calibrated": (0.01, 0.02, 0.002)}
+
+
+def synthetic_network_outputs(opt, b, t, ctx_len, seed=0, device="cpu", motion="wild"):
     """Seeded stand-ins for what the networks outside the path would hand over, on ``device``."""
     g = torch.Generator().manual_seed(seed)
     no, nl = opt.num_obj, opt.num_lyt
@@ -66,6 +81,10 @@ def synthetic_network_outputs(opt, b, t, ctx_len, seed=0, device="cpu"):
     obj[..., [0, 3]] = -0.2 + 0.2 * obj[..., [0, 3]]  # scales around bias_obj - 0.2
     obj[..., [1, 2]] = 0.2 * obj[..., [1, 2]]        # small shear
     bg = 0.02 * torch.randn(b, 1, 1, 6 + 2 * lb, generator=g) * torch.arange(t).view(1, t, 1, 1)
+    lin, shift, pts = BG_MOTION[motion]  # ("wild" multiplies by 1: the same numbers as ever)
+    bg[..., [0, 1, 2, 3]] *= lin / 0.02
+    bg[..., [4, 5]] *= shift / 0.02
+    bg[..., 6:] *= pts / 0.02
     occ_score = torch.randn(b, t, no, generator=g)
     cls = torch.softmax(2.0 * torch.randn(b, no, nl, generator=g), dim=-1)
     out = dict(raw=raw, pred_obj_pose=obj.reshape(b * t, no, -1), pred_bg_pose=bg.reshape(b * t, 1, -1),
@@ -123,11 +142,20 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
         return estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(b, nt, no, lo, 2),
                                        bg_pose.view(b, nt, 1, lb, 2), occ_score, obj_alpha_mask=mask)
 
-    warper.keep_alpha_ctx_max = True  # max_l alpha_ctx comes out of the fused flow pass as a by-product
+    def decode(*args):
+        """decode_output + max_l alpha_ctx, which the fused flow pass produces as a by-product (the warper's
+        switch and its result are restored / cleared before returning: no state is left on the module)."""
+        prev = warper.keep_alpha_ctx_max
+        warper.keep_alpha_ctx_max = True
+        try:
+            res = decode_output(warper, *args)
+            return res, warper.alpha_ctx_max
+        finally:
+            warper.keep_alpha_ctx_max = prev
+            warper.alpha_ctx_max = None
 
-    def disocc(alpha_ctx):  # synthesizer.py:447-450
-        mx = warper.alpha_ctx_max  # == alpha_ctx.max(dim=3)[0], without the pass over alpha_ctx
-        if mx is None:
+    def disocc(alpha_ctx, mx):  # synthesizer.py:447-450
+        if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the pass over alpha_ctx
             mx = alpha_ctx.amax(dim=3)
         dmax, dmin = mx.amax(dim=1), mx.amin(dim=1)
         dmax = dmax.clone()
@@ -142,10 +170,10 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
         ctx_ts = ctx_ts[:, -opt.last_n_ctx:].contiguous()
     pred_ts = torch.arange(t, device=dev, dtype=torch.int64)
     real_input = torch.cat([real_vid, real_lyt], dim=2)
-    rec_output, _, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
-                                                                  net["cls"], ctx_ts.contiguous(), pred_ts)
+    (rec_output, _, _, _, _, raw_output, alpha_ctx), mx = decode(real_input, grid, occ, obj_alpha, bga, net["cls"],
+                                                                 ctx_ts, pred_ts)
     out["rec_vid"] = rec_output[:, :, :3]
-    out["rec_disocc"] = disocc(alpha_ctx)
+    out["rec_disocc"] = disocc(alpha_ctx, mx)
     out["inp_rec_vid"] = wif(raw_output)  # synthesizer.py:460
     if not opt.no_future:
         # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
@@ -155,9 +183,9 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
         pred_ts = torch.arange(ctx_len, t, device=dev, dtype=torch.int64)
         ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(b, -1, tp)
         occ, obj_alpha, bga, grid = alpha_grid_occ(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
-        pred_output, pred_flow, _, alpha, _, raw_output, alpha_ctx = decode_output(
-            warper, real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_ts.contiguous(), pred_ts)
-        out["pred_disocc"] = disocc(alpha_ctx)
+        (pred_output, pred_flow, _, alpha, _, raw_output, alpha_ctx), mx = decode(
+            real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_ts, pred_ts)
+        out["pred_disocc"] = disocc(alpha_ctx, mx)
         out["pred_flow"] = pred_flow
         out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred_output[:, :, :3]], dim=1)
         out["inp_pred_vid"] = torch.cat([real_vid[:, :ctx_len], wif(raw_output)], dim=1)

@@ -49,14 +49,16 @@ class Pipeline:
     """One rank's share of a C4 / C5 run: ``clips`` clips resident on ``device``; ``__call__`` runs
     ``predict`` on them and returns its dict (``inp_pred_vid`` (B, T, 3, Hd, Wd) is the product)."""
 
-    def __init__(self, name, clips, device, seed=0):
+    def __init__(self, name, clips, device, seed=0, motion="calibrated"):
         self.name = name
+        self.motion = motion  # background motion of the stand-ins: demo.BG_MOTION
         self.opt = recipe_opt(name)
         self.frames, self.ctx_len = RECIPES[name][5], RECIPES[name][6]
         self.clips = clips
         self.warper = Warper(self.opt).to(device)
         self.wif = WIF(self.opt, unet=demo.UniformFusionUNet()).to(device)
-        self.net = demo.synthetic_network_outputs(self.opt, clips, self.frames, self.ctx_len, seed=seed, device=device)
+        self.net = demo.synthetic_network_outputs(self.opt, clips, self.frames, self.ctx_len, seed=seed, device=device,
+                                                  motion=motion)
         self.vid, self.lyt = synthetic_clip(self.opt, clips, self.frames, seed, device)
 
     def __call__(self):
@@ -64,19 +66,31 @@ class Pipeline:
 
     def hd_algorithmic_bytes(self):
         """Bytes the full-resolution entry points have to move per ``predict`` (each input read once,
-        each output written once; fp32), by C-ABI name -- the denominators of the bench line's table."""
+        each output written once; fp32), by C-ABI name -- the denominators of the bench line's table.  A context
+        frame (its a01 planes for the flow pass, its C channels for the frame warp) is counted ONCE per (b, t),
+        however many predicted frames gather from it.  Without autograd ``decode_output`` runs the ``_raw``
+        entry points (the context alphas are composited straight into raw_output's slots): their counts have
+        neither the L planes per (b, tc, tp) the frame warp would read nor the L it would copy, and one score
+        plane written and read instead."""
         o = self.opt
         b, t, tc = self.clips, self.frames, self.ctx_len
         nl, ncls, c = o.num_obj + 1, o.num_lyt, 3 + o.num_lyt
         hw = o.dim * int(o.dim * o.aspect_ratio)
         hwd = o.load_dim * int(o.load_dim * o.aspect_ratio)
+        ghost = 0 if o.allow_ghost else nl - 1
         out = {}
         for tp in (t, t - tc):  # reconstruction over all T frames, prediction over the T - Tc future ones
             m = b * tc * tp
+            lr = m * (nl * 2 + ghost) * hw                      # per-layer flows and object masks, low resolution
+            fcw_out = m * (2 + nl + 1 + 1) * hwd                # flow, alpha_ctx, disocc, layer maximum
             add = {
                 "waldo_flow_ctx_alpha_fwd": 4 * (b * tc * nl * hw + b * tc * ncls * hwd + 2 * b * tc * nl * hwd),
-                "waldo_flow_ctx_warp_fwd": 4 * (m * nl * 2 * hw + m * nl * hwd + m * (2 + nl + 1 + 1) * hwd),  # + alpha_max
-                "waldo_frame_warp_fuse_fwd": 4 * (m * (c + 2 + nl) * hwd + b * tp * (c + 1) * hwd + m * (c + nl) * hwd),
+                "waldo_flow_ctx_warp_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out),
+                "waldo_flow_ctx_warp_raw_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out + m * hwd),  # + score
+                "waldo_frame_warp_fuse_fwd": 4 * (b * tc * c * hwd + m * (2 + nl) * hwd + b * tp * (c + 1) * hwd
+                                                  + m * (c + nl) * hwd),
+                "waldo_frame_warp_fuse_raw_fwd": 4 * (b * tc * c * hwd + m * (2 + 1) * hwd + b * tp * (c + 1) * hwd
+                                                      + m * c * hwd),
                 # the fusion reads channels 0-2 and 4 of the raw frames and the UNet's four outputs (wif.py:49-54)
                 "waldo_wif_fuse_fwd": 4 * (m * 4 * hwd + m * 4 * hwd + b * tp * 3 * hwd),
             }
