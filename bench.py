@@ -213,6 +213,10 @@ def main():
                     help="--pipeline: background motion of the stand-in pose heads (waldo_amd/tools/demo.py:BG_MOTION); "
                          "'wild' is the folded warp rounds 1-3 benchmarked on, 'calibrated' keeps the local stretch of "
                          "the warp within what optical flow of the reference's demo clips shows")
+    ap.add_argument("--debug-option", type=int, action="append", default=[],
+                    help="set a test-only kernel-variant switch of the C ABI (include/waldo_hip.h: WALDO_DEBUG_*) for A/B "
+                         "timing, e.g. 3 = frame warp by gathers only")
+    ap.add_argument("--lib", default=None, help="A/B timing: another build of the library (tools_dev/build_variant.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -254,6 +258,10 @@ def main():
 
     import waldo_amd
     from waldo_amd import _lib, functional as WF
+    if args.lib:
+        _lib.use_library(args.lib)
+    for opt in args.debug_option:
+        assert _lib.load().waldo_set_debug_option(opt, 1) == 0
     from waldo_amd.graphs import GraphedCall
     from waldo_amd.tools.utils import get_grid
 

@@ -466,37 +466,6 @@ def test_staged_forward_equals_plain_forward(dev, nl):
     assert torch.equal(staged[0], plain[0]) and torch.equal(staged[1], plain[1])
 
 
-@pytest.mark.parametrize("cfg", [(8, 8, 128, 128, 0.05), (3, 4, 64, 128, 0.05), (2, 11, 48, 64, 0.05), (4, 12, 96, 96, 0.05),
-                                 (8, 8, 128, 128, 0.3), (1, 5, 20, 36, 0.1)])
-@pytest.mark.parametrize("from_pts", [True, False])
-def test_short_launches_stage_all_layers_at_once(dev, cfg, from_pts):
-    """Launches of at most 2048 tile-frames (BASELINE config C2 is 512) take the latency-shaped forward: all layers'
-    footprint boxes in flight and in LDS at once, one barrier per tile-frame.  Bit-identical to the rolling-window
-    kernel (same operands, same arithmetic), with and without the folded TPS mapping, ragged sizes, padded layer
-    counts and warps violent enough that some boxes fall back to gathers."""
-    from waldo_amd import _lib, functional as WF
-    import waldo_amd
-    f, nl, h, w, sigma = cfg
-    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=nl + f, sigma=sigma)
-    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
-    lib = _lib.load()
-    with torch.no_grad():
-        if from_pts:
-            args = (layers.to(dev), pts.to(dev), occ.to(dev), tps.inverse_kernel, tps.basis_t)
-            call = lambda: WF.warp_composite(*args, return_alpha=True)  # noqa: E731
-        else:
-            mapping = WF.tps_mapping(tps.inverse_kernel, pts.to(dev))
-            args = (layers.to(dev), mapping, occ.to(dev), tps.basis_t, True, 0.0)
-            call = lambda: WF._WarpComposite.apply(*args)  # noqa: E731  (the two-step forward: mapping from memory)
-        fast = call()
-        assert lib.waldo_set_debug_option(_lib.DEBUG_FWD_ROLLING, 1) == 0
-        try:
-            rolling = call()
-        finally:
-            lib.waldo_set_debug_option(_lib.DEBUG_FWD_ROLLING, 0)
-    assert torch.equal(fast[0], rolling[0]) and torch.equal(fast[1], rolling[1])
-
-
 @pytest.mark.parametrize("where", ["grad_rgb", "layers"])
 def test_non_finite_gradients_stay_visible(dev, where):
     """A NaN in the incoming gradient or in a layer must reach grad_layers on BOTH backward paths

@@ -307,6 +307,83 @@ def test_flow_ctx_fused_passes(dev, over, ctx_only):
         close(x, z, what="fused vs unfused:" + name)
 
 
+def _flow_ctx_warp_spelled_out(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s):
+    """lvd.py:784-818 with framework ops, on whatever device the inputs are: the statement the kernel's short cuts
+    (absent layers skipped per wavefront) must not be distinguishable from, NaNs included."""
+    import torch.nn.functional as F
+    m, nl, _, h, w = flow_lr.shape
+    b, tc, tp = ctx_ts.shape
+    hd, wd = h * s, w * s
+    up = (lambda x: F.interpolate(x, scale_factor=s, mode="bilinear")) if s > 1 else (lambda x: x)
+    flow = up(flow_lr.reshape(m * nl, 2, h, w)).view(m, nl, 2, hd, wd)
+    xs = O.get_grid(hd, wd).to(flow_lr.device)                                          # 1 Hd Wd 2
+    samp = xs.unsqueeze(1) + flow.permute(0, 1, 3, 4, 2)                               # M L Hd Wd 2
+    src = a01.view(b, tw, nl, hd, wd)[torch.arange(b, device=a01.device).view(b, 1, 1), ctx_ts]   # B Tc Tp L Hd Wd
+    val = F.grid_sample(src.reshape(m * nl, 1, hd, wd), samp.reshape(m * nl, hd, wd, 2), align_corners=False)
+    val = val.view(m, nl, hd, wd)
+    if isobj is not None:
+        keep = (up(isobj) > 0.9).to(val.dtype)
+        val = torch.cat([val[:, :1], torch.where(keep > 0, val[:, 1:], torch.zeros_like(val[:, 1:]))], dim=1)
+    dis = val.max(dim=1)[0]
+    oc = occ[:, pred_ts].unsqueeze(1).expand(b, tc, tp, nl, nl).reshape(m, nl, nl)       # [i][j]
+    fac = 1 - val.unsqueeze(2) * oc.view(m, nl, nl, 1, 1)                               # M i j Hd Wd
+    prod = torch.ones_like(val)
+    for i in range(nl):                                                                 # the kernel's order over i
+        prod = prod * fac[:, i]
+    actx = val * prod
+    out_flow = (actx.unsqueeze(2) * flow).sum(dim=1)
+    return out_flow, actx * 2 - 1, dis
+
+
+@pytest.mark.parametrize("poison", ["none", "occ", "flow", "alpha"])
+def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
+    """The wavefront-level short cuts of flow_ctx_warp_kernel (a layer whose object mask is off in all 64 lanes is
+    not sampled; layers with alpha 0 in all lanes leave the occlusion product): on a scene of SMALL objects --
+    most layers absent from most wavefronts -- the results equal the spelled-out expression, and a NaN / inf in the
+    order, in the low-resolution flows or in the context alphas lands exactly where the expression puts it."""
+    from waldo_amd import functional as WF
+    b, t, tc, tp, nl, h, w, s, tw = 1, 3, 2, 2, 12, 32, 64, 4, 2
+    hd, wd = h * s, w * s
+    g = torch.Generator(device=dev).manual_seed(21)
+    m = b * tc * tp
+    flow_lr = 0.05 * torch.randn(m, nl, 2, h, w, generator=g, device=dev)
+    # every object: a disc of a few cells somewhere in the frame; mask 1 inside, 0 outside
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    cy = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * h
+    cx = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * w
+    isobj = (((yy - cy) ** 2 + (xx - cx) ** 2) < 36).float()
+    a01 = torch.rand(b * tw, nl, hd, wd, generator=g, device=dev)
+    a01[:, 1:] *= (torch.rand(b * tw, nl - 1, hd, wd, generator=g, device=dev) > 0.5)   # exact zeros inside objects too
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    ctx_ts = torch.randint(0, tw, (b, tc, tp), generator=g, device=dev)
+    pred_ts = torch.tensor([2, 0], device=dev)
+    if poison == "occ":
+        occ[0, 2, 3, 5] = float("nan")      # frame 2 is predicted frame 0: a NaN factor in column 5 of every pixel
+        occ[0, 0, 7, 1] = float("inf")
+    elif poison == "flow":
+        flow_lr[1, 4, 0, 10, 20] = float("nan")    # an object that is absent there: 0 * NaN all the same
+        flow_lr[2, 0, 1, 5, 5] = float("inf")
+    elif poison == "alpha":
+        # (NaN only: an INFINITE texel under a zero tap weight is NaN in the four-weight form of F.grid_sample and
+        # may be finite in the lerp form of the kernels -- a difference of the sampling form, not of the skipping)
+        a01[0, 6, 40:60, 100:140] = float("nan")
+        a01[1, 0, 5, 7] = float("nan")
+    with torch.no_grad():
+        flow, actx, dis, amax = WF.flow_ctx_warp(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True)
+        rflow, ractx, rdis = _flow_ctx_warp_spelled_out(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s)
+    for x, y, name in ((flow, rflow, "flow"), (actx, ractx, "alpha_ctx"), (dis, rdis, "disocc"), (amax, ractx.amax(dim=1), "max")):
+        assert torch.equal(torch.isnan(x), torch.isnan(y)), f"{poison}: NaNs of {name} differ"
+        ok = ~torch.isnan(y)
+        # +-inf must agree exactly; finite values to the chain's tolerance
+        assert torch.equal(torch.isinf(x[ok]), torch.isinf(y[ok])), f"{poison}: infinities of {name} differ"
+        fin = ok & ~torch.isinf(y)
+        close(x[fin], y[fin], what=f"{poison}: {name}")
+    if poison == "none":
+        # absent layers come out as the exact constants
+        gone = (actx == -1.0).float().mean().item()
+        assert gone > 0.5, gone
+
+
 @pytest.mark.parametrize("over,ctx_only,include_self", [
     (dict(num_obj=3, dim=16, load_dim=0), False, True),                       # the LVD recipe's shape: x1, ctx "prev"
     (dict(num_obj=16, obj_shape=[2, 2], dim=8, load_dim=32), True, False),   # L = 17, x4, ghost mask

@@ -108,6 +108,18 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 // the padding layers filled with those of layer L - 1.  A tap of a layer is then ONE ds_read_b128 at a
 // compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
 // ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
+#ifndef WALDO_FCW_SPARSE
+#define WALDO_FCW_SPARSE 1  // wave-uniform skipping of absent layers (flow_ctx_warp_kernel); 0: every layer, every factor
+#endif
+#ifndef WALDO_FCW_MASK_FIRST
+#define WALDO_FCW_MASK_FIRST 1  // 0: whole records of every layer; 1: a layer's mask first, its flow record if wanted;
+                                // 2: the masks of ALL layers up front (one LDS round trip), records of wanted layers.
+                                // C5 pipeline, A/B on one box (tools_dev/ab_pipeline.sh): 7.67 / 7.55 / 7.80 ms per step
+#endif
+#ifndef WALDO_FCW_CONST_OUT
+#define WALDO_FCW_CONST_OUT 0   // 1: outputs of layers outside the active set as constants, behind a wave-uniform branch
+                                // -- measured SLOWER (8.1 against 7.6 ms: twelve more branches cut the store stream up)
+#endif
 #ifndef WALDO_FCW_CHUNK
 #define WALDO_FCW_CHUNK 4  // 4: 116 registers at L = 12 (four waves per SIMD) and 1.92 ms at the C5 size; 6: 140 and 2.04 ms
 #endif
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   // the order of the predicted frame from LDS (OccLds): at L = 12 the scalar loads made the kernel issue as
   // many scalar as vector instructions (1480 / 1464 per wavefront)
   __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
-  occ_stage<LP>(occm, occ + ((int64_t)b * T + tpred) * L * L, L);
+  const bool occ_bad = occ_stage<LP>(occm, occ + ((int64_t)b * T + tpred) * L * L, L);
   // ---- the tile's patch of the low-resolution planes (2 L flow planes, L - 1 object masks)
   const int nob = isobj_lr != nullptr ? L - 1 : 0;
   LrPatch lq = lr_patch(y - (int)(threadIdx.x >> 6), x - (int)(threadIdx.x & (kWave - 1)), Hd, Wd, rscale, H, W);
@@ -168,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   lq.ncols = __builtin_amdgcn_readfirstlane(lq.ncols);
   const int area = lq.nrows * lq.ncols;
   const bool staged = area <= kBlock && area * G::kCell <= G::kCap;  // uniform
+  bool flow_bad = false;
   if (staged) {
     // thread = (cell, layer group): kBlock / area groups share the layers of a cell
     const int ngrp = kBlock / area;
@@ -183,10 +196,13 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
         const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW + off;
         f32x4 rec = {fl[0], fl[HW], 0.0f, 0.0f};
         if (nob && lc >= 1) rec[2] = isobj_lr[((int64_t)m * (L - 1) + (lc - 1)) * HW + off];
+        flow_bad |= !(fabsf(rec[0]) <= 3.0e38f) | !(fabsf(rec[1]) <= 3.0e38f);
         *reinterpret_cast<f32x4*>(lrimg + cell * G::kCell + 4 * l) = rec;
       }
   }
-  __syncthreads();
+  // (the barrier doubles as the vote: a non-finite entry anywhere in the order or in the tile's low-resolution flows
+  // switches the skipping below off; a tile whose patch is not staged is not examined: dense)
+  const bool dense = WALDO_FCW_SPARSE ? (__syncthreads_or(occ_bad | flow_bad | !staged) != 0) : (__syncthreads(), true);
   if (x >= Wd || y >= Hd) return;
   const int64_t p = (int64_t)y * Wd + x;
   const UpTaps ut = up_taps(y, x, rscale, H, W);
@@ -201,9 +217,40 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   // its values -- taken two layers at a time (round 2) a wavefront waits L / 2 times for memory, and at
   // three waves per SIMD that wait is what the kernel's time was made of.  Two copies of the loop, one per
   // source of the low-resolution taps.
+  // SPARSITY (round 4).  Objects are small: in a wavefront's 64-pixel row segment most layers are absent -- their
+  // ghost mask is below the threshold in every lane, or their sampled alpha is 0 in every lane.  Two wave-uniform
+  // short cuts, both exact:
+  //  * a layer l >= 1 whose upsampled object mask is <= 0.9 in EVERY lane has alpha 0 whatever it samples
+  //    (lvd.py:785-802: `alpha_ctx * is_obj`): its taps, its two 8-byte gathers and its bilinear value are skipped;
+  //    neither is its flow upsampled: it enters the result as 0 * flow;
+  //  * in the occlusion product a layer with alpha == 0 in every lane contributes the factor 1 - 0 * occ = 1 to
+  //    every column and its own column's result is 0 * product = 0: rows and columns outside the wavefront's
+  //    ACTIVE set are skipped (k^2 instead of L^2 factor evaluations, k ~ 2-4 of 12), and such a layer's outputs
+  //    are the constants 2 * 0 - 1 = -1 (alpha_ctx), + 0 (score, flow).
+  // "Exact" needs finite operands: 0 * inf would have been NaN.  A non-finite entry of the order or of the tile's
+  // low-resolution flows (`dense`, voted at the barrier above) or a non-finite sampled alpha in any lane (`wild`,
+  // below) switches everything back to all L layers and all L x L factors, so NaNs propagate exactly as before.
   float a[LP], fx[LP], fy[LP];
   float dis = -INFINITY;
-  const float* ap = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer min(l, L - 1), stepped
+  const float* ap0 = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer l: + min(l, L - 1) * HWd
+  unsigned active = 0;  // wave-uniform: bit l = some lane has a[l] != 0
+  bool wild = false;    // some lane sampled a non-finite alpha
+  // the object masks of all layers up front (staged tiles): 4 (L - 1) four-byte LDS reads in flight together, one
+  // wait; bit l of keep_bits (per lane) = layer l is visible here, bit l of want_bits (wave-uniform) = in some lane
+  unsigned keep_bits = 0xffffffffu, want_bits = 0xffffffffu;
+  if (WALDO_FCW_MASK_FIRST == 2 && staged && nob) {
+    float g[LP];
+#pragma unroll
+    for (int l = 1; l < LP; ++l)
+      g[l] = up_blend(ut, lrimg[lt.o00 + 4 * l + 2], lrimg[lt.o01 + 4 * l + 2], lrimg[lt.o10 + 4 * l + 2],
+                      lrimg[lt.o11 + 4 * l + 2]);
+#pragma unroll
+    for (int l = 1; l < LP; ++l) {
+      const bool kp = g[l] > 0.9f;
+      if (!kp) keep_bits &= ~(1u << l);
+      if (__ballot(kp) == 0ull) want_bits &= ~(1u << l);
+    }
+  }
   auto layers = [&](auto from_lds) {
     constexpr bool LDS = decltype(from_lds)::value;
     constexpr int CH = LP < WALDO_FCW_CHUNK ? LP : WALDO_FCW_CHUNK;  // layers whose loads are in flight together
@@ -211,97 +258,133 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
     for (int l0 = 0; l0 < LP; l0 += CH) {
       PairTaps pt[CH];
       f32x2_p ra[CH], rb[CH];
-      bool inter[CH];
-      float ghost[CH];
+      bool inter[CH], keep[CH];
+      unsigned need = 0;  // wave-uniform: bit k = layer l0 + k is sampled
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int l = l0 + k;
         if (l >= LP) break;
-        float fxl, fyl, g = 1.0f;
-        if (LDS) {
-          const f32x4 v00 = *reinterpret_cast<const f32x4*>(lrimg + lt.o00 + 4 * l);
-          const f32x4 v01 = *reinterpret_cast<const f32x4*>(lrimg + lt.o01 + 4 * l);
-          const f32x4 v10 = *reinterpret_cast<const f32x4*>(lrimg + lt.o10 + 4 * l);
-          const f32x4 v11 = *reinterpret_cast<const f32x4*>(lrimg + lt.o11 + 4 * l);
-          fxl = up_blend(ut, v00[0], v01[0], v10[0], v11[0]);
-          fyl = up_blend(ut, v00[1], v01[1], v10[1], v11[1]);
-          if (l >= 1) g = up_blend(ut, v00[2], v01[2], v10[2], v11[2]);
+        float fxl = 0.0f, fyl = 0.0f, g = 1.0f;
+        const bool masked = l >= 1 && nob;  // uniform: this layer has an object mask
+        bool want;
+        if (WALDO_FCW_MASK_FIRST == 2 && LDS) {
+          keep[k] = (keep_bits >> l) & 1u;
+          want = l < L && (WALDO_FCW_SPARSE ? ((want_bits >> l) & 1u) != 0 : true);
         } else {
-          const int lc = min(l, L - 1);
-          const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW;
-          fxl = up_sample(fl, ut);
-          fyl = up_sample(fl + HW, ut);
-          if (nob && l >= 1) g = up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(lc - 1, 0)) * HW, ut);
+          if (LDS) {
+            // the mask alone first (four 4-byte reads): most layers stop here
+            if (masked)
+              g = up_blend(ut, lrimg[lt.o00 + 4 * l + 2], lrimg[lt.o01 + 4 * l + 2], lrimg[lt.o10 + 4 * l + 2],
+                           lrimg[lt.o11 + 4 * l + 2]);
+          } else if (masked) {
+            g = up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(min(l, L - 1) - 1, 0)) * HW, ut);
+          }
+          keep[k] = !(masked && !(g > 0.9f));
+          // a padding layer (l >= L) is never sampled: its alpha is 0 by definition
+          want = l < L && (WALDO_FCW_SPARSE ? __ballot(keep[k]) != 0ull : true);
+        }
+        if (want || ((dense || WALDO_FCW_MASK_FIRST == 0) && l < L)) {  // (dense: the flow of every layer, its product with alpha 0 may be NaN)
+          if (LDS) {
+            const f32x2_p v00 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o00 + 4 * l);
+            const f32x2_p v01 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o01 + 4 * l);
+            const f32x2_p v10 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o10 + 4 * l);
+            const f32x2_p v11 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o11 + 4 * l);
+            fxl = up_blend(ut, v00[0], v01[0], v10[0], v11[0]);
+            fyl = up_blend(ut, v00[1], v01[1], v10[1], v11[1]);
+          } else {
+            const float* fl = flow_lr + (((int64_t)m * L + min(l, L - 1)) * 2) * HW;
+            fxl = up_sample(fl, ut);
+            fyl = up_sample(fl + HW, ut);
+          }
         }
         fx[l] = fxl;
         fy[l] = fyl;
-        ghost[k] = g;
-        pt[k] = pair_taps(gx0 + fxl, gy0 + fyl, Hd, Wd, inter[k]);
+        if (want) {
+          need |= 1u << k;
+          pt[k] = pair_taps(gx0 + fxl, gy0 + fyl, Hd, Wd, inter[k]);
 #ifdef WALDO_ABL_FCW_NOGATHER  // timing-only ablation: one coalesced load instead of the taps
-        ra[k] = rb[k] = (f32x2_p){ap[p], fxl};
+          ra[k] = rb[k] = (f32x2_p){ap0[p], fxl};
 #else
-        pair_load(ap, pt[k], ra[k], rb[k]);
+          pair_load(ap0 + (int64_t)min(l, L - 1) * HWd, pt[k], ra[k], rb[k]);
 #endif
-        if (l + 1 < L) ap += HWd;
+        }
         if (k & 1) __builtin_amdgcn_sched_barrier(0);  // the LDS records of two layers at a time (32 registers)
       }
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int l = l0 + k;
         if (l >= LP) break;
-        float v = pair_value(ra[k], rb[k], pt[k], inter[k]);
-        if (l >= 1) v = (nob && !(ghost[k] > 0.9f)) ? 0.0f : v;
-        // the value HERE: the wave-uniform border branches cut the loop body into basic blocks, and the
-        // compiler sinks this arithmetic to the first use of a[] after the loop -- keeping the taps and loaded
-        // pairs of EVERY layer alive to the end (216 registers at L = 12)
-        asm volatile("" : "+v"(v));
-        dis = nan_max(dis, v);  // (a padding layer repeats a real one: the maximum does not notice)
-        a[l] = l < L ? v : 0.0f;
+        float v = 0.0f;
+        if (need & (1u << k)) {
+          v = pair_value(ra[k], rb[k], pt[k], inter[k]);
+          v = keep[k] ? v : 0.0f;
+          // the value HERE: the wave-uniform border branches cut the loop body into basic blocks, and the
+          // compiler sinks this arithmetic to the first use of a[] after the loop -- keeping the taps and loaded
+          // pairs of EVERY layer alive to the end (216 registers at L = 12)
+          asm volatile("" : "+v"(v));
+          if (__ballot(v != 0.0f) != 0ull) active |= 1u << l;
+          wild |= __ballot(!(fabsf(v) <= 3.0e38f)) != 0ull;
+        }
+        if (l < L) dis = nan_max(dis, v);
+        a[l] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // one chunk's loads at a time
     }
   };
   if (staged) layers(std::true_type{});
   else layers(std::false_type{});
+  if (!WALDO_FCW_SPARSE || dense || wild) active = L >= 32 ? 0xffffffffu : (1u << L) - 1u;
   disocc[(int64_t)m * HWd + p] = dis;
   float ox = 0.0f, oy = 0.0f;
   float amax = -INFINITY;  // max over the layers of the composited alpha (Synthesizer.predict's disocclusion test)
   float* ac = alpha_ctx + b * lay.sb + ((m / Tp) % Tc) * lay.stc + tp * lay.stp;
   float ssum = 0.0f;
   // four columns j of the order per step, two and two on the packed-fp32 pipe (the product of every column
-  // runs over i in the same order as in the other kernels of the path)
+  // runs over i in the same order as in the other kernels of the path); rows and column quads outside the active
+  // set are skipped (see above)
 #pragma unroll
   for (int j = 0; j < LP; j += 4) {
     f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
 #ifdef WALDO_ABL_FCW_NOOCC  // timing-only ablation: without the L x L products
     prd[0][0] = occm[j];
 #else
+    if ((active >> j) & 0xfu) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
-      const f32x4_o o = occ_quad<LP, false>(occm, i, j);
-      const f32x2_w ai = {a[i], a[i]};
-      // 1 - a o in one rounding (v_pk_fma_f32): four packed operations per row instead of six
-      const f32x2_w one = {1.0f, 1.0f};
-      prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
-      if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
+      for (int i = 0; i < LP; ++i) {
+        if (active & (1u << i)) {  // wave-uniform
+          const f32x4_o o = occ_quad<LP, false>(occm, i, j);
+          const f32x2_w ai = {a[i], a[i]};
+          // 1 - a o in one rounding (v_pk_fma_f32): four packed operations per row instead of six
+          const f32x2_w one = {1.0f, 1.0f};
+          prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
+          if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
+        }
+      }
     }
 #endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (j + k >= LP) break;
-      const float v = a[j + k] * prd[k >> 1][k & 1];  // 0 for padding layers
-      ox += v * fx[j + k];
-      oy += v * fy[j + k];
+      if (!WALDO_FCW_CONST_OUT || (active & (1u << (j + k)))) {  // wave-uniform
+        const float v = a[j + k] * prd[k >> 1][k & 1];
+        ox += v * fx[j + k];
+        oy += v * fy[j + k];
 #ifndef WALDO_ABL_FCW_NOSTORE
-      if (j + k < L) {
-        const float av = v * 2.0f - 1.0f;
-        ac[p] = av;
-        ac += HWd;
-        amax = nan_max(amax, av);
-        if (SCORE) ssum += (av + 1.0f) / 2.0f;
-      }
+        if (j + k < L) {
+          const float av = v * 2.0f - 1.0f;
+          ac[p] = av;
+          amax = nan_max(amax, av);
+          if (SCORE) ssum += (av + 1.0f) / 2.0f;
+        }
 #endif
+      } else if (j + k < L) {
+        // alpha 0 in every lane (all operands finite): 2 * 0 - 1, + 0 to the score and to the flow
+#ifndef WALDO_ABL_FCW_NOSTORE
+        ac[p] = -1.0f;
+        amax = nan_max(amax, -1.0f);
+#endif
+      }
+      if (j + k < L) ac += HWd;
     }
     __builtin_amdgcn_sched_barrier(0);  // a quad of columns at a time (bounds the registers)
   }

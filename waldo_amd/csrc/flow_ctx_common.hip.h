@@ -78,16 +78,21 @@ struct OccLds {
   static constexpr int kFloats = 2 * LP * kRow;
 };
 
-// block-wide; no barrier inside
+// block-wide; no barrier inside.  Returns whether THIS thread saw a non-finite entry (callers that skip factors
+// of the product vote on it: 1 - 0 * inf is not 1).
 template <int LP>
-__device__ __forceinline__ void occ_stage(float* occm, const float* __restrict__ oc, int L) {
+__device__ __forceinline__ bool occ_stage(float* occm, const float* __restrict__ oc, int L) {
   constexpr int R = OccLds<LP>::kRow;
+  bool bad = false;
   for (int e = threadIdx.x; e < LP * R; e += kBlock) {
     const int r = e / R, c = e - r * R;
     const int rc = min(r, L - 1), cc = min(c, L - 1);
-    occm[e] = oc[rc * L + cc];           // [i = r][j = c]
+    const float v = oc[rc * L + cc];
+    bad |= !(fabsf(v) <= 3.0e38f);
+    occm[e] = v;                         // [i = r][j = c]
     occm[LP * R + e] = oc[cc * L + rc];  // [j = r][i = c]
   }
+  return bad;
 }
 
 typedef float f32x4_o __attribute__((ext_vector_type(4)));

@@ -142,3 +142,7 @@ extern "C" int waldo_warp_composite_bwd(const float* layers, const float* basis_
 namespace waldo { int k1_stamps_read(unsigned long long* dst, int n); }
 extern "C" int waldo_debug_k1_stamps(unsigned long long* dst, int n) { return waldo::k1_stamps_read(dst, n); }
 #endif
+#ifdef WALDO_FWD_STAMPS
+namespace waldo { int fwd_stamps_read(unsigned long long* dst, int n); }
+extern "C" int waldo_debug_fwd_stamps(unsigned long long* dst, int n) { return waldo::fwd_stamps_read(dst, n); }
+#endif

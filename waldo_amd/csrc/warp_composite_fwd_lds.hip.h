@@ -50,6 +50,20 @@ namespace waldo {
                              // fwd 0.726 / 0.728 / 0.736 / 0.836 / 0.990 ms, bwd 2.222 / 2.225 / 2.242 / 2.58 / 2.59)
 #endif
 
+// Diagnostic build only (-DWALDO_FWD_STAMPS): s_memtime stamps of wave 0 at the phase boundaries of the first
+// frame of a workgroup's chunk (tools_dev/fwd_stamps.py); never compiled into the product library.
+#ifdef WALDO_FWD_STAMPS
+constexpr int kFwdStampSlots = 16, kFwdStampBlocks = 4096;
+__device__ unsigned long long waldo_fwd_stamps[kFwdStampBlocks * kFwdStampSlots];
+#define WALDO_FSTAMP(i)                                                                  \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < kFwdStampBlocks)                                \
+      waldo_fwd_stamps[blockIdx.x * kFwdStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define WALDO_FSTAMP(i) do { } while (0)
+#endif
+
 struct BoxTaps {
   float fx, fy;                  // fractional parts
   float v00, v01, v10, v11;      // 1 / 0 validity of the corners
@@ -175,14 +189,13 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // tps_mapping_fwd_kernel (bit-identical values), one frame ahead, into an LDS table -- the
 // forward-only path then is ONE kernel (at 8 frames of 128 x 128 the separate mapping kernel and
 // its launch gap were a quarter of the call).
-// ALLS ("all layers staged": the shape for SHORT launches, a few hundred tile-frames -- BASELINE config C2 is 512):
-// the chip is not full, so nothing hides the latency of a workgroup's own dependent chain, and the rolling window
-// above is L barrier-separated steps of load -> LDS -> taps (~1.2 us each).  Here the box loads of ALL layers are
-// issued at once (LP x 8 registers), all images are written to LDS (LP x 8 KB), ONE barrier, then every layer is
-// sampled: one exposed memory round trip and one barrier per tile-frame instead of L.  Same arithmetic on the same
-// operands: bit-identical output.
-template <int LP, bool EXL, bool FOLD, bool ALLS = false>
-__global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
+// Measured and dropped in round 4 ("all layers staged" for short launches: every layer's box loads issued at once,
+// LP images in LDS, ONE barrier per tile-frame instead of L): bit-identical, and no faster -- 12.2 us against 11.8 at
+// BASELINE config C2.  tools_dev/fwd_stamps.py shows why: of a C2 tile-frame's ~10 us a third is the first memory
+// round trip (basis operand, mapping fold), a sixth the MFMA grid + transposition, and the L staged layer steps cost
+// 4.4 us rolling against 3.1 + 1.8 (issue) all at once.  DESIGN.md section 4c.
+template <int LP, bool EXL, bool FOLD>
+__global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
     const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  constexpr int kImgFloats = (ALLS ? LP : 2) * kImgBufFloats;   // two buffers of float4 texels (ALLS: one per layer)
+  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of float4 texels
   constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
   const int arow = lane & 15, kk = lane >> 4;
   int chunk, tile, rest_;
   if (!xcd_decode_banded(blockIdx.x, nchunks, nbands, ntiles, 1, chunk, tile, rest_)) return;
+  WALDO_FSTAMP(0);
   const int col0 = (tile % ntx) * kLdsTile, row0 = (tile / ntx) * kLdsTile + wave * 4;
   // 16 x 16 tile: wave w covers rows 4w .. 4w+3, lane -> (row 4w + lane / 16, column lane % 16)
   PixelMap pm;
@@ -228,8 +242,43 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
       }
     }
   };
+  // The FIRST frame's table, ahead of the frame loop, where nothing else is live yet: a thread's entries (L * K3 * 2
+  // <= 2 kBlock up to 12 layers) are loaded TOGETHER (clamped indices, no branch around the loads) and then summed --
+  // as the loop above the second trip, which only the first few threads make, is a second exposed memory round
+  // trip that the whole workgroup waits for at the barrier (1.3 us of a C2 tile-frame's 10).  Same fma order per
+  // entry: same bits.
+  auto fold_first = [&](int fm) {
+    if constexpr (FOLD && LP <= 12) {
+      constexpr int kTrips = (LP * K3 * 2 + kBlock - 1) / kBlock;
+      const int n_ent = L * K3 * 2;
+      float rv[kTrips][K3 - 3], xv[kTrips][K3 - 3];
+#pragma unroll
+      for (int q = 0; q < kTrips; ++q) {
+        const int e = min((int)threadIdx.x + q * kBlock, n_ent - 1);
+        const int c = e & 1, r = (e >> 1) % K3, l = (e >> 1) / K3;
+        const float* row = inv_kernel + r * K3;
+        const float* x = src_pts + ((int64_t)fm * L + l) * (K3 - 3) * 2 + c;
+#pragma unroll
+        for (int n = 0; n < K3 - 3; ++n) {
+          rv[q][n] = row[n];
+          xv[q][n] = x[2 * n];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kTrips; ++q) {
+        const int e = (int)threadIdx.x + q * kBlock;
+        float acc = 0.0f;
+#pragma unroll
+        for (int n = 0; n < K3 - 3; ++n) acc = fmaf(rv[q][n], xv[q][n], acc);
+        if (e < n_ent) smap[(fm & 1) * (LP * K3 * 2) + e] = acc;
+      }
+    } else {
+      fold_mapping(fm);
+    }
+  };
   // zero-weight taps of wild (NaN) coordinates may read any word of the image: keep it finite
-  for (int i = threadIdx.x; i < kMain; i += kBlock) lds[i] = 0.0f;
+  static_assert(kMain % 4 == 0, "cleared sixteen bytes at a time");
+  for (int i = threadIdx.x; i < kMain / 4; i += kBlock) reinterpret_cast<f32x4*>(lds)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
   // MFMA A operand, v_mfma_f32_16x16x4_f32: A[row = lane & 15][k = lane >> 4]; row = pixel column
   // arow of tile row g of this wave, k = 4 * ks + kk.  Kept across the frames of the chunk.
@@ -247,8 +296,9 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
   }
   const int f0 = chunk * frames_per_block;
   const int f1 = min(F, f0 + frames_per_block);
-  if (f0 < f1) fold_mapping(f0);
+  if (f0 < f1) fold_first(f0);
   __syncthreads();
+  WALDO_FSTAMP(1);  // LDS cleared, basis operand loaded, first mapping folded
 
   // pixel-unit grid: the MFMA column of this lane is an x column (even) or a y column (odd)
   const float half_size = 0.5f * (float)((arow & 1) ? H : W);
@@ -343,6 +393,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
       }
     }
     __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
+    if (f == f0) WALDO_FSTAMP(2);  // grid on MFMA, ranges, transposition
     // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 of every wave turn the range of
     // "their" column into block origins, then the corners go to SGPRs
     int lo_t[NT], hi_t[NT];
@@ -378,7 +429,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
     // rolling window of kAhead layers is in flight (the load of layer l + kAhead is issued when
     // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
     // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
-    constexpr int kAhead = (ALLS || LP < WALDO_STAGE_AHEAD) ? LP : WALDO_STAGE_AHEAD;
+    constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
     static_assert(kStageCap / 2 == kBlock, "one box item per lane");
     int item_l = threadIdx.x;
     asm volatile("" : "+v"(item_l));
@@ -405,15 +456,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
-    if constexpr (ALLS) {
-#pragma unroll
-      for (int l = 0; l < LP; ++l) {
-        if (!EXL && l >= L) continue;
-        if (bh[l] * bw[l] <= kStageCap && item_l < bh[l] * (bw[l] >> 1))
-          stage_store(img + l * kImgBufFloats, item_l, stg[l]);
-      }
-      __syncthreads();  // every layer's image complete
-    }
+    if (f == f0) WALDO_FSTAMP(3);  // boxes, first loads issued
     {
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
@@ -423,18 +466,16 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
           continue;
         }
         const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
-        if constexpr (!ALLS) {
-          if (fits) {
-            const int n = bh[l] * (bw[l] >> 1);
-            if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
-              stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
-          }
-          if (l + kAhead < LP) issue(l + kAhead);
-          __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
+        if (fits) {
+          const int n = bh[l] * (bw[l] >> 1);
+          if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
+            stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
         }
+        if (l + kAhead < LP) issue(l + kAhead);
+        __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
           const TapCore tc = tap_core_px(gx[l], gy[l], H, W);
-          const float* b0 = img + (ALLS ? l : (l & 1)) * kImgBufFloats;
+          const float* b0 = img + (l & 1) * kImgBufFloats;
           f32x2_t sv[2];
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1
@@ -467,6 +508,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
       }
     }
 
+    if (f == f0) WALDO_FSTAMP(5);  // every layer sampled
     // ---- composite: a_0 = 1 (lvd.py:105), a_l = (s_l3 + 1) / 2
     float a[LP];
 #pragma unroll
@@ -509,6 +551,7 @@ __global__ __launch_bounds__(kBlock, ALLS ? 1 : (LP <= 8 ? WALDO_FWD8_WAVES : (L
       o[2 * HW] = 2.0f * b - 1.0f;
     }
     __syncthreads();  // boxred and the image buffers are re-used by the next frame
+    if (f == f0) WALDO_FSTAMP(6);  // composite, stores issued, closing barrier
   }
 }
 

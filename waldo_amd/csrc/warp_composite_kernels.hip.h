@@ -389,8 +389,6 @@ static inline int chunk_frames(int F, int64_t ntiles) {
   return 1;
 }
 
-constexpr int64_t kAllStagedMaxTileFrames = 2048;  // launches up to this many (16 x 16 tile, frame) pairs: ALLS
-
 struct TileGeom {
   int ntx, nty, ntiles;
 };
@@ -422,20 +420,8 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
     if (!debug_option(WALDO_DEBUG_FWD_PLAIN) && staged_eligible(H, W)) {
       const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
       dim3 grid16((unsigned)xcd_grid_banded(nchunks, nbands, nt16, 1));
-      // short launches (BASELINE config C2: 512 tile-frames) take the latency-shaped variant: every layer's box
-      // in flight at once, one barrier per tile-frame (ALLS; compiled up to 12 layers: LP x 8 KB of LDS)
-      const bool all_staged = LP <= 12 && (int64_t)nt16 * F <= kAllStagedMaxTileFrames &&
-                              !debug_option(WALDO_DEBUG_FWD_ROLLING);
       auto go = [&](auto exl, auto fold) {
         constexpr bool EXL = decltype(exl)::value, FOLD = decltype(fold)::value;
-        if constexpr (LP <= 12) {
-          if (all_staged) {
-            hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, EXL, FOLD, true>), grid16, dim3(kBlock), 0, st,
-                               layers, basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, L, H, W, fpb, ntx16,
-                               nt16, nchunks, nbands, delta);
-            return;
-          }
-        }
         hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, EXL, FOLD>), grid16, dim3(kBlock), 0, st, layers,
                            basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16,
                            nchunks, nbands, delta);

@@ -8,3 +8,10 @@ int k1_stamps_read(unsigned long long* dst, int n) {
 }
 }  // namespace waldo
 #endif
+#ifdef WALDO_FWD_STAMPS
+namespace waldo {
+int fwd_stamps_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(waldo_fwd_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+}  // namespace waldo
+#endif
