@@ -43,9 +43,7 @@ int waldo_max_layers(void);
 #define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
 #define WALDO_DEBUG_BWD_GENERIC 2 /* fused backward: the generic per-tap-atomics kernel for every shape
                                      (waldo_warp_composite_bwd_workspace_bytes answers 0) */
-#define WALDO_DEBUG_FWF_GATHER 3  /* Warper.input_to_output: per-tap gathers for every tile instead of staged
-                                     footprint boxes (same bits) */
-#define WALDO_DEBUG_COUNT 4
+#define WALDO_DEBUG_COUNT 3
 int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------

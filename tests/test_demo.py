@@ -2,8 +2,10 @@
 waldo_amd/tools/demo.py -- the call order of Synthesizer.predict (models/synthesizer.py:434-480) on
 the committed six-frame clip -- on the HIP path against the SAME chain restated with the CPU oracle,
 stage by stage.  Grid inversion rounds positions to cells, so fp32-level differences upstream flip
-a few cells: the inverted grids and everything downstream are compared with a
-robust measure (share of deviating pixels + mean error), the stages before them tightly."""
+a few cells: the inverted grids alone are compared with a robust measure (share of
+deviating pixels + mean error); everything DOWNSTREAM of them is compared on identical grids -- the restated chain
+is fed the grids the HIP path produced -- and held to the chain bound of tests/parity.py (1e-4 + the measured
+fp32 noise of the restatement itself), like every other chain test."""
 import os
 
 import pytest
@@ -12,6 +14,7 @@ import torch
 from oracle import producers_oracle as PO
 from oracle import warper_oracle as WO
 from oracle import wif_oracle as O
+from parity import close  # tests/parity.py
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,23 +30,30 @@ def robust(a, b, what, tol=2e-3, share=0.02, mean_tol=1e-3):
     assert bad <= share and d.mean().item() <= mean_tol, (what, bad, d.mean().item())
 
 
-def oracle_predict(opt, vid, lyt, net, ctx_len):
-    """demo.predict restated with oracle functions only (CPU)."""
+def oracle_predict(opt, vid, lyt, net, ctx_len, grid=None, dtype=torch.float32):
+    """demo.predict restated with oracle functions only (CPU), in ``dtype``; ``grid``: the four grids to use
+    instead of the restatement's own (so that both sides of a comparison invert nothing differently)."""
+    given = grid
+    vid, lyt = vid.to(dtype), lyt.to(dtype)
+    net = {k: v.to(dtype) for k, v in net.items()}
     from waldo_amd.tools import demo
     cfg = WO.WarperCfg.from_opt(opt)
     b, t = vid.shape[:2]
     no = opt.num_obj
     lo, lb = opt.obj_shape[0] * opt.obj_shape[1], opt.latent_shape[0] * opt.latent_shape[1]
-    buf = demo.pose_buffers(opt, "cpu")
-    mask = demo.obj_alpha_mask(opt, "cpu")
-    bg_alpha = torch.ones(b, 1, *cfg.src_shape)
+    buf = {k: v.to(dtype) for k, v in demo.pose_buffers(opt, "cpu").items()}
+    mask = demo.obj_alpha_mask(opt, "cpu").to(dtype)
+    bg_alpha = torch.ones(b, 1, *cfg.src_shape, dtype=dtype)
 
     def stage(pop, pbp, score, nt):
         obj_pose = PO.pose_affine(pop, buf["mul_obj"], buf["bias_obj"], buf["tgt_pts_obj"].view(lo, 2))
-        bg_pose = PO.pose_affine(pbp, torch.ones(6), buf["bias_bg"], buf["tgt_pts_bg"].view(lb, 2))
+        bg_pose = PO.pose_affine(pbp, torch.ones(6, dtype=dtype), buf["bias_bg"], buf["tgt_pts_bg"].view(lb, 2))
         oa = PO.decoder_tail(net["raw"], None, 0.0, opt.scale_factor)
         oa = PO.alpha_arithmetic(oa.view(b, no, 1, *oa.shape[-2:]), mask)
-        grid = WO.warper_grids(cfg, obj_pose.view(b, nt, no, lo, 2), bg_pose.view(b, nt, 1, lb, 2))
+        if given is not None:
+            grid = [g.to(dtype) for g in given]
+        else:
+            grid = WO.warper_grids(cfg, obj_pose.view(b, nt, no, lo, 2), bg_pose.view(b, nt, 1, lb, 2))
         return obj_pose, oa, O.compute_occ(score), grid
 
     out = {}
@@ -55,14 +65,14 @@ def oracle_predict(opt, vid, lyt, net, ctx_len):
     out["rec_vid"] = dec[0][:, :, :3]
     raw = dec[5]
     vt = raw.permute(0, 2, 1, 3, 4, 5)
-    out["inp_rec_vid"] = WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:]), ab=True)
+    out["inp_rec_vid"] = WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:], dtype=dtype), ab=True)
     tp = t - ctx_len
     oa2, occ2, grid2 = oa, occ, grid  # full-length "predicted" pose sequences: the same synthetic poses
     ctx_ts = torch.arange(ctx_len).view(1, -1, 1).expand(b, -1, tp).contiguous()
     dec = WO.decode_output(cfg, inp, grid2, occ2, oa2, bg_alpha, net["cls"], ctx_ts, torch.arange(ctx_len, t), True, False)
     out["pred_vid"] = torch.cat([vid[:, :ctx_len], dec[0][:, :, :3]], 1)
     vt = dec[5].permute(0, 2, 1, 3, 4, 5)
-    out["inp_pred_vid"] = torch.cat([vid[:, :ctx_len], WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:]), True)], 1)
+    out["inp_pred_vid"] = torch.cat([vid[:, :ctx_len], WO.wif_fuse(vt, torch.zeros(*vt.shape[:3], 4, *vt.shape[-2:], dtype=dtype), True)], 1)
     return out
 
 
@@ -89,10 +99,15 @@ def test_demo_clip_predict_chain(dev, tmp_path):
     grid = warper(pts.view(1, 6, 3, 4, 2), flp.bg_pose_to_points(netd["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"]).view(1, 6, 1, 16, 2))
     assert (grid[0].cpu() - ref["grid"][0]).abs().max() <= 1e-4
     robust(grid[1], ref["grid"][1], "inverted object grids", tol=1e-3, share=0.02, mean_tol=5e-2)
-    # the frames predict produces
+    robust(grid[3], ref["grid"][3], "inverted background grid", tol=1e-3, share=0.02, mean_tol=5e-2)
+    # the frames predict produces, against the chain restated ON THE SAME GRIDS (fp32 and fp64): the chain bound
+    hip_grid = [g.cpu() for g in grid]
+    same32 = oracle_predict(opt, vid, lyt, net, ctx_len, grid=hip_grid)
+    same64 = oracle_predict(opt, vid, lyt, net, ctx_len, grid=hip_grid, dtype=torch.float64)
     for key in ("rec_vid", "inp_rec_vid", "pred_vid", "inp_pred_vid"):
         assert torch.isfinite(got[key]).all()
-        robust(got[key], ref[key], key)
+        close(got[key], same32[key], what=key, exact=same64[key])
+        robust(got[key], ref[key], key)  # and, loosely, against the chain that inverted its own grids
     assert got["rec_vid"].shape == (1, 6, 3, 128, 128) and got["pred_vid"].shape == (1, 6, 3, 128, 128)
     assert torch.equal(got["pred_vid"][:, :ctx_len].cpu(), vid[:, :ctx_len])
     # reconstruction from 4 context frames of a real clip: not a blank image

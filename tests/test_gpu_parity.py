@@ -94,7 +94,8 @@ def test_grid_sample_golden(dev, golden, delta):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1, 1, 1), (2, 3, 7, 5, 300, 1), (4, 2, 64, 64, 128, 256),
-                                   (6, 23, 16, 32, 16, 32)])
+                                   (6, 23, 16, 32, 16, 32),
+                                   (2, 2, 128, 256, 40, 32), (1, 40, 64, 128, 8, 8)])
 def test_grid_sample_random(dev, shape):
     from waldo_amd import functional as WF
     n, c, hi, wi, ho, wo = shape

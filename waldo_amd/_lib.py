@@ -78,7 +78,6 @@ PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
 DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
 DEBUG_BWD_GENERIC = 2
-DEBUG_FWF_GATHER = 3
 
 _lock = threading.Lock()
 _lib = None

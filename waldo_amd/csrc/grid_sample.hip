@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
       gix = fmaf(gv, ddx, gix);
       giy = fmaf(gv, bot - top, giy);
     }
+#ifndef WALDO_ABL_GS_NOATOMIC  // timing-only ablation: without the scatter
     if (grad_input != nullptr) {
       float* gp = grad_input + (nin * C + c) * HWi;
       if (t.w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gv * t.w00);
@@ -65,12 +66,22 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
       if (t.w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gv * t.w10);
       if (t.w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gv * t.w11);
     }
+#endif
   }
   if (grad_grid != nullptr) {
     float2* o = reinterpret_cast<float2*>(grad_grid + (n * HWo + p) * 2);
     *o = make_float2(gix * (0.5f * (float)Wi), giy * (0.5f * (float)Hi));
   }
 }
+
+// Measured and dropped in round 4: the scatter summed in LDS first.  The kernel above is bound by its global atomics
+// (at the LVD recipe 58 us per call against 18 us with the scatter compiled out, -DWALDO_ABL_GS_NOATOMIC), so a
+// variant gave every workgroup a BAND of output rows of one map, an LDS window of the input rows the band's taps
+// reach (ds_add_f32), and one coalesced global atomic per non-zero texel of the window at the end -- correct (it
+// passed the parity tests against the per-tap form and the oracle) and SLOWER: 84 / 74 / 77 / 72 us per call with
+// bands of 16 / 4 / 2 / 8 rows (profiles/r04_ab_grid_sample_bwd_window.txt).  A band is a serial loop of dependent
+// round trips per wavefront (grid -> taps -> store) where the per-pixel kernel keeps 20 000 workgroups in flight,
+// the grid is read twice (window placement), and ds_add_f32 retires ~3 cycles per lane.
 
 // Four consecutive output pixels per thread (HWo % 4 == 0): the grid and the outputs move as 16-byte vectors
 // and a lane has four pixels' tap loads in flight: forward -12 % (15.6 -> 13.6 us per call at the LVD recipe).

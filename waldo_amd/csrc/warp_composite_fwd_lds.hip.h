@@ -194,8 +194,11 @@ __device__ __forceinline__ f32x2_t lerp2(const f32x2_t p00, const f32x2_t p01, c
 // BASELINE config C2.  tools_dev/fwd_stamps.py shows why: of a C2 tile-frame's ~10 us a third is the first memory
 // round trip (basis operand, mapping fold), a sixth the MFMA grid + transposition, and the L staged layer steps cost
 // 4.4 us rolling against 3.1 + 1.8 (issue) all at once.  DESIGN.md section 4c.
-template <int LP, bool EXL, bool FOLD>
-__global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
+// NW: wavefronts per workgroup.  4: a 16 x 16 tile (wave w = rows 4w .. 4w+3).  8: a 16 x 32 tile, waves 4 .. 7 on its
+// right half -- the footprint box of the wider tile has less halo per pixel (round 4's experiment: DESIGN.md
+// section 4); the staged image holds 128 NW texels, one two-texel item per lane as before.
+template <int LP, bool EXL, bool FOLD, int NW = 4>
+__global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (EXL ? WALDO_FWD12_WAVES : 3) : 2))) void warp_composite_fwd_lds_kernel(
     const float* __restrict__ layers, const float* __restrict__ basis_t,
     const float* __restrict__ mapping, const float* __restrict__ inv_kernel,
     const float* __restrict__ src_pts, const float* __restrict__ occ, float* __restrict__ rgb,
@@ -204,8 +207,9 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers
   constexpr int K3 = 19, KS = (K3 + 3) / 4;
   constexpr int NC = 2 * LP, NT = (NC + 15) / 16, GGC = NT * 16, TP = GGC + 1;
-  constexpr int kImgFloats = 2 * kImgBufFloats;   // two buffers of float4 texels
-  constexpr int kTFloats = 4 * kWave * TP;        // per-wave transposition slices of the grid
+  constexpr int kThreads = NW * kWave, kCap = kStageCap * NW / 4, kBuf = 4 * kCap;  // texels / floats of one layer image
+  constexpr int kImgFloats = 2 * kBuf;            // two buffers of float4 texels
+  constexpr int kTFloats = NW * kWave * TP;       // per-wave transposition slices of the grid
   constexpr int kMain = kImgFloats > kTFloats ? kImgFloats : kTFloats;
   const int L = EXL ? LP : Lrt;
   const int64_t HW = (int64_t)H * W;
@@ -216,7 +220,8 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   int chunk, tile, rest_;
   if (!xcd_decode_banded(blockIdx.x, nchunks, nbands, ntiles, 1, chunk, tile, rest_)) return;
   WALDO_FSTAMP(0);
-  const int col0 = (tile % ntx) * kLdsTile, row0 = (tile / ntx) * kLdsTile + wave * 4;
+  const int col0 = (tile % ntx) * (kLdsTile * NW / 4) + (wave >> 2) * kLdsTile;
+  const int row0 = (tile / ntx) * kLdsTile + (wave & 3) * 4;
   // 16 x 16 tile: wave w covers rows 4w .. 4w+3, lane -> (row 4w + lane / 16, column lane % 16)
   PixelMap pm;
   pm.live = col0 + arow < W && row0 + kk < H;
@@ -224,14 +229,14 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   const int64_t p = pm.p;
 
   constexpr int kMapFloats = FOLD ? 2 * LP * K3 * 2 : 0;  // two frames' mapping tables
-  __shared__ __attribute__((aligned(16))) float lds[kMain + 4 * GGC * 2 + kMapFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kMain + NW * GGC * 2 + kMapFloats];
   float* img = lds;
   float* boxred = lds + kMain;  // [wave][column][min, max]
-  float* smap = boxred + 4 * GGC * 2;
+  float* smap = boxred + NW * GGC * 2;
   // mapping of frame fm into table fm & 1: entry e = (layer * K3 + k) * 2 + xy
   auto fold_mapping = [&](int fm) {
     if constexpr (FOLD) {
-      for (int e = threadIdx.x; e < L * K3 * 2; e += kBlock) {
+      for (int e = threadIdx.x; e < L * K3 * 2; e += kThreads) {
         const int c = e & 1, r = (e >> 1) % K3, l = (e >> 1) / K3;
         const float* row = inv_kernel + r * K3;
         const float* x = src_pts + ((int64_t)fm * L + l) * (K3 - 3) * 2 + c;
@@ -249,12 +254,12 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   // entry: same bits.
   auto fold_first = [&](int fm) {
     if constexpr (FOLD && LP <= 12) {
-      constexpr int kTrips = (LP * K3 * 2 + kBlock - 1) / kBlock;
+      constexpr int kTrips = (LP * K3 * 2 + kThreads - 1) / kThreads;
       const int n_ent = L * K3 * 2;
       float rv[kTrips][K3 - 3], xv[kTrips][K3 - 3];
 #pragma unroll
       for (int q = 0; q < kTrips; ++q) {
-        const int e = min((int)threadIdx.x + q * kBlock, n_ent - 1);
+        const int e = min((int)threadIdx.x + q * kThreads, n_ent - 1);
         const int c = e & 1, r = (e >> 1) % K3, l = (e >> 1) / K3;
         const float* row = inv_kernel + r * K3;
         const float* x = src_pts + ((int64_t)fm * L + l) * (K3 - 3) * 2 + c;
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
       }
 #pragma unroll
       for (int q = 0; q < kTrips; ++q) {
-        const int e = (int)threadIdx.x + q * kBlock;
+        const int e = (int)threadIdx.x + q * kThreads;
         float acc = 0.0f;
 #pragma unroll
         for (int n = 0; n < K3 - 3; ++n) acc = fmaf(rv[q][n], xv[q][n], acc);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
   };
   // zero-weight taps of wild (NaN) coordinates may read any word of the image: keep it finite
   static_assert(kMain % 4 == 0, "cleared sixteen bytes at a time");
-  for (int i = threadIdx.x; i < kMain / 4; i += kBlock) reinterpret_cast<f32x4*>(lds)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = threadIdx.x; i < kMain / 4; i += kThreads) reinterpret_cast<f32x4*>(lds)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
   // MFMA A operand, v_mfma_f32_16x16x4_f32: A[row = lane & 15][k = lane >> 4]; row = pixel column
   // arow of tile row g of this wave, k = 4 * ks + kk.  Kept across the frames of the chunk.
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
     for (int nt = 0; nt < NT; ++nt) {
       float mn = boxred[(nt * 16 + arow) * 2 + 0], mx = boxred[(nt * 16 + arow) * 2 + 1];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
+      for (int w = 1; w < NW; ++w) {
         mn = fminf(mn, boxred[(w * GGC + nt * 16 + arow) * 2 + 0]);
         mx = fmaxf(mx, boxred[(w * GGC + nt * 16 + arow) * 2 + 1]);
       }
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
       bh[l] = ymax - ymin + 1;
 #ifdef WALDO_ABL_NOFALLBACK  // timing-only ablation: oversize boxes are cut to the cap (wrong values)
       bw[l] = min(bw[l], 128);
-      bh[l] = min(bh[l], kStageCap / bw[l]);
+      bh[l] = min(bh[l], kCap / bw[l]);
 #endif
     }
 
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
     // layer l leaves its registers for LDS): memory latency is exposed once per frame; then each
     // layer goes registers -> LDS -> taps; the image is double-buffered, one barrier per layer.
     constexpr int kAhead = LP < WALDO_STAGE_AHEAD ? LP : WALDO_STAGE_AHEAD;
-    static_assert(kStageCap / 2 == kBlock, "one box item per lane");
+    static_assert(kCap / 2 == kThreads, "one box item per lane");
     int item_l = threadIdx.x;
     asm volatile("" : "+v"(item_l));
     float s[LP][4];
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
       const float* src = layers + ((int64_t)WALDO_LAYER_FRAME(f) * L + lc) * 4 * HW;
       // unconditional loads (items past the box re-read its last item; a box that does not fit
       // reads texel 0): no exec-mask branches, so the loads are issued back to back
-      const bool fits = bh[l] * bw[l] <= kStageCap;
+      const bool fits = bh[l] * bw[l] <= kCap;
       const int bw2 = bw[l] >> 1, n = fits ? bh[l] * bw2 : 1;
       const int ox = fits ? __mul24(by0[l], W) + bx0[l] : 0;
       // item, bw2 < 2^9 and the +0.5: the approximate reciprocal (1 ulp) gives the exact quotient
@@ -465,17 +470,17 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
           s[l][3] = -1.0f;
           continue;
         }
-        const bool fits = bh[l] * bw[l] <= kStageCap;  // block-uniform
+        const bool fits = bh[l] * bw[l] <= kCap;  // block-uniform
         if (fits) {
           const int n = bh[l] * (bw[l] >> 1);
           if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
-            stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
+            stage_store(img + (l & 1) * kBuf, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
           const TapCore tc = tap_core_px(gx[l], gy[l], H, W);
-          const float* b0 = img + (l & 1) * kImgBufFloats;
+          const float* b0 = img + (l & 1) * kBuf;
           f32x2_t sv[2];
           if (__ballot(!tap_interior(tc, H, W)) == 0ull) {
             // wave-uniform: all corners inside the layer, every validity factor is exactly 1
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(kBlock, (LP <= 8 ? WALDO_FWD8_WAVES : (LP <= 12 ? (
           } else {
             const BoxTaps t = make_box_taps(tc, H, W);
             // inside the box by construction; the clamp only matters for NaN coordinates
-            const int idx = min(max(__mul24(t.yb - by0[l], bw[l]) + (t.xb - bx0[l]), 0), kStageCap - bw[l] - 2);
+            const int idx = min(max(__mul24(t.yb - by0[l], bw[l]) + (t.xb - bx0[l]), 0), kCap - bw[l] - 2);
             const PairBlock pb = assign_corners(read_block(b0, idx, bw[l]), t.cs, t.rs);
             // delta padding (lvd.py:548,559): shift the corner values before their validity
             const f32x2_t d2 = {delta, delta};

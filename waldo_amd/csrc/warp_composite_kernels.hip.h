@@ -403,6 +403,9 @@ static inline TileGeom tile_geom(int H, int W, int rows) {
 
 // inv_kernel / src_pts != nullptr (K3 == 19, staged shapes only: checked by the C-ABI entry point):
 // the mapping is computed inside the forward kernel and `mapping` is not read
+#ifndef WALDO_FWD_NW
+#define WALDO_FWD_NW 4
+#endif
 template <int LP, int K3P, bool EXK>
 static void launch_fwd(const float* layers, const float* basis_t, const float* mapping,
                        const float* inv_kernel, const float* src_pts,
@@ -418,11 +421,14 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
   if constexpr (EXK) {
     // LDS-staged sampling needs 16-byte-aligned rows and a 2x2 block inside the layer
     if (!debug_option(WALDO_DEBUG_FWD_PLAIN) && staged_eligible(H, W)) {
-      const int ntx16 = (W + kLdsTile - 1) / kLdsTile, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
+      // WALDO_FWD_NW: wavefronts per workgroup of the staged forward, 4 (16 x 16 tiles) or 8 (16 x 32; up to 12 layers)
+      constexpr int NW = (WALDO_FWD_NW == 8 && LP <= 12) ? 8 : 4;
+      constexpr int TW = kLdsTile * NW / 4;
+      const int ntx16 = (W + TW - 1) / TW, nt16 = ntx16 * ((H + kLdsTile - 1) / kLdsTile);
       dim3 grid16((unsigned)xcd_grid_banded(nchunks, nbands, nt16, 1));
       auto go = [&](auto exl, auto fold) {
         constexpr bool EXL = decltype(exl)::value, FOLD = decltype(fold)::value;
-        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, EXL, FOLD>), grid16, dim3(kBlock), 0, st, layers,
+        hipLaunchKernelGGL((warp_composite_fwd_lds_kernel<LP, EXL, FOLD, NW>), grid16, dim3(NW * kWave), 0, st, layers,
                            basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, L, H, W, fpb, ntx16, nt16,
                            nchunks, nbands, delta);
       };
