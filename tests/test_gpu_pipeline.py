@@ -1,6 +1,7 @@
-"""GPU: the C4 recipe of waldo_amd/tools/pipeline.py (what ``bench.py --config C4 --pipeline`` times) runs
-end to end on one clip: shapes as Synthesizer.predict produces them (models/synthesizer.py:434-472),
-finite values, the context frames passed through untouched, and bitwise the same on a second run."""
+"""GPU: the C4 and C5 recipes of waldo_amd/tools/pipeline.py (what ``bench.py --config C4 / C5 --pipeline`` times) run
+end to end on one clip at their own sizes: shapes as Synthesizer.predict produces them (models/synthesizer.py:434-472),
+finite values, the context frames passed through untouched, bitwise the same on a second run, and -- the decode
+without autograd composites the context alphas straight into raw_output -- the same frames as the two-tensor path."""
 import pytest
 import torch
 
@@ -25,3 +26,44 @@ def test_c4_pipeline_one_clip(dev):
     alg = pipe.hd_algorithmic_bytes()
     assert {"waldo_flow_ctx_alpha_fwd", "waldo_flow_ctx_warp_raw_fwd", "waldo_frame_warp_fuse_raw_fwd",
             "waldo_wif_fuse_fwd"} <= set(alg) and all(v > 0 for v in alg.values())
+
+
+@pytest.mark.parametrize("motion", ["calibrated", "wild"])
+def test_c5_pipeline_one_clip(dev, motion):
+    """The Cityscapes recipe at its own size (512 x 1024, 12 layers, 14 frames, 4 contexts), both stand-in motions."""
+    from waldo_amd import functional as WF
+    from waldo_amd.tools.pipeline import RECIPES, Pipeline
+    pipe = Pipeline("C5", 1, dev, seed=5, motion=motion)
+    t, ctx = RECIPES["C5"][5], RECIPES["C5"][6]
+    out = pipe()
+    hd, wd = 512, 1024
+    for k in ("rec_vid", "inp_rec_vid", "pred_vid", "inp_pred_vid"):
+        assert out[k].shape == (1, t, 3, hd, wd), k
+    assert out["pred_flow"].shape == (1, ctx, t - ctx, 2, hd, wd)
+    assert out["rec_disocc"].shape == (1, t, 1, hd, wd) and out["pred_disocc"].shape == (1, t - ctx, 1, hd, wd)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    assert torch.equal(out["inp_pred_vid"][:, :ctx], pipe.vid[:, :ctx])
+    assert out["inp_rec_vid"].std() > 0.05  # not a blank frame
+    again = pipe()
+    for k in ("inp_pred_vid", "inp_rec_vid", "pred_flow", "rec_disocc"):
+        assert torch.equal(out[k], again[k]), k
+    # the same predict with the raw-slot short cut switched off (alpha_ctx in a tensor of its own, read and copied by
+    # the frame warp): bit for bit the same products
+    into_raw = WF.flow_ctx_warp_into_raw
+    calls = []
+
+    def two_tensor_path(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self, layer_max=False):
+        calls.append(1)
+        res = WF.flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=layer_max)
+        b, tc, tp = ctx_ts.shape
+        return (res[0], res[1].view(b, tc, tp, *res[1].shape[1:])) + tuple(res[2:])
+
+    WF.flow_ctx_warp_into_raw = two_tensor_path
+    try:
+        plain = pipe()
+    finally:
+        WF.flow_ctx_warp_into_raw = into_raw
+    assert len(calls) == 2  # reconstruction and prediction both went the long way
+    for k in out:
+        assert torch.equal(out[k], plain[k]), k

@@ -384,6 +384,56 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
         assert gone > 0.5, gone
 
 
+@pytest.mark.parametrize("poison", ["none", "occ", "dist", "logits", "alpha"])
+def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
+    """The same short cuts in flow_ctx_alpha_kernel (layers whose upsampled alpha is 0 in all 64 lanes skip their
+    filter weight and leave the occlusion product) against the spelled-out expression of lvd.py:731-766, with most
+    objects absent from most wavefronts, and with a NaN / inf in the order, the class distributions, the layout
+    logits or the rough alphas."""
+    import torch.nn.functional as F
+    from waldo_amd import functional as WF
+    b, t, tw, nl, ncls, h, w, s = 2, 3, 2, 12, 20, 16, 32, 4
+    hd, wd = h * s, w * s
+    g = torch.Generator(device=dev).manual_seed(33)
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    cy = torch.rand(b * tw, nl, 1, 1, generator=g, device=dev) * h
+    cx = torch.rand(b * tw, nl, 1, 1, generator=g, device=dev) * w
+    alpha_lr = torch.rand(b * tw, nl, h, w, generator=g, device=dev) * (((yy - cy) ** 2 + (xx - cx) ** 2) < 16).float()
+    alpha_lr[:, 0] = 1.0                                                    # the background is everywhere
+    inp = torch.randn(b, t, 3 + ncls, hd, wd, generator=g, device=dev) * 2
+    dist = torch.rand(b, nl - 1, ncls, generator=g, device=dev).softmax(dim=2)
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    if poison == "occ":
+        occ[0, 1, 4, 2] = float("nan")
+        occ[1, 0, 0, 7] = float("inf")
+    elif poison == "dist":
+        dist[0, 5, 3] = float("nan")
+    elif poison == "logits":
+        inp[1, 1, 3 + 4, 10:20, 30:50] = float("nan")
+        inp[0, 0, 3 + 1, 5, 5] = float("inf")
+    elif poison == "alpha":
+        alpha_lr[1, 6, 3, 4] = float("nan")
+    with torch.no_grad():
+        a01, alpha = WF.flow_ctx_alpha(alpha_lr, inp, dist, occ, tw, 3, s)
+        a = F.interpolate(alpha_lr, scale_factor=s, mode="bilinear")                        # B*Tw L Hd Wd
+        prob = inp[:, :tw, 3:].softmax(dim=2).reshape(b * tw, 1, ncls, hd, wd)
+        d = dist.view(b, 1, nl - 1, ncls, 1, 1).expand(-1, tw, -1, -1, -1, -1).reshape(b * tw, nl - 1, ncls, 1, 1)
+        wgt = 1 - (d - prob).abs().sum(dim=2) / 2
+        a = torch.cat([a[:, :1], a[:, 1:] * wgt], dim=1)
+        oc = occ[:, :tw].reshape(b * tw, nl, nl)
+        prod = torch.ones_like(a)
+        for i in range(nl):
+            prod = prod * (1 - a[:, i:i + 1] * oc[:, i].view(b * tw, nl, 1, 1))
+        ref = a * prod
+    for x, y, name in ((a01, ref, "a01"), (alpha, ref * 2 - 1, "alpha")):
+        assert torch.equal(torch.isnan(x), torch.isnan(y)), f"{poison}: NaNs of {name} differ"
+        fin = torch.isfinite(y)
+        assert torch.equal(torch.isinf(x[~torch.isnan(y)]), torch.isinf(y[~torch.isnan(y)])), f"{poison}: infinities of {name}"
+        close(x[fin], y[fin], what=f"{poison}: {name}")
+    if poison == "none":
+        assert (a01 == 0).float().mean().item() > 0.5
+
+
 @pytest.mark.parametrize("over,ctx_only,include_self", [
     (dict(num_obj=3, dim=16, load_dim=0), False, True),                       # the LVD recipe's shape: x1, ctx "prev"
     (dict(num_obj=16, obj_shape=[2, 2], dim=8, load_dim=32), True, False),   # L = 17, x4, ghost mask

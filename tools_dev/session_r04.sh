@@ -1,0 +1,18 @@
+#!/bin/bash
+# dev: everything round 4 commits under profiles/ (run on the GPU box):  bash tools_dev/session_r04.sh
+cd $GRAFT_REPO_ROOT
+bash tools_dev/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1
+for c in C2 C4 C5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/r04_bench_$c.json 2> gpurun_out/err_$c.txt; done
+python bench.py --config C5 --pipeline --steps 8 --warmup 2 > gpurun_out/r04_bench_C5_pipeline.json 2> gpurun_out/err_p5.txt
+python bench.py --config C5 --pipeline --steps 8 --warmup 2 --motion wild > gpurun_out/r04_bench_C5_pipeline_wild.json 2> gpurun_out/err_p5w.txt
+python bench.py --config C4 --pipeline --steps 8 --warmup 2 > gpurun_out/r04_bench_C4_pipeline.json 2> gpurun_out/err_p4.txt
+python bench.py --config C4 --pipeline --steps 8 --warmup 2 --motion wild > gpurun_out/r04_bench_C4_pipeline_wild.json 2> gpurun_out/err_p4w.txt
+python bench.py --config LVD --steps 40 > gpurun_out/r04_bench_LVD.json 2> gpurun_out/err_lvd.txt
+bash tools_dev/pmc_any.sh r04_C5 bench.py --config C5 --pipeline --steps 2 --warmup 1 > gpurun_out/r04_pipeline_C5_counters.txt 2>&1
+bash tools_dev/pmc_any.sh r04_C5w bench.py --config C5 --pipeline --steps 2 --warmup 1 --motion wild > gpurun_out/r04_pipeline_C5_wild_counters.txt 2>&1
+bash tools_dev/pmc_any.sh r04_LVD bench.py --config LVD --steps 10 --warmup 2 > gpurun_out/r04_lvd_step_counters.txt 2>&1
+cp gpurun_out/pmc_r04_C5/stats/*/*kernel_stats.csv gpurun_out/r04_pipeline_C5_kernel_stats.csv
+cp gpurun_out/pmc_r04_LVD/stats/*/*kernel_stats.csv gpurun_out/r04_lvd_step_kernel_stats.csv
+[ -x tools_dev/r3_stream ] || hipcc --offload-arch=gfx950 -O3 -o tools_dev/r3_stream tools_dev/r3_stream.hip
+./tools_dev/r3_stream > gpurun_out/r04_micro_stream.txt 2>&1
+echo done

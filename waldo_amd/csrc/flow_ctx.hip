@@ -27,6 +27,18 @@
 
 namespace waldo {
 
+#ifndef WALDO_FCW_SPARSE
+#define WALDO_FCW_SPARSE 1  // wave-uniform skipping of absent layers (flow_ctx_warp_kernel); 0: every layer, every factor
+#endif
+#ifndef WALDO_FCW_MASK_FIRST
+#define WALDO_FCW_MASK_FIRST 1  // 0: whole records of every layer; 1: a layer's mask first, its flow record if wanted;
+                                // 2: the masks of ALL layers up front (one LDS round trip), records of wanted layers.
+                                // C5 pipeline, A/B on one box (tools_dev/ab_pipeline.sh): 7.67 / 7.55 / 7.80 ms per step
+#endif
+#ifndef WALDO_FCW_CONST_OUT
+#define WALDO_FCW_CONST_OUT 0   // 1: outputs of layers outside the active set as constants, behind a wave-uniform branch
+                                // -- measured SLOWER (8.1 against 7.6 ms: twelve more branches cut the store stream up)
+#endif
 template <int LP>
 __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
@@ -42,9 +54,11 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
   // the objects' class distributions of this batch entry: broadcast reads from LDS
   __shared__ __attribute__((aligned(16))) float sdist[(LP - 1) * kMaxCls];
   __shared__ __attribute__((aligned(16))) float occm[OccLds<LP>::kFloats];
-  if (dist != nullptr) dist_stage<LP>(sdist, dist + (int64_t)b * (L - 1) * Nl, L, Nl);
-  occ_stage<LP>(occm, occ + ((int64_t)b * T + t) * L * L, L);
-  __syncthreads();
+  bool tab_bad = false;
+  if (dist != nullptr) tab_bad = dist_stage<LP>(sdist, dist + (int64_t)b * (L - 1) * Nl, L, Nl);
+  tab_bad |= occ_stage<LP>(occm, occ + ((int64_t)b * T + t) * L * L, L);
+  // (the barrier doubles as the vote on non-finite entries of the two tables: see the short cuts below)
+  const bool dense = WALDO_FCW_SPARSE ? __syncthreads_or(tab_bad) != 0 : (__syncthreads(), true);
   if (x >= Wd || y >= Hd) return;
   const UpTaps ut = up_taps(y, x, 1.0f / (float)scale, H, W);
 
@@ -52,6 +66,20 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 #pragma unroll
   for (int l = 0; l < LP; ++l)
     a[l] = (l < L) ? up_sample(alpha_lr + ((int64_t)n * L + min(l, L - 1)) * HW, ut) : 0.0f;
+  // The wavefront's ACTIVE layers: those whose upsampled alpha is non-zero in some lane (an object's rough alpha is
+  // exactly 0 outside its canvas: grid_sample's zeros padding, lvd.py:727).  A layer outside the set keeps alpha 0
+  // through the filter (0 * weight) and the product (factor 1 - 0 * occ = 1, result 0 * product): its filter weight
+  // and its row and column of the product are skipped.  Exact while the operands are finite; a non-finite alpha in
+  // any lane, non-finite layout logits in any lane or a non-finite entry of the order / the class distributions
+  // (`dense`) switches back to every layer.
+  unsigned active = 0;
+  bool wild = false;
+#pragma unroll
+  for (int l = 0; l < LP; ++l) {
+    if (__ballot(a[l] != 0.0f) != 0ull) active |= 1u << l;
+    wild |= __ballot(!(fabsf(a[l]) <= 3.0e38f)) != 0ull;
+  }
+  if (!WALDO_FCW_SPARSE || dense || wild) active = LP >= 32 ? 0xffffffffu : (1u << LP) - 1u;
 
   if (dist != nullptr) {
     // softmax over the Nl layout logits of this pixel (held in registers)
@@ -71,8 +99,12 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
     }
 #pragma unroll
     for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
+    // (non-finite logits make every filter weight NaN, and 0 * NaN is NaN: no short cuts then)
+    if (__ballot(!(den >= 1.0f && den <= 3.0e38f)) != 0ull) active = LP >= 32 ? 0xffffffffu : (1u << LP) - 1u;
 #pragma unroll
-    for (int l = 1; l < LP; ++l) a[l] *= 1.0f - dist_l1(sdist + (l - 1) * kMaxCls, pr, Nl) / 2.0f;  // padding: 0 stays 0
+    for (int l = 1; l < LP; ++l)
+      if (active & (1u << l))  // wave-uniform
+        a[l] *= 1.0f - dist_l1(sdist + (l - 1) * kMaxCls, pr, Nl) / 2.0f;  // padding: 0 stays 0
   }
 
   // padding layers carry alpha 0 (factor exactly 1); branch-free so that the arrays stay in registers.
@@ -81,14 +113,17 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 #pragma unroll
   for (int j = 0; j < LP; j += 4) {
     f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+    if ((active >> j) & 0xfu) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
-      const f32x4_o o = occ_quad<LP, false>(occm, i, j);
-      const f32x2_w ai = {a[i], a[i]};
-      const f32x2_w one = {1.0f, 1.0f};  // 1 - a o in one rounding (v_pk_fma_f32)
-      prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
-      if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not all LP
+      for (int i = 0; i < LP; ++i) {
+        if (active & (1u << i)) {  // wave-uniform
+          const f32x4_o o = occ_quad<LP, false>(occm, i, j);
+          const f32x2_w ai = {a[i], a[i]};
+          const f32x2_w one = {1.0f, 1.0f};  // 1 - a o in one rounding (v_pk_fma_f32)
+          prd[0] = prd[0] * __builtin_elementwise_fma(-ai, (f32x2_w){o[0], o[1]}, one);
+          if (j + 2 < LP) prd[1] = prd[1] * __builtin_elementwise_fma(-ai, (f32x2_w){o[2], o[3]}, one);
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -108,18 +143,6 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 // the padding layers filled with those of layer L - 1.  A tap of a layer is then ONE ds_read_b128 at a
 // compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
 // ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
-#ifndef WALDO_FCW_SPARSE
-#define WALDO_FCW_SPARSE 1  // wave-uniform skipping of absent layers (flow_ctx_warp_kernel); 0: every layer, every factor
-#endif
-#ifndef WALDO_FCW_MASK_FIRST
-#define WALDO_FCW_MASK_FIRST 1  // 0: whole records of every layer; 1: a layer's mask first, its flow record if wanted;
-                                // 2: the masks of ALL layers up front (one LDS round trip), records of wanted layers.
-                                // C5 pipeline, A/B on one box (tools_dev/ab_pipeline.sh): 7.67 / 7.55 / 7.80 ms per step
-#endif
-#ifndef WALDO_FCW_CONST_OUT
-#define WALDO_FCW_CONST_OUT 0   // 1: outputs of layers outside the active set as constants, behind a wave-uniform branch
-                                // -- measured SLOWER (8.1 against 7.6 ms: twelve more branches cut the store stream up)
-#endif
 #ifndef WALDO_FCW_CHUNK
 #define WALDO_FCW_CHUNK 4  // 4: 116 registers at L = 12 (four waves per SIMD) and 1.92 ms at the C5 size; 6: 140 and 2.04 ms
 #endif
@@ -407,6 +430,9 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 
 #ifndef WALDO_FWF_TILE_COLS
 #define WALDO_FWF_TILE_COLS 32  // workgroup tile = 8 rows x 32 columns (HdTile); measured below
+#endif
+#ifndef WALDO_FWF_BANDS
+#define WALDO_FWF_BANDS 8
 #endif
 #ifndef WALDO_FWF_NT
 #define WALDO_FWF_NT 1  // non-temporal stores for out / raw (read next by another kernel, far larger than any cache): -3.5 %
@@ -716,7 +742,12 @@ static int frame_warp_fuse_launch(const char* fn, const float* input, const floa
     return WALDO_EINVAL;
   }
   const int64_t units = (int64_t)B * Tp;
-  const HdGeom geom = HdTile<WALDO_FWF_TILE_COLS>::geom(units, Hd, Wd);
+  HdGeom geom = HdTile<WALDO_FWF_TILE_COLS>::geom(units, Hd, Wd);
+  // Every unit's tiles in 8 bands, one per XCD: the whole chip walks the (b, tp) units IN ORDER instead of eight
+  // units side by side, so the Tp units of a clip, which gather from the same Tc context frames, follow each other
+  // closely (the frames of one clip, 193 MB at the Cityscapes recipe, are what the 256 MiB Infinity Cache can hold).
+  // A/B on one box: 10.94 -> 10.59 ms per C5 pipeline step (-3 %).
+  geom.nbands = WALDO_FWF_BANDS;
   if (hd_grid(units, geom) > 2147483647) {
     set_error("%s: problem too large for one launch", fn);
     return WALDO_EINVAL;

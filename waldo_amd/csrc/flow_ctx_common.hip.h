@@ -101,13 +101,18 @@ typedef float f32x4_o __attribute__((ext_vector_type(4)));
 // (row l - 1 = object min(l, L - 1) - 1; zeros from class Nl on, and everywhere when there is no object), so
 // that a layer's row sits at a compile-time address and is read four classes at a time -- it was a branch, a
 // ds_read_b32 and a wait per (layer, class).  Block-wide; no barrier inside.
+// Returns whether THIS thread saw a non-finite value (see occ_stage).
 template <int LP>
-__device__ __forceinline__ void dist_stage(float* sdist, const float* __restrict__ dist_b, int L, int Nl) {
+__device__ __forceinline__ bool dist_stage(float* sdist, const float* __restrict__ dist_b, int L, int Nl) {
   const int No = L - 1;
+  bool bad = false;
   for (int e = threadIdx.x; e < (LP - 1) * kMaxCls; e += kBlock) {
     const int r = e / kMaxCls, c = e - r * kMaxCls;
-    sdist[e] = (c < Nl && No > 0) ? dist_b[min(r, No - 1) * Nl + c] : 0.0f;
+    const float v = (c < Nl && No > 0) ? dist_b[min(r, No - 1) * Nl + c] : 0.0f;
+    bad |= !(fabsf(v) <= 3.0e38f);
+    sdist[e] = v;
   }
+  return bad;
 }
 
 // sum_c |dist[row][c] - pr[c]| over the Nl classes in ascending order (pr[c] == 0 from class Nl on: the
