@@ -117,6 +117,9 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 #pragma unroll
       for (int i = 0; i < LP; ++i) {
         if (active & (1u << i)) {  // wave-uniform
+          // (a REAL branch: left alone hipcc if-converts the four packed operations into selects of the factor 1 and
+          // evaluates all L x L factors again; an asm statement cannot be executed speculatively)
+          asm volatile("");
           const f32x4_o o = occ_quad<LP, false>(occm, i, j);
           const f32x2_w ai = {a[i], a[i]};
           const f32x2_w one = {1.0f, 1.0f};  // 1 - a o in one rounding (v_pk_fma_f32)
@@ -143,6 +146,10 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 // the padding layers filled with those of layer L - 1.  A tap of a layer is then ONE ds_read_b128 at a
 // compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
 // ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
+#ifndef WALDO_FCW_ROWS
+#define WALDO_FCW_ROWS 4  // pixels per thread of flow_ctx_warp_kernel at scale >= 2 (tile = 4 WALDO_FCW_ROWS x 64 pixels)
+#endif
+constexpr int kFcwRows = WALDO_FCW_ROWS;
 #ifndef WALDO_FCW_CHUNK
 #define WALDO_FCW_CHUNK 4  // 4: 116 registers at L = 12 (four waves per SIMD) and 1.92 ms at the C5 size; 6: 140 and 2.04 ms
 #endif
@@ -167,8 +174,13 @@ __device__ __forceinline__ float nan_max(float a, float b) { return __builtin_el
 
 // SCORE: also write score[m] = sum_l (alpha_ctx_l + 1) / 2, summed as frame_warp_fuse sums it from the stored
 // values (lvd.py:841) -- the frame warp then reads ONE plane per context instead of L.
-template <int LP, bool SCORE>
-__global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
+// R: pixels per thread, kHdRows rows apart (tall tiles, hd_pixel_rows): the tile's staging -- the order (2 L^2 LDS
+// entries), the low-resolution patch (one record per cell and layer: three global loads each) and the barrier -- was
+// paid per 256 pixels; timing-only ablations put everything but the gathers, the product and the stores at 5 of the
+// kernel's 7.8 ms per C5 pipeline step.  With R = 4 a 16 x 64 tile stages 6 x 18 cells where four 4 x 64 tiles staged
+// 4 x (3 x 18).
+template <int LP, bool SCORE, int R>
+__global__ __launch_bounds__(kBlock, (R > 1 && LP <= 17) ? 4 : 1) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
@@ -179,8 +191,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
-  int m, x, y;  // m = (b, tc, tp)
-  if (!hd_pixel(units, Hd, Wd, tiles, nbands, m, x, y)) return;
+  int m, x, y_first;  // m = (b, tc, tp)
+  if (!hd_pixel_rows<R>(units, Hd, Wd, tiles, nbands, m, x, y_first)) return;
   const int tp = m % Tp, b = m / (Tc * Tp);
   const float rscale = 1.0f / (float)scale;
   // frame of the context alpha (clamped: the index comes from device memory) and of the order
@@ -196,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   const bool occ_bad = occ_stage<LP>(occm, occ + ((int64_t)b * T + tpred) * L * L, L);
   // ---- the tile's patch of the low-resolution planes (2 L flow planes, L - 1 object masks)
   const int nob = isobj_lr != nullptr ? L - 1 : 0;
-  LrPatch lq = lr_patch(y - (int)(threadIdx.x >> 6), x - (int)(threadIdx.x & (kWave - 1)), Hd, Wd, rscale, H, W);
+  LrPatch lq = lr_patch(y_first - (int)(threadIdx.x >> 6), x - (int)(threadIdx.x & (kWave - 1)), Hd, Wd, rscale, H, W,
+                        kHdRows * R);
   lq.r_lo = __builtin_amdgcn_readfirstlane(lq.r_lo);  // the same in every thread of the workgroup
   lq.c_lo = __builtin_amdgcn_readfirstlane(lq.c_lo);
   lq.nrows = __builtin_amdgcn_readfirstlane(lq.nrows);
@@ -226,7 +239,11 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   // (the barrier doubles as the vote: a non-finite entry anywhere in the order or in the tile's low-resolution flows
   // switches the skipping below off; a tile whose patch is not staged is not examined: dense)
   const bool dense = WALDO_FCW_SPARSE ? (__syncthreads_or(occ_bad | flow_bad | !staged) != 0) : (__syncthreads(), true);
-  if (x >= Wd || y >= Hd) return;
+  if (x >= Wd) return;
+#pragma unroll 1
+  for (int rr = 0; rr < R; ++rr) {
+  const int y = y_first + kHdRows * rr;
+  if (y >= Hd) break;
   const int64_t p = (int64_t)y * Wd + x;
   const UpTaps ut = up_taps(y, x, rscale, H, W);
   LrTaps lt = lr_taps(y, x, rscale, H, W, lq);
@@ -375,6 +392,9 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
 #pragma unroll
       for (int i = 0; i < LP; ++i) {
         if (active & (1u << i)) {  // wave-uniform
+          // (a REAL branch: left alone hipcc if-converts the four packed operations into selects of the factor 1 and
+          // evaluates all L x L factors again; an asm statement cannot be executed speculatively)
+          asm volatile("");
           const f32x4_o o = occ_quad<LP, false>(occm, i, j);
           const f32x2_w ai = {a[i], a[i]};
           // 1 - a o in one rounding (v_pk_fma_f32): four packed operations per row instead of six
@@ -415,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_warp_kernel(
   flow[((int64_t)m * 2 + 1) * HWd + p] = oy;
   if (alpha_max != nullptr) alpha_max[(int64_t)m * HWd + p] = amax;
   if (SCORE) score[(int64_t)m * HWd + p] = ssum;
+  }  // rows of this thread
 }
 
 // A10: Warper.input_to_output (models/nets/lvd.py:830-853), forward: warp of the context frames by
@@ -656,16 +677,19 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   return launch_status("waldo_flow_ctx_alpha_fwd");
 }
 
-#define WALDO_FCW_CASE(LPV)                                                                                   \
-  case LPV:                                                                                                  \
-    if (score != nullptr)                                                                                    \
-      hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, true>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,  \
-                         flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc,  \
-                         alpha_max, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands);         \
-    else                                                                                                     \
-      hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, false>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st, \
-                         flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc,  \
-                         alpha_max, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands);         \
+#define WALDO_FCW_LAUNCH(LPV, SC, RV)                                                                          \
+  hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,    \
+                     flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc, alpha_max, \
+                     T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
+#define WALDO_FCW_CASE(LPV)                                        \
+  case LPV:                                                       \
+    if (rows == 1) {                                              \
+      if (score != nullptr) WALDO_FCW_LAUNCH(LPV, true, 1);       \
+      else WALDO_FCW_LAUNCH(LPV, false, 1);                       \
+    } else {                                                      \
+      if (score != nullptr) WALDO_FCW_LAUNCH(LPV, true, kFcwRows); \
+      else WALDO_FCW_LAUNCH(LPV, false, kFcwRows);                \
+    }                                                             \
     break;
 
 static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const float* isobj_lr, const float* a01,
@@ -686,7 +710,10 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const HdGeom geom = hd_geom(N, H * scale, W * scale);
+  // tall tiles where the low-resolution patch is staged (an upsampling by 2 or more); at scale 1 (no patch) the
+  // 4 x 64 tile of the other kernels
+  const int rows = scale >= 2 ? kFcwRows : 1;
+  const HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
   switch (flow_ctx_pad_l(L)) {
     WALDO_FCW_CASE(4)
     WALDO_FCW_CASE(8)

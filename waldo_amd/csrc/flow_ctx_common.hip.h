@@ -185,6 +185,26 @@ __device__ __forceinline__ bool hd_pixel(int units, int Hd, int Wd, int tiles, i
   return true;
 }
 
+// Tall tiles: a workgroup covers R x kHdRows rows of 64 columns, every thread R pixels kHdRows rows apart (flow_ctx_warp:
+// what a tile stages and computes once -- the order, the low-resolution patch, the per-pixel column constants -- is
+// shared by R times the pixels).  y is the thread's FIRST row; its others are y + kHdRows * r.
+inline HdGeom hd_geom_rows(int64_t units, int Hd, int Wd, int R) {
+  HdGeom g;
+  g.tiles = ((Hd + kHdRows * R - 1) / (kHdRows * R)) * ((Wd + kHdCols - 1) / kHdCols);
+  g.nbands = xcd_bands((int)(units % 8 == 0 ? 8 : units % 8));
+  return g;
+}
+template <int R>
+__device__ __forceinline__ bool hd_pixel_rows(int units, int Hd, int Wd, int tiles, int nbands, int& unit, int& x, int& y) {
+  int tile, rest_;
+  if (!xcd_decode_banded(blockIdx.x, units, nbands, tiles, 1, unit, tile, rest_)) return false;
+  const int ntx = (Wd + kHdCols - 1) / kHdCols;
+  const int ty = tile / ntx;
+  x = (tile - ty * ntx) * kHdCols + (int)(threadIdx.x & (kWave - 1));
+  y = ty * (kHdRows * R) + (int)(threadIdx.x >> 6);
+  return true;
+}
+
 // The same with a workgroup of (256 / TC) x TC pixels, a wavefront covering 64 / TC rows of TC columns
 // (frame_warp_fuse: WALDO_FWF_TILE_COLS).
 template <int TC>
@@ -224,11 +244,12 @@ struct LrPatch {
   int r_lo, c_lo, nrows, ncols;
 };
 
-__device__ __forceinline__ LrPatch lr_patch(int ty0, int tx0, int Hd, int Wd, float rscale, int H, int W) {
+__device__ __forceinline__ LrPatch lr_patch(int ty0, int tx0, int Hd, int Wd, float rscale, int H, int W,
+                                            int tile_rows = kHdRows) {
   LrPatch q;
   q.r_lo = up_tap(ty0, rscale, H).i0;
   q.c_lo = up_tap(tx0, rscale, W).i0;
-  q.nrows = up_tap(min(ty0 + kHdRows - 1, Hd - 1), rscale, H).i1 - q.r_lo + 1;
+  q.nrows = up_tap(min(ty0 + tile_rows - 1, Hd - 1), rscale, H).i1 - q.r_lo + 1;
   q.ncols = up_tap(min(tx0 + kHdCols - 1, Wd - 1), rscale, W).i1 - q.c_lo + 1;
   return q;
 }
