@@ -414,9 +414,15 @@ def main():
             many(*many.inputs)
         fence()
         many_us = (time.perf_counter() - t0) / n * 1e6
+        kernel_us = (many_us - floor_us) / reps_in_graph
+        alg_fwd = (16 * nl + 12) * h * w * frames
         launch_split = {"replay_us": round(elapsed / args.steps * 1e6, 2),
                         "empty_graph_replay_us": round(floor_us, 2),
-                        "kernel_us": round((many_us - floor_us) / reps_in_graph, 2),
+                        "kernel_us": round(kernel_us, 2),
+                        # the roofline fraction on either clock: a whole replay (what `roofline.frac` uses) and the
+                        # kernel without the per-replay launch floor
+                        "frac_replay": round(alg_fwd / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                        "frac_kernel": round(alg_fwd / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "note": f"empty graph = one 64-element add; kernel_us = (replay of a graph of {reps_in_graph} "
                                 "forwards - empty-graph replay) / 16: the forward kernel with its in-graph dependency "
                                 "boundary, without the per-replay launch floor"}

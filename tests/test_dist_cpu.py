@@ -73,3 +73,28 @@ def test_all_gather_frames_world2_gloo(frames):
     assert all(ok for _, ok, _, _ in res), res
     assert sum(n for _, _, n, _ in res) == frames
     assert all(tmax == 2.0 for *_, tmax in res)
+
+
+def test_bench_spawns_one_process_per_rank_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls `--gpus 1`): bench.py starts
+    `python -m torch.distributed.run` as a child.  On this CPU-only box every rank then stops with "needs a GPU"
+    (the HIP path has no CPU fallback) -- which is exactly what shows that two ranks were started with the rank
+    environment set, and that the parent hands the launcher's failure on instead of exiting 2 on a world-size
+    mismatch as it did before."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_gpu_dist.py::test_bench_starts_its_own_ranks runs the real thing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode not in (0, 2), (r.returncode, r.stderr[-500:])
+    assert r.stderr.count("needs a GPU") >= 2, r.stderr[-1500:]
+
+
+def test_cpu_budget_is_within_the_affinity_mask():
+    import bench
+    n = bench.cpu_budget()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
