@@ -335,9 +335,10 @@ def main():
         layers.requires_grad_()
         pts.requires_grad_()
 
-    from waldo_amd.dist import all_gather_frames
+    from waldo_amd.dist import all_gather_frames_async
 
     graphed = None
+    pending = [None]  # the previous step's all-gather, still in flight while this step computes
     if mode == "fwd":  # launch-bound shapes: the call sequence replayed from one HIP graph
         graphed = GraphedCall(lambda l, p, o: WF.warp_composite(l, p, o, tps.inverse_kernel, tps.basis_t),
                               layers, pts, occ)
@@ -350,7 +351,9 @@ def main():
         if mode == "infer":
             with torch.no_grad():
                 rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
-                all_gather_frames(rgb, frames * world)
+                prev, pending[0] = pending[0], all_gather_frames_async(rgb, frames * world)
+                if prev is not None:
+                    prev.wait()
             return
         layers.grad = None
         pts.grad = None
@@ -358,6 +361,9 @@ def main():
         (loss or _SquareMean.apply)(rgb).backward()
 
     def fence():
+        if pending[0] is not None:  # every gather started inside a timed region ends inside it
+            pending[0].wait()
+            pending[0] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -489,7 +495,8 @@ def main():
                                    f"{nl} layers x 4x{h}x{w}, 16 TPS control points, {what}",
                        "frames_per_gpu": frames, "layers": nl, "height": h, "width": w,
                        "parallelism": f"frames sharded x{world}, "
-                                      + ("one all-gather of the composited frames" if mode == "infer"
+                                      + ("one all-gather of the composited frames per step, overlapped with the next "
+                                         "step's kernels" if mode == "infer"
                                          else "no data-path collective")},
             "roofline": roof,
         }
@@ -587,16 +594,22 @@ def run_pipeline(args, clips, world, rank, device, dist):
     keeps `clips` whole clips (clips are independent: no data-path collective until the end), runs
     predict() on them and the ranks all-gather the inpainted predicted frames."""
     from waldo_amd import _lib
-    from waldo_amd.dist import all_gather_frames
+    from waldo_amd.dist import all_gather_frames_async
     from waldo_amd.tools.pipeline import Pipeline
     pipe = Pipeline(args.config, clips, device, seed=rank, motion=args.motion)
     t, hd, wd = pipe.frames, pipe.vid.shape[-2], pipe.vid.shape[-1]
+    pending = [None]  # the previous step's all-gather: over xGMI while this step's kernels run
 
     def step():
         out = pipe()["inp_pred_vid"]
-        return all_gather_frames(out.reshape(clips * t, 3, hd, wd), clips * t * world)
+        prev, pending[0] = pending[0], all_gather_frames_async(out.reshape(clips * t, 3, hd, wd), clips * t * world)
+        if prev is not None:
+            prev.wait()
 
     def fence():
+        if pending[0] is not None:  # every gather started inside the timed region ends inside it
+            pending[0].wait()
+            pending[0] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -643,7 +656,8 @@ def run_pipeline(args, clips, world, rank, device, dist):
                                    f"of the last {t - pipe.ctx_len}; networks outside the path replaced by seeded "
                                    f"stand-ins (UNet stand-in costs nothing), background motion '{pipe.motion}'",
                        "frames_per_gpu": clips * t, "layers": o.num_obj + 1, "height": hd, "width": wd,
-                       "parallelism": f"clips sharded x{world}, one all-gather of the inpainted predicted frames"},
+                       "parallelism": f"clips sharded x{world}, one all-gather of the inpainted predicted frames per step, "
+                                      f"overlapped with the next step's kernels"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
                          "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]},

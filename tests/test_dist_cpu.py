@@ -50,6 +50,13 @@ def _worker(rank, world, port, frames, q):
     (mine,) = shard_frames([full], frames, rank, world)
     out = all_gather_frames(mine.clone(), frames)
     ok = torch.equal(out, full)
+    # the overlapped form bench.py's inference steps use: two gathers in flight one after the other, each waited
+    # for a step late; same frames
+    from waldo_amd.dist import all_gather_frames_async
+    first = all_gather_frames_async(mine.clone(), frames)
+    second = all_gather_frames_async((mine + 100.0).clone(), frames)
+    ok = ok and torch.equal(first.wait(), full) and torch.equal(second.wait(), full + 100.0)
+    ok = ok and torch.equal(first.wait(), full)  # waiting twice is harmless
     # the barrier + max-over-ranks timing reduction bench.py uses
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -85,6 +85,45 @@ def all_gather_frames(local, frames, group=None, collective_for_one=False):
     return out[:frames]
 
 
+class PendingGather:
+    """An all-gather of composited frames in flight (``all_gather_frames_async``).  ``wait()`` makes the current
+    stream wait for it and returns the (frames, C, H, W) tensor.  Holds the buffers the collective reads and writes."""
+
+    def __init__(self, work, out, local, frames, device=None):
+        self.work, self.out, self.local, self.frames, self.device = work, out, local, frames, device
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        res = self.out[:self.frames]
+        return res.to(self.device) if self.device is not None else res
+
+
+def all_gather_frames_async(local, frames, group=None):
+    """``all_gather_frames`` without waiting: the collective runs on the communicator's own stream (RCCL) while the
+    caller launches the next frames' kernels; ``.wait()`` on the returned ``PendingGather`` before the result is read.
+    The frames of step i travel over xGMI while step i + 1 computes -- at the Cityscapes recipe 352 MB per rank
+    against a 28 ms step."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        assert local.shape[0] == frames
+        return PendingGather(None, local, local, frames)
+    world = dist.get_world_size(group)
+    per = (frames + world - 1) // world
+    if local.shape[0] > per:
+        raise ValueError("local block larger than ceil(frames / world)")
+    if local.shape[0] < per:
+        local = torch.cat([local, local.new_zeros(per - local.shape[0], *local.shape[1:])], dim=0)
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # (host staging: see all_gather_frames)
+        host = local.cpu().contiguous()
+        out = host.new_empty(world * per, *host.shape[1:])
+        return PendingGather(dist.all_gather_into_tensor(out, host, group=group, async_op=True), out, host, frames,
+                             device=local.device)
+    local = local.contiguous()
+    out = local.new_empty(world * per, *local.shape[1:])
+    return PendingGather(dist.all_gather_into_tensor(out, local, group=group, async_op=True), out, local, frames)
+
+
 def sharded_warp_composite(layers, src_pts, occ, inverse_kernel, basis_t, gather=True, delta=0.0):
     """Inference over all ranks: composite this rank's frames on its GPU (HIP kernels), then
     all-gather the RGB frames.  Inputs are the FULL (F, ...) tensors present on every rank (or
