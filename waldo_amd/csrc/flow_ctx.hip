@@ -710,9 +710,13 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  // tall tiles where the low-resolution patch is staged (an upsampling by 2 or more); at scale 1 (no patch) the
-  // 4 x 64 tile of the other kernels
-  const int rows = scale >= 2 ? kFcwRows : 1;
+  // tall tiles where the tall tile's low-resolution patch still fits the staged image (x4 at the Cityscapes recipe:
+  // 6 x 18 cells; at x2, the KITTI recipe, 10 x 34 cells do not fit 256 threads / the LDS image, and the unstaged path
+  // is far slower: 5.9 against 4.0 ms per C4 pipeline step); otherwise the 4 x 64 tile of the other kernels
+  const int lp = flow_ctx_pad_l(L);
+  const int cells = ((kHdRows * kFcwRows + scale - 1) / scale + 2) * ((kHdCols + scale - 1) / scale + 2);
+  const int cap = lp <= 12 ? 7168 : 8192, cell_floats = 4 * lp + 4;  // FcwLds<LP>::kCap / kCell
+  const int rows = (scale >= 2 && cells <= kBlock && cells * cell_floats <= cap) ? kFcwRows : 1;
   const HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
   switch (flow_ctx_pad_l(L)) {
     WALDO_FCW_CASE(4)
