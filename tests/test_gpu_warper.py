@@ -335,14 +335,16 @@ def _flow_ctx_warp_spelled_out(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s)
     return out_flow, actx * 2 - 1, dis
 
 
-@pytest.mark.parametrize("poison", ["none", "occ", "flow", "alpha"])
-def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
+@pytest.mark.parametrize("poison,hw", [("none", (32, 64)), ("occ", (32, 64)), ("flow", (32, 64)), ("alpha", (32, 64)),
+                                       ("none", (9, 20)), ("alpha", (9, 20))])  # 36 x 80: ragged 16 x 64 tiles
+def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison, hw):
     """The wavefront-level short cuts of flow_ctx_warp_kernel (a layer whose object mask is off in all 64 lanes is
     not sampled; layers with alpha 0 in all lanes leave the occlusion product): on a scene of SMALL objects --
     most layers absent from most wavefronts -- the results equal the spelled-out expression, and a NaN / inf in the
     order, in the low-resolution flows or in the context alphas lands exactly where the expression puts it."""
     from waldo_amd import functional as WF
-    b, t, tc, tp, nl, h, w, s, tw = 1, 3, 2, 2, 12, 32, 64, 4, 2
+    b, t, tc, tp, nl, s, tw = 1, 3, 2, 2, 12, 4, 2
+    h, w = hw
     hd, wd = h * s, w * s
     g = torch.Generator(device=dev).manual_seed(21)
     m = b * tc * tp
@@ -351,7 +353,7 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
     yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
     cy = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * h
     cx = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * w
-    isobj = (((yy - cy) ** 2 + (xx - cx) ** 2) < 36).float()
+    isobj = (((yy - cy) ** 2 + (xx - cx) ** 2) < (36 if h >= 32 else 9)).float()
     a01 = torch.rand(b * tw, nl, hd, wd, generator=g, device=dev)
     a01[:, 1:] *= (torch.rand(b * tw, nl - 1, hd, wd, generator=g, device=dev) > 0.5)   # exact zeros inside objects too
     occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
@@ -361,12 +363,12 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
         occ[0, 2, 3, 5] = float("nan")      # frame 2 is predicted frame 0: a NaN factor in column 5 of every pixel
         occ[0, 0, 7, 1] = float("inf")
     elif poison == "flow":
-        flow_lr[1, 4, 0, 10, 20] = float("nan")    # an object that is absent there: 0 * NaN all the same
+        flow_lr[1, 4, 0, h // 3, w // 3] = float("nan")    # an object that is absent there: 0 * NaN all the same
         flow_lr[2, 0, 1, 5, 5] = float("inf")
     elif poison == "alpha":
         # (NaN only: an INFINITE texel under a zero tap weight is NaN in the four-weight form of F.grid_sample and
         # may be finite in the lerp form of the kernels -- a difference of the sampling form, not of the skipping)
-        a01[0, 6, 40:60, 100:140] = float("nan")
+        a01[0, 6, hd // 3:hd // 2, wd // 3:wd // 2] = float("nan")
         a01[1, 0, 5, 7] = float("nan")
     with torch.no_grad():
         flow, actx, dis, amax = WF.flow_ctx_warp(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True)
@@ -381,7 +383,7 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison):
     if poison == "none":
         # absent layers come out as the exact constants
         gone = (actx == -1.0).float().mean().item()
-        assert gone > 0.5, gone
+        assert gone > 0.4, gone
 
 
 @pytest.mark.parametrize("poison", ["none", "occ", "dist", "logits", "alpha"])
