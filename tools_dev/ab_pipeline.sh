@@ -4,7 +4,7 @@
 entry=$1; shift
 for round in 1 2; do
   for lib in "$@"; do
-    python bench.py --config C5 --pipeline --steps 4 --warmup 2 --lib "$lib" 2>/dev/null | python -c "
+    python bench.py --config ${CFG:-C5} --pipeline --steps 4 --warmup 2 --lib "$lib" 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.readline())
 e = {k: v['ms_per_step'] for k, v in d['pipeline']['entry_points'].items() if '$entry' in k}

@@ -156,7 +156,8 @@ constexpr int kFcwRows = WALDO_FCW_ROWS;
 template <int LP>
 struct FcwLds {
   static constexpr int kCell = 4 * LP + 4;             // floats per cell (+ 4: cells of a row on different banks)
-  static constexpr int kCap = LP <= 12 ? 7168 : 8192;  // floats: 136 cells (x 2 upsampling) up to L = 12
+  static constexpr int kCap = LP <= 8 ? 7680 : (LP <= 12 ? 7168 : 8192);  // floats: 136 cells (4 x 64 tile at x 2) up to L = 12;
+                                                                          // L <= 8: 204 cells (8 x 64 tile at x 2)
 };
 
 // where the L planes of alpha_ctx[b, tc, tp] go: element strides of the three unit indices from `alpha_ctx` (the
@@ -686,6 +687,9 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
     if (rows == 1) {                                              \
       if (score != nullptr) WALDO_FCW_LAUNCH(LPV, true, 1);       \
       else WALDO_FCW_LAUNCH(LPV, false, 1);                       \
+    } else if (rows == 2) {                                       \
+      if (score != nullptr) WALDO_FCW_LAUNCH(LPV, true, 2);       \
+      else WALDO_FCW_LAUNCH(LPV, false, 2);                       \
     } else {                                                      \
       if (score != nullptr) WALDO_FCW_LAUNCH(LPV, true, kFcwRows); \
       else WALDO_FCW_LAUNCH(LPV, false, kFcwRows);                \
@@ -712,11 +716,15 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
   hipStream_t st = (hipStream_t)stream;
   // tall tiles where the tall tile's low-resolution patch still fits the staged image (x4 at the Cityscapes recipe:
   // 6 x 18 cells; at x2, the KITTI recipe, 10 x 34 cells do not fit 256 threads / the LDS image, and the unstaged path
-  // is far slower: 5.9 against 4.0 ms per C4 pipeline step); otherwise the 4 x 64 tile of the other kernels
+  // is far slower: 5.9 against 4.0 ms per C4 pipeline step) -- there two pixels per thread (6 x 34 cells) if that
+  // fits; otherwise the 4 x 64 tile of the other kernels
   const int lp = flow_ctx_pad_l(L);
-  const int cells = ((kHdRows * kFcwRows + scale - 1) / scale + 2) * ((kHdCols + scale - 1) / scale + 2);
-  const int cap = lp <= 12 ? 7168 : 8192, cell_floats = 4 * lp + 4;  // FcwLds<LP>::kCap / kCell
-  const int rows = (scale >= 2 && cells <= kBlock && cells * cell_floats <= cap) ? kFcwRows : 1;
+  const int cap = lp <= 8 ? 7680 : (lp <= 12 ? 7168 : 8192), cell_floats = 4 * lp + 4;  // FcwLds<LP>::kCap / kCell
+  auto fits = [&](int r) {
+    const int cells = ((kHdRows * r + scale - 1) / scale + 2) * ((kHdCols + scale - 1) / scale + 2);
+    return cells <= kBlock && cells * cell_floats <= cap;
+  };
+  const int rows = scale < 2 ? 1 : (fits(kFcwRows) ? kFcwRows : (fits(2) ? 2 : 1));
   const HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
   switch (flow_ctx_pad_l(L)) {
     WALDO_FCW_CASE(4)

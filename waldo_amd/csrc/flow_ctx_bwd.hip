@@ -320,10 +320,14 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_WARP_WAVES) void flow_ctx_warp_bw
               const float wx0 = 1.0f - t.fx, wy0 = 1.0f - t.fy;
               const float w00 = wx0 * wy0 * (t.vx0 * t.vy0), w01 = t.fx * wy0 * (t.vx1 * t.vy0);
               const float w10 = wx0 * t.fy * (t.vx0 * t.vy1), w11 = t.fx * t.fy * (t.vx1 * t.vy1);
+#ifndef WALDO_ABL_FCB_NOATOMIC  // timing-only ablation: without the scatter
               if (w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gsg * w00);
               if (w01 != 0.0f) atomicAdd(gp + (t.o01 >> 2), gsg * w01);
               if (w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gsg * w10);
               if (w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gsg * w11);
+#else
+              if (w00 + w01 + w10 + w11 == 123.0f) gp[0] = gsg;
+#endif
             }
           }
         }
