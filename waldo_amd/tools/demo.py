@@ -41,10 +41,20 @@ def demo_opt(dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20, **over):
 
 class UniformFusionUNet(nn.Module):
     """UNet stand-in: zero colour residual (channels 0-2), equal scores (channel 3) -- the fusion of
-    wif.py:49-54 then averages the warped context frames with their sigmoid(alpha + 5) weights."""
+    wif.py:49-54 then averages the warped context frames with their sigmoid(alpha + 5) weights.  The zeros are
+    made once per shape and handed out again (nobody writes to them): the stand-in for a network OUTSIDE the path
+    should not put half a millisecond of fills into the pipeline's timing."""
+
+    def __init__(self):
+        super().__init__()
+        self._zeros = {}
 
     def forward(self, x):
-        return x.new_zeros(x.shape[0], 4, *x.shape[-2:])
+        key = (x.shape[0], tuple(x.shape[-2:]), x.device, x.dtype)
+        z = self._zeros.get(key)
+        if z is None:
+            z = self._zeros[key] = x.new_zeros(x.shape[0], 4, *x.shape[-2:])
+        return z
 
 
 # Background motion of the stand-ins, as (drift of the 2 x 2 affine part, of the translation, of the per-point
