@@ -592,6 +592,7 @@ class _FlowCtxAlpha(torch.autograd.Function):
                       scale, _lib.current_stream(alpha_lr.device))
         ctx.save_for_backward(alpha_lr, input, dist, occ)
         ctx.cfg = (tw, chan_off, scale)
+        ctx.set_materialize_grads(False)  # backward below handles a missing gradient of either output
         return a01, out
 
     @staticmethod
@@ -602,6 +603,8 @@ class _FlowCtxAlpha(torch.autograd.Function):
         b, t, c, hd, wd = input.shape
         ncls = dist.shape[2] if dist is not None else 0
         # alpha_out = 2 a01 - 1
+        if g_a01 is None and g_out is None:
+            return None, None, None, None, None, None, None
         if g_a01 is None:
             g = 2.0 * g_out
         elif g_out is None:
@@ -661,6 +664,7 @@ class _FlowCtxWarp(torch.autograd.Function):
         ctx.save_for_backward(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ)
         ctx.cfg = (tw, scale)
         ctx.mark_non_differentiable(amax)
+        ctx.set_materialize_grads(False)  # unused outputs: None, not zero-filled tensors (the kernel takes NULL)
         return flow, alpha_ctx, disocc, amax
 
     @staticmethod
@@ -799,6 +803,9 @@ class _FrameWarpFuse(torch.autograd.Function):
                       1 if include_self else 0, float(eps), _lib.current_stream(input.device))
         ctx.save_for_backward(input, flow, alpha, ctx_ts)
         ctx.cfg = (bool(include_self), float(eps))
+        # an output the loss does not use comes back as None, not as a zero-filled tensor of its size (raw_output is
+        # the largest tensor of the chain; the kernel takes NULL for either gradient)
+        ctx.set_materialize_grads(False)
         return out, raw.permute(0, 2, 1, 3, 4, 5)
 
     @staticmethod

@@ -330,7 +330,8 @@ class Warper(nn.Module):
         s = int(self.scale_hd)
         tw = tc if ctx_only else t
         alpha = self.layer_to_output((obj_alpha + 1) / 2, (bg_alpha + 1) / 2, grid, delta_bg=0, delta_obj=0)
-        alpha = alpha[:, :tw]                                                   # B Tw L 1 H W
+        if tw < alpha.size(1):  # (a full-range slice still costs autograd a zero-filled buffer and a copy backward)
+            alpha = alpha[:, :tw]                                               # B Tw L 1 H W
         dist = None
         if ctx_only or not self.no_filter:
             if s >= 2 and s & (s - 1) == 0 and input.is_cuda and hd % s == 0 and wd % s == 0:
@@ -505,9 +506,11 @@ def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pr
     output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
     if hasattr(alpha_ctx, "_waldo_raw"):
         del alpha_ctx._waldo_raw  # the view goes to the caller as a plain tensor
-    raw_alpha = output[:, :, -1:]
+    # (ONE split instead of two slices of `output`: backward is a concatenation of the two gradients, where two
+    # SliceBackward nodes each zero-fill a buffer of the full size and autograd adds them)
+    output, raw_alpha = torch.split(output, [output.size(2) - 1, 1], dim=2)
     if use_disocc:
         if warper.include_self:
             disocc = torch.cat([disocc, torch.ones_like(disocc[:, :1])], dim=1)
         raw_output = torch.cat([raw_output, disocc], dim=3)
-    return output[:, :, :-1], flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx
+    return output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx
