@@ -67,3 +67,26 @@ def test_c5_pipeline_one_clip(dev, motion):
     assert len(calls) == 2  # reconstruction and prediction both went the long way
     for k in out:
         assert torch.equal(out[k], plain[k]), k
+
+
+def test_predict_replays_from_one_hip_graph(dev):
+    """The whole hot-path part of predict() -- producers, both Warper.forward calls, both decodes, both WIF fusions,
+    ~200 launches -- is capturable into ONE HIP graph (the library launches on the caller's stream and never
+    synchronises; the path's constant tensors live on the device; index validation is skipped during capture) and the
+    replay has the same bits as the eager call, also after the clip changes."""
+    from waldo_amd.graphs import GraphedCall
+    from waldo_amd.tools import demo
+    from waldo_amd.tools.pipeline import Pipeline, synthetic_clip
+    pipe = Pipeline("C4", 1, dev, seed=9)
+
+    def run(vid, lyt):
+        out = demo.predict(pipe.opt, pipe.warper, pipe.wif, vid, lyt, pipe.net, pipe.ctx_len)
+        return out["inp_pred_vid"], out["inp_rec_vid"], out["pred_flow"], out["pred_disocc"]
+
+    with torch.no_grad():
+        graphed = GraphedCall(run, pipe.vid, pipe.lyt)
+        other = synthetic_clip(pipe.opt, 1, pipe.frames, 10, dev)
+        for vid, lyt in ((pipe.vid, pipe.lyt), other, (pipe.vid, pipe.lyt)):
+            eager = run(vid, lyt)
+            for x, y in zip(graphed(vid, lyt), eager):
+                assert torch.equal(x, y)

@@ -102,8 +102,27 @@ def synthetic_network_outputs(opt, b, t, ctx_len, seed=0, device="cpu", motion="
     return {k: v.to(device) for k, v in out.items()}
 
 
+_CONSTANTS = {}
+
+
+def _cached(kind, opt, device, make):
+    """The path's constant tensors (the pose heads' buffers, the padding mask, the background alpha) live on the
+    device ONCE per option set, as a model's registered buffers do: made inside predict() they were ten small
+    host-to-device copies per call -- each one a point where the host stops queueing kernels -- and kept the call
+    from being captured into a HIP graph."""
+    key = (kind, str(device), tuple(opt.obj_shape), tuple(opt.latent_shape), opt.patch_size, opt.scale_factor,
+           opt.pad_obj_alpha, opt.dim, float(opt.aspect_ratio))
+    if key not in _CONSTANTS:
+        _CONSTANTS[key] = make()
+    return _CONSTANTS[key]
+
+
 def pose_buffers(opt, device):
     """Buffers of the pose heads (models/nets/flp.py:119-123) at the demo's option values."""
+    return _cached("pose", opt, device, lambda: _pose_buffers(opt, device))
+
+
+def _pose_buffers(opt, device):
     lo = opt.obj_shape[0] * opt.obj_shape[1]
     lb = opt.latent_shape[0] * opt.latent_shape[1]
     return dict(
@@ -116,6 +135,10 @@ def pose_buffers(opt, device):
 
 def obj_alpha_mask(opt, device):
     """lvd.py:27-34: zero border of ``pad_obj_alpha`` decoder pixels around the object canvas."""
+    return _cached("mask", opt, device, lambda: _obj_alpha_mask(opt, device))
+
+
+def _obj_alpha_mask(opt, device):
     ho = opt.obj_shape[0] * opt.patch_size * opt.scale_factor
     wo = opt.obj_shape[1] * opt.patch_size * opt.scale_factor
     po = opt.pad_obj_alpha * opt.scale_factor
@@ -140,7 +163,7 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     dev = real_vid.device
     buf = pose_buffers(opt, dev)
     mask = obj_alpha_mask(opt, dev)
-    bg_alpha = torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev)
+    bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
 
     def alpha_grid_occ(pred_obj_pose, pred_bg_pose, occ_score, nt):
         # pose heads' affine (flp.py:259-273), decoder tail (lvd.py:245-254), then
