@@ -190,8 +190,7 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     def disocc(alpha_ctx, mx):  # synthesizer.py:447-450
         if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the pass over alpha_ctx
             mx = alpha_ctx.amax(dim=3)
-        dmax, dmin = mx.amax(dim=1), mx.amin(dim=1)
-        dmax = dmax.clone()
+        dmin, dmax = torch.aminmax(mx, dim=1)  # (one pass for both reductions of synthesizer.py:447-448)
         dmax[dmax - dmin > 1] = 0
         return dmax.unsqueeze(2)
 
