@@ -131,6 +131,44 @@ def test_grid_sample_broadcast(dev):
     close(o2.grad, obj.grad, rel=True, what="grad_obj")
 
 
+@pytest.mark.parametrize("hwo", [(12, 10), (16, 32)])   # one pixel per thread / four (Ho * Wo % 4 == 0)
+def test_grid_sample_mask_by_product(dev, hwo):
+    """waldo_grid_sample2d_mask_fwd: the output is the plain call's, and the mask is grid_sample(ones, grid) -- the
+    warped all-ones canvas of Warper.grid_to_flow_ctx's ghost test (lvd.py:785-791) -- bit for bit; with the input
+    expanded over time, with the grid repeated over the contexts, and under autograd (the mask carries none)."""
+    from waldo_amd import functional as WF
+    b, t, no, c, ho, wo = 2, 3, 4, 2, 8, 8
+    h, w = hwo
+    torch.manual_seed(4)
+    obj = torch.randn(b * t * no, c, ho, wo, device=dev)
+    grid = (torch.rand(b * t * no, h, w, 2, device=dev) * 2.6 - 1.3)
+    ones = torch.ones(b * t * no, 1, ho, wo, device=dev)
+    with torch.no_grad():
+        out, mask = WF.grid_sample(obj, grid, delta=0.0, return_mask=True)
+        assert torch.equal(out, WF.grid_sample(obj, grid, delta=0.0))
+        assert torch.equal(mask, WF.grid_sample(ones, grid, delta=0.0))
+        assert 0.05 < (mask > 0.9).float().mean().item() < 0.95   # the grid leaves the canvas in places
+        # input shared over time
+        out, mask = WF.grid_sample(obj[:b * no], grid, delta=1.0, broadcast=(t * no, no), return_mask=True)
+        assert torch.equal(out, WF.grid_sample(obj[:b * no], grid, delta=1.0, broadcast=(t * no, no)))
+        assert torch.equal(mask, WF.grid_sample(ones, grid, delta=0.0))
+        # grid repeated over two contexts
+        rep = 2
+        big = torch.randn(b * rep * t * no, c, ho, wo, device=dev)
+        gr = (b * rep * t * no, rep * t * no, t * no)
+        out, mask = WF.grid_sample(big, grid, grid_repeat=gr, return_mask=True)
+        assert torch.equal(out, WF.grid_sample(big, grid, grid_repeat=gr))
+        assert torch.equal(mask, WF.grid_sample(torch.ones(b * rep * t * no, 1, ho, wo, device=dev), grid, grid_repeat=gr))
+    x, g = obj.clone().requires_grad_(), grid.clone().requires_grad_()
+    out, mask = WF.grid_sample(x, g, return_mask=True)
+    assert not mask.requires_grad
+    (out.square().sum() + mask.sum()).backward()
+    x2, g2 = obj.clone().requires_grad_(), grid.clone().requires_grad_()
+    WF.grid_sample(x2, g2).square().sum().backward()
+    assert torch.equal(g.grad, g2.grad)
+    close(x.grad, x2.grad, 1e-5, rel=True, what="grad_input (float atomics: order of additions)")
+
+
 def test_grid_sample_empty(dev):
     from waldo_amd import functional as WF
     out = WF.grid_sample(torch.zeros(0, 3, 4, 4, device=dev), torch.zeros(0, 5, 5, 2, device=dev))

@@ -12,15 +12,26 @@ __device__ __forceinline__ int64_t in_index(int64_t n, int64_t outer_div, int64_
   return (n / outer_div) * inner + (n % inner);
 }
 
+// The sample of an all-ones image at the same taps: tap_sample() on the constant 1 (the same operations on the
+// validity products: the bits grid_sample(ones, grid) gives).  Warper.grid_to_flow_ctx asks for it next to the layer
+// flows (`is_obj = obj_to_output(ones) > 0.9`, lvd.py:785-791): the same grids, so the mask is a by-product.
+__device__ __forceinline__ float tap_sample_ones(const Taps& t) {
+  const float v00 = t.vx0 * t.vy0, v01 = t.vx1 * t.vy0, v10 = t.vx0 * t.vy1, v11 = t.vx1 * t.vy1;
+  const float top = fmaf(t.fx, v01 - v00, v00);
+  const float bot = fmaf(t.fx, v11 - v10, v10);
+  return fmaf(t.fy, bot - top, top);
+}
+
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
-    int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta, int64_t outer_div,
-    int64_t inner, int64_t g_outer_div, int64_t g_inner) {
+    float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   if (p >= HWo) return;
   const float2 g = *reinterpret_cast<const float2*>(grid + (in_index(n, g_outer_div, g_inner) * HWo + p) * 2);
   const Taps t = make_taps(g.x, g.y, Hi, Wi);
+  if (mask_out != nullptr) mask_out[n * HWo + p] = tap_sample_ones(t);
   const int64_t HWi = (int64_t)Hi * Wi;
   const float* in = input + in_index(n, outer_div, inner) * C * HWi;
   float* out = output + n * C * HWo + p;
@@ -94,8 +105,8 @@ typedef float f32x4_gs __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
-    int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta, int64_t outer_div,
-    int64_t inner, int64_t g_outer_div, int64_t g_inner) {
+    float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = ((int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x) * 4;
   if (p >= HWo) return;
@@ -121,6 +132,12 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     for (int q = 0; q < 4; ++q) o[q] = tap_sample(in + (int64_t)c * HWi, t[q]) + shift[q];
     *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
   }
+  if (mask_out != nullptr) {
+    f32x4_gs o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = tap_sample_ones(t[q]);
+    *reinterpret_cast<f32x4_gs*>(mask_out + n * HWo + p) = o;
+  }
 }
 
 static int check_gs(const char* fn, int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
@@ -142,34 +159,53 @@ static int check_gs(const char* fn, int64_t N, int C, int Hi, int Wi, int Ho, in
 
 using namespace waldo;
 
-extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output,
-                                       int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
-                                       float delta, int64_t outer_div, int64_t inner,
-                                       int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
-  int rc = check_gs("waldo_grid_sample2d_fwd", N, C, Hi, Wi, Ho, Wo, outer_div, inner);
+static int grid_sample2d_fwd_launch(const char* fn, const float* input, const float* grid, float* output, float* mask_out,
+                                    int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta, int64_t outer_div,
+                                    int64_t inner, int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
+  int rc = check_gs(fn, N, C, Hi, Wi, Ho, Wo, outer_div, inner);
   if (rc) return rc;
   if (grid_outer_div < 1 || grid_inner < 1) {
-    set_error("waldo_grid_sample2d_fwd: bad grid broadcast (%lld, %lld)", (long long)grid_outer_div, (long long)grid_inner);
+    set_error("%s: bad grid broadcast (%lld, %lld)", fn, (long long)grid_outer_div, (long long)grid_inner);
     return WALDO_EINVAL;
   }
   if (N == 0) return WALDO_OK;
   if (!input || !grid || !output) {
-    set_error("waldo_grid_sample2d_fwd: null pointer");
+    set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
   }
   const int64_t HWo = (int64_t)Ho * Wo;
   if (HWo % 4 == 0) {
     const int tiles4 = (int)((HWo / 4 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(grid_sample2d_fwd4_kernel, dim3((unsigned)(N * tiles4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner, grid_outer_div,
-                       grid_inner);
-    return launch_status("waldo_grid_sample2d_fwd");
+                       (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner,
+                       grid_outer_div, grid_inner);
+    return launch_status(fn);
   }
   const int tiles = (int)((HWo + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(grid_sample2d_fwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
-                     (hipStream_t)stream, input, grid, output, N, C, Hi, Wi, HWo, tiles, delta,
+                     (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles, delta,
                      outer_div, inner, grid_outer_div, grid_inner);
-  return launch_status("waldo_grid_sample2d_fwd");
+  return launch_status(fn);
+}
+
+extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output,
+                                       int64_t N, int C, int Hi, int Wi, int Ho, int Wo,
+                                       float delta, int64_t outer_div, int64_t inner,
+                                       int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
+  return grid_sample2d_fwd_launch("waldo_grid_sample2d_fwd", input, grid, output, nullptr, N, C, Hi, Wi, Ho, Wo, delta,
+                                  outer_div, inner, grid_outer_div, grid_inner, stream);
+}
+
+extern "C" int waldo_grid_sample2d_mask_fwd(const float* input, const float* grid, float* output, float* mask_out,
+                                            int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
+                                            int64_t outer_div, int64_t inner, int64_t grid_outer_div,
+                                            int64_t grid_inner, waldo_stream_t stream) {
+  if (N > 0 && !mask_out) {
+    set_error("waldo_grid_sample2d_mask_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  return grid_sample2d_fwd_launch("waldo_grid_sample2d_mask_fwd", input, grid, output, mask_out, N, C, Hi, Wi, Ho, Wo,
+                                  delta, outer_div, inner, grid_outer_div, grid_inner, stream);
 }
 
 extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,

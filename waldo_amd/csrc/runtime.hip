@@ -34,7 +34,7 @@ bool debug_option(int option) {
 
 }  // namespace waldo
 
-extern "C" int waldo_version(void) { return 1009; }
+extern "C" int waldo_version(void) { return 1010; }
 
 extern "C" int waldo_set_debug_option(int option, int value) {
   if (option < 0 || option >= WALDO_DEBUG_COUNT) {

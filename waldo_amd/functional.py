@@ -240,7 +240,7 @@ def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True, perm=N
 # --------------------------------------------------------------------------------------
 class _GridSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, grid, delta, outer_div, inner):
+    def forward(ctx, inp, grid, delta, outer_div, inner, want_mask=False):
         _lib.check_cuda(inp, grid)
         inp = _c(inp)
         grid = _c(grid)
@@ -252,16 +252,25 @@ class _GridSample(torch.autograd.Function):
                 raise _lib.WaldoHipError(f"grid_sample: batch mismatch {nin} vs {n}")
             outer_div = inner = max(n, 1)
         out = inp.new_empty(n, c, ho, wo)
+        mask = inp.new_empty(n, 1, ho, wo) if want_mask else None
         with torch.cuda.device(inp.device):
-            _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
-                      c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
-                      _lib.current_stream(inp.device))
+            if want_mask:
+                _lib.call("waldo_grid_sample2d_mask_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
+                          n, c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
+                          _lib.current_stream(inp.device))
+            else:
+                _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
+                          c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
+                          _lib.current_stream(inp.device))
         ctx.save_for_backward(inp, grid)
         ctx.cfg = (float(delta), outer_div, inner)
+        if want_mask:
+            ctx.mark_non_differentiable(mask)
+            return out, mask
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_mask=None):
         inp, grid = ctx.saved_tensors
         delta, outer_div, inner = ctx.cfg
         grad_out = _c(grad_out)
@@ -273,10 +282,10 @@ class _GridSample(torch.autograd.Function):
             _lib.call("waldo_grid_sample2d_bwd", _lib.ptr(inp), _lib.ptr(grid),
                       _lib.ptr(grad_out), _lib.ptr(gi), _lib.ptr(gg), n, c, hi, wi, ho, wo,
                       delta, outer_div, inner, _lib.current_stream(inp.device))
-        return gi, gg, None, None, None
+        return gi, gg, None, None, None, None
 
 
-def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None):
+def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_mask=False):
     """``F.grid_sample(inp + delta, grid) - delta`` with the PyTorch defaults (bilinear, zeros,
     align_corners=False).  inp (Nin, C, Hi, Wi), grid (N, Ho, Wo, 2) -> (N, C, Ho, Wo).
 
@@ -286,7 +295,10 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None):
 
     grid_repeat=(n_out, outer_div, inner): the same map for the GRID -- ``grid`` holds (Ng, Ho, Wo, 2) maps and
     output n of ``n_out`` reads map ``(n // outer_div) * inner + n % inner``: the predicted frames' grids
-    repeated over the contexts (lvd.py:665-668) without the copies.  Inference only (no gradient)."""
+    repeated over the contexts (lvd.py:665-668) without the copies.  Inference only (no gradient).
+
+    return_mask: also return ``grid_sample(ones_like(inp[:, :1]), grid)`` (N, 1, Ho, Wo) -- the warped all-ones image
+    of ``Warper.grid_to_flow_ctx``'s ghost test (lvd.py:785-791), a by-product of the same taps (no gradient)."""
     if grid_repeat is not None:
         n_out, god, gin = (int(v) for v in grid_repeat)
         if torch.is_grad_enabled() and (inp.requires_grad or grid.requires_grad):
@@ -300,12 +312,17 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None):
                 (broadcast is None and nin != n_out):
             raise _lib.WaldoHipError(f"grid_sample: grid_repeat {grid_repeat} against {ng} grids / {nin} inputs")
         out = inp.new_empty(n_out, c, ho, wo)
+        mask = inp.new_empty(n_out, 1, ho, wo) if return_mask else None
         with torch.cuda.device(inp.device):
-            _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n_out, c, hi, wi,
-                      ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
-        return out
+            if return_mask:
+                _lib.call("waldo_grid_sample2d_mask_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
+                          n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
+            else:
+                _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n_out, c, hi, wi,
+                          ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
+        return (out, mask) if return_mask else out
     od, inn = broadcast if broadcast is not None else (None, None)
-    return _GridSample.apply(inp, grid, delta, od, inn)
+    return _GridSample.apply(inp, grid, delta, od, inn, bool(return_mask))
 
 
 # --------------------------------------------------------------------------------------

@@ -164,7 +164,9 @@ class Warper(nn.Module):
         output = self.obj_to_output(obj, grid, delta_obj)
         return torch.cat([self.bg_to_output(bg, grid, delta_bg), output], dim=2)
 
-    def obj_to_output(self, obj, grid, delta_obj=1):
+    def obj_to_output(self, obj, grid, delta_obj=1, return_mask=False):
+        """Reference lvd.py:533-549.  ``return_mask``: also the warped all-ones canvas of the same grids,
+        ``obj_to_output(ones_like(obj[..., :1, :, :]), grid, delta_obj=0)`` -- a by-product of the taps."""
         src_grid_obj = grid[1]
         c1 = obj.size(-3)
         ho, wo = self.tgt_shape
@@ -173,14 +175,20 @@ class Warper(nn.Module):
             rep, sg = src_grid_obj.repeat, src_grid_obj.grid
             b0, t, no = sg.shape[:3]
             out = WF.grid_sample(obj.reshape(b0 * rep * t * no, c1, ho, wo), sg.reshape(b0 * t * no, h, w, 2),
-                                 delta=delta_obj, grid_repeat=(b0 * rep * t * no, rep * t * no, t * no))
+                                 delta=delta_obj, grid_repeat=(b0 * rep * t * no, rep * t * no, t * no),
+                                 return_mask=return_mask)
+            if return_mask:
+                return out[0].view(b0 * rep, t, no, c1, h, w), out[1].view(b0 * rep, t, no, 1, h, w)
             return out.view(b0 * rep, t, no, c1, h, w)
         b, t, no = src_grid_obj.shape[:3]
         g = src_grid_obj.reshape(b * t * no, h, w, 2)
         if obj.ndim == 5:  # (B, No, C+1, Ho, Wo) shared over time (lvd.py:544): n_in = b*No + o
-            out = WF.grid_sample(obj.reshape(b * no, c1, ho, wo), g, delta=delta_obj, broadcast=(t * no, no))
+            out = WF.grid_sample(obj.reshape(b * no, c1, ho, wo), g, delta=delta_obj, broadcast=(t * no, no),
+                                 return_mask=return_mask)
         else:
-            out = WF.grid_sample(obj.reshape(b * t * no, c1, ho, wo), g, delta=delta_obj)
+            out = WF.grid_sample(obj.reshape(b * t * no, c1, ho, wo), g, delta=delta_obj, return_mask=return_mask)
+        if return_mask:
+            return out[0].view(b, t, no, c1, h, w), out[1].view(b, t, no, 1, h, w)
         return out.view(b, t, no, c1, h, w)
 
     def bg_to_output(self, bg, grid, delta_bg=1, eps=1e-6):
@@ -346,9 +354,14 @@ class Warper(nn.Module):
         gridp = [None, sgo, None, sgb]
         is_obj = None
         if ctx_only and not self.allow_ghost:
-            ones = torch.ones(b * tc, tp, no, 1, ho, wo, device=input.device, dtype=input.dtype)
-            is_obj = self.obj_to_output(ones, gridp, delta_obj=0).reshape(b * tc * tp, no, h, w)
-        flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
+            # the warped all-ones canvas of the ghost test (lvd.py:785-791) comes out of the SAME grids the object
+            # flows are warped with one statement later (lvd.py:792): a by-product of that call's taps instead of
+            # a launch of its own over B * Tc * Tp * No maps
+            obj_part, is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True)
+            is_obj = is_obj.reshape(b * tc * tp, no, h, w)
+            flow_lr = torch.cat([self.bg_to_output(bg_flow, gridp, 0), obj_part], dim=2)
+        else:
+            flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
         if into_raw:
             res = WF.flow_ctx_warp_into_raw(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts,
                                             occ, tw, s, input.size(2), self.include_self and tp == t,
