@@ -119,14 +119,19 @@ int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output
                             int C, int Hi, int Wi, int Ho, int Wo, float delta,
                             int64_t outer_div, int64_t inner, int64_t grid_outer_div,
                             int64_t grid_inner, waldo_stream_t stream);
-/* The same with a by-product: mask_out (N,1,Ho,Wo) = the sample of an ALL-ONES image at the same grid, i.e. what
- * Warper.obj_to_output(ones, grid) returns and Warper.grid_to_flow_ctx thresholds at 0.9 into `is_obj`
- * (models/nets/lvd.py:785-791) -- the object flows are warped with the very same grids one statement later
- * (lvd.py:792), so the mask costs one store instead of a launch of its own over B*Tc*Tp*No maps. */
-int waldo_grid_sample2d_mask_fwd(const float* input, const float* grid, float* output, float* mask_out,
-                                 int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
-                                 int64_t outer_div, int64_t inner, int64_t grid_outer_div, int64_t grid_inner,
-                                 waldo_stream_t stream);
+/* The same with two extras for Warper.grid_to_flow_ctx (models/nets/lvd.py:785-796), where the reference warps an
+ * all-ones canvas, then the object flows and the background flow with the same grids, and concatenates the results:
+ *   mask_out (N,1,Ho,Wo) or NULL: the sample of an ALL-ONES image at the same grid -- what Warper.obj_to_output(ones,
+ *     grid) returns and the ghost test thresholds at 0.9 (lvd.py:785-791) -- a by-product of the taps (one store
+ *     instead of a launch of its own over B*Tc*Tp*No maps);
+ *   out_group / out_stride / out_offset: output map n is written to slot (n / out_group) * out_stride + out_offset +
+ *     n % out_group of an output tensor of (slots, C, Ho, Wo) maps ((N, N, 0): the plain output).  With (1, L, 0) for
+ *     the background and (No, L, 1) for the objects the two calls of Warper.layer_to_output (lvd.py:533-537) write
+ *     straight into the (frames, L, C, Ho, Wo) tensor its torch.cat would build. */
+int waldo_grid_sample2d_ex_fwd(const float* input, const float* grid, float* output, float* mask_out,
+                               int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
+                               int64_t outer_div, int64_t inner, int64_t grid_outer_div, int64_t grid_inner,
+                               int64_t out_group, int64_t out_stride, int64_t out_offset, waldo_stream_t stream);
 /* grad_input (Nin,C,Hi,Wi) must be ZERO-FILLED by the caller (accumulated with atomics; may be
  * NULL to skip); grad_grid (N,Ho,Wo,2) is overwritten (may be NULL to skip). */
 int waldo_grid_sample2d_bwd(const float* input, const float* grid, const float* grad_output,

@@ -133,10 +133,11 @@ def test_grid_sample_broadcast(dev):
 
 @pytest.mark.parametrize("hwo", [(12, 10), (16, 32)])   # one pixel per thread / four (Ho * Wo % 4 == 0)
 def test_grid_sample_mask_by_product(dev, hwo):
-    """waldo_grid_sample2d_mask_fwd: the output is the plain call's, and the mask is grid_sample(ones, grid) -- the
+    """waldo_grid_sample2d_ex_fwd: the output is the plain call's, and the mask is grid_sample(ones, grid) -- the
     warped all-ones canvas of Warper.grid_to_flow_ctx's ghost test (lvd.py:785-791) -- bit for bit; with the input
-    expanded over time, with the grid repeated over the contexts, and under autograd (the mask carries none)."""
-    from waldo_amd import functional as WF
+    expanded over time, with the grid repeated over the contexts, and under autograd (the mask carries none).  And
+    its output slots: two calls fill the concatenated (frames, L, C, H, W) tensor of Warper.layer_to_output."""
+    from waldo_amd import _lib, functional as WF
     b, t, no, c, ho, wo = 2, 3, 4, 2, 8, 8
     h, w = hwo
     torch.manual_seed(4)
@@ -159,6 +160,21 @@ def test_grid_sample_mask_by_product(dev, hwo):
         out, mask = WF.grid_sample(big, grid, grid_repeat=gr, return_mask=True)
         assert torch.equal(out, WF.grid_sample(big, grid, grid_repeat=gr))
         assert torch.equal(mask, WF.grid_sample(torch.ones(b * rep * t * no, 1, ho, wo, device=dev), grid, grid_repeat=gr))
+        # output slots: the background (one map per frame) and the objects (No per frame) written straight into the
+        # tensor Warper.layer_to_output's torch.cat would build
+        frames = b * t
+        bgmap = torch.randn(frames, c, ho, wo, device=dev)
+        bggrid = (torch.rand(frames, h, w, 2, device=dev) * 2.6 - 1.3)
+        want = torch.cat([WF.grid_sample(bgmap, bggrid).view(frames, 1, c, h, w),
+                          WF.grid_sample(obj, grid).view(frames, no, c, h, w)], dim=1)
+        dst = torch.full((frames, no + 1, c, h, w), float("nan"), device=dev)
+        assert WF.grid_sample(bgmap, bggrid, out=(dst, 1, no + 1, 0)) is dst
+        _, mask = WF.grid_sample(obj, grid, return_mask=True, out=(dst, no, no + 1, 1))
+        assert torch.equal(dst, want) and torch.equal(mask, WF.grid_sample(ones, grid, delta=0.0))
+        with pytest.raises(_lib.WaldoHipError):
+            WF.grid_sample(obj, grid, out=(dst, no, no, 1))          # offset + group > stride
+        with pytest.raises(_lib.WaldoHipError):
+            WF.grid_sample(obj, grid, out=(dst[:1], no, no + 1, 1))  # too small
     x, g = obj.clone().requires_grad_(), grid.clone().requires_grad_()
     out, mask = WF.grid_sample(x, g, return_mask=True)
     assert not mask.requires_grad

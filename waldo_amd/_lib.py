@@ -34,8 +34,8 @@ SIGNATURES = {
     "waldo_inverse_warp_bwd": [_c_f] * 9 + [_i64, _int, _int, _int, _int, _int, _stream],
     "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
                                 _i64, _i64, _i64, _stream],
-    "waldo_grid_sample2d_mask_fwd": [_c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
-                                     _i64, _i64, _i64, _stream],
+    "waldo_grid_sample2d_ex_fwd": [_c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
+                                   _i64, _i64, _i64, _i64, _i64, _i64, _stream],
     "waldo_grid_sample2d_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int,
                                 _flt, _i64, _i64, _stream],
     "waldo_occ_composite_fwd": [_c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],

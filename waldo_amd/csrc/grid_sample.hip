@@ -12,6 +12,15 @@ __device__ __forceinline__ int64_t in_index(int64_t n, int64_t outer_div, int64_
   return (n / outer_div) * inner + (n % inner);
 }
 
+// Where output map n goes: slot (n / group) * stride + offset + n % group of an output tensor of (slots, C, Ho, Wo)
+// maps.  (N, 1, 0) is the plain (N, C, Ho, Wo) output.  Warper.layer_to_output (lvd.py:533-537) concatenates the
+// warped background (one map per frame) and the warped objects (No per frame) along the layer axis: with
+// (group, stride, offset) = (1, L, 0) and (No, L, 1) the two calls write straight into the concatenated tensor.
+struct OutSlots {
+  int64_t group, stride, offset;
+  __device__ __forceinline__ int64_t slot(int64_t n) const { return (n / group) * stride + offset + n % group; }
+};
+
 // The sample of an all-ones image at the same taps: tap_sample() on the constant 1 (the same operations on the
 // validity products: the bits grid_sample(ones, grid) gives).  Warper.grid_to_flow_ctx asks for it next to the layer
 // flows (`is_obj = obj_to_output(ones) > 0.9`, lvd.py:785-791): the same grids, so the mask is a by-product.
@@ -25,7 +34,7 @@ __device__ __forceinline__ float tap_sample_ones(const Taps& t) {
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
-    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner) {
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   if (p >= HWo) return;
@@ -34,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
   if (mask_out != nullptr) mask_out[n * HWo + p] = tap_sample_ones(t);
   const int64_t HWi = (int64_t)Hi * Wi;
   const float* in = input + in_index(n, outer_div, inner) * C * HWi;
-  float* out = output + n * C * HWo + p;
+  float* out = output + os.slot(n) * C * HWo + p;
   // sum of the weights of the in-range taps: sample(x + delta) = sample(x) + delta * wsum
   const float wsum = (t.w00 + t.w01) + (t.w10 + t.w11);
   const float shift = fmaf(delta, wsum, -delta);
@@ -106,7 +115,7 @@ typedef float f32x4_gs __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
-    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner) {
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = ((int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x) * 4;
   if (p >= HWo) return;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
   t[3] = make_taps(g1[2], g1[3], Hi, Wi);
   const int64_t HWi = (int64_t)Hi * Wi;
   const float* in = input + in_index(n, outer_div, inner) * C * HWi;
-  float* out = output + n * C * HWo + p;
+  float* out = output + os.slot(n) * C * HWo + p;
   float shift[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -161,7 +170,13 @@ using namespace waldo;
 
 static int grid_sample2d_fwd_launch(const char* fn, const float* input, const float* grid, float* output, float* mask_out,
                                     int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta, int64_t outer_div,
-                                    int64_t inner, int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
+                                    int64_t inner, int64_t grid_outer_div, int64_t grid_inner, OutSlots os,
+                                    waldo_stream_t stream) {
+  if (os.group < 1 || os.stride < os.group || os.offset < 0 || os.offset + os.group > os.stride) {
+    set_error("%s: bad output slots (group %lld, stride %lld, offset %lld)", fn, (long long)os.group,
+              (long long)os.stride, (long long)os.offset);
+    return WALDO_EINVAL;
+  }
   int rc = check_gs(fn, N, C, Hi, Wi, Ho, Wo, outer_div, inner);
   if (rc) return rc;
   if (grid_outer_div < 1 || grid_inner < 1) {
@@ -178,13 +193,13 @@ static int grid_sample2d_fwd_launch(const char* fn, const float* input, const fl
     const int tiles4 = (int)((HWo / 4 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(grid_sample2d_fwd4_kernel, dim3((unsigned)(N * tiles4)), dim3(kBlock), 0,
                        (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner,
-                       grid_outer_div, grid_inner);
+                       grid_outer_div, grid_inner, os);
     return launch_status(fn);
   }
   const int tiles = (int)((HWo + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(grid_sample2d_fwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
                      (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles, delta,
-                     outer_div, inner, grid_outer_div, grid_inner);
+                     outer_div, inner, grid_outer_div, grid_inner, os);
   return launch_status(fn);
 }
 
@@ -193,19 +208,18 @@ extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, fl
                                        float delta, int64_t outer_div, int64_t inner,
                                        int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
   return grid_sample2d_fwd_launch("waldo_grid_sample2d_fwd", input, grid, output, nullptr, N, C, Hi, Wi, Ho, Wo, delta,
-                                  outer_div, inner, grid_outer_div, grid_inner, stream);
+                                  outer_div, inner, grid_outer_div, grid_inner, OutSlots{N > 0 ? N : 1, N > 0 ? N : 1, 0},
+                                  stream);
 }
 
-extern "C" int waldo_grid_sample2d_mask_fwd(const float* input, const float* grid, float* output, float* mask_out,
-                                            int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
-                                            int64_t outer_div, int64_t inner, int64_t grid_outer_div,
-                                            int64_t grid_inner, waldo_stream_t stream) {
-  if (N > 0 && !mask_out) {
-    set_error("waldo_grid_sample2d_mask_fwd: null pointer");
-    return WALDO_EINVAL;
-  }
-  return grid_sample2d_fwd_launch("waldo_grid_sample2d_mask_fwd", input, grid, output, mask_out, N, C, Hi, Wi, Ho, Wo,
-                                  delta, outer_div, inner, grid_outer_div, grid_inner, stream);
+extern "C" int waldo_grid_sample2d_ex_fwd(const float* input, const float* grid, float* output, float* mask_out,
+                                          int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
+                                          int64_t outer_div, int64_t inner, int64_t grid_outer_div,
+                                          int64_t grid_inner, int64_t out_group, int64_t out_stride,
+                                          int64_t out_offset, waldo_stream_t stream) {
+  return grid_sample2d_fwd_launch("waldo_grid_sample2d_ex_fwd", input, grid, output, mask_out, N, C, Hi, Wi, Ho, Wo,
+                                  delta, outer_div, inner, grid_outer_div, grid_inner,
+                                  OutSlots{out_group, out_stride, out_offset}, stream);
 }
 
 extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,

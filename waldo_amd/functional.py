@@ -255,9 +255,9 @@ class _GridSample(torch.autograd.Function):
         mask = inp.new_empty(n, 1, ho, wo) if want_mask else None
         with torch.cuda.device(inp.device):
             if want_mask:
-                _lib.call("waldo_grid_sample2d_mask_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
+                _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
                           n, c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
-                          _lib.current_stream(inp.device))
+                          max(n, 1), max(n, 1), 0, _lib.current_stream(inp.device))
             else:
                 _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
                           c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
@@ -285,7 +285,7 @@ class _GridSample(torch.autograd.Function):
         return gi, gg, None, None, None, None
 
 
-def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_mask=False):
+def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_mask=False, out=None):
     """``F.grid_sample(inp + delta, grid) - delta`` with the PyTorch defaults (bilinear, zeros,
     align_corners=False).  inp (Nin, C, Hi, Wi), grid (N, Ho, Wo, 2) -> (N, C, Ho, Wo).
 
@@ -298,29 +298,48 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_m
     repeated over the contexts (lvd.py:665-668) without the copies.  Inference only (no gradient).
 
     return_mask: also return ``grid_sample(ones_like(inp[:, :1]), grid)`` (N, 1, Ho, Wo) -- the warped all-ones image
-    of ``Warper.grid_to_flow_ctx``'s ghost test (lvd.py:785-791), a by-product of the same taps (no gradient)."""
-    if grid_repeat is not None:
-        n_out, god, gin = (int(v) for v in grid_repeat)
+    of ``Warper.grid_to_flow_ctx``'s ghost test (lvd.py:785-791), a by-product of the same taps (no gradient).
+
+    out=(tensor, group, stride, offset): write output map n into slot ``(n // group) * stride + offset + n % group``
+    of ``tensor`` (slots, C, Ho, Wo) instead of a tensor of its own -- the two calls of ``Warper.layer_to_output``
+    (lvd.py:533-537) then fill the concatenated tensor directly.  Inference only; returns ``tensor``."""
+    if grid_repeat is not None or out is not None:
         if torch.is_grad_enabled() and (inp.requires_grad or grid.requires_grad):
-            raise _lib.WaldoHipError("grid_sample: grid_repeat is forward only; expand the grid for a gradient")
+            raise _lib.WaldoHipError("grid_sample: grid_repeat / out are forward only (no gradient flows through them)")
         _lib.check_cuda(inp, grid)
         inp, grid = _c(inp.detach()), _c(grid.detach())
         nin, c, hi, wi = inp.shape
         ng, ho, wo, _ = grid.shape
+        if grid_repeat is not None:
+            n_out, god, gin = (int(v) for v in grid_repeat)
+        else:
+            n_out, god, gin = ng, max(ng, 1), max(ng, 1)
         od, inn = broadcast if broadcast is not None else (max(n_out, 1), max(n_out, 1))
         if god < 1 or gin < 1 or (n_out > 0 and ((n_out - 1) // god) * gin + min(gin, n_out) > ng) or \
                 (broadcast is None and nin != n_out):
             raise _lib.WaldoHipError(f"grid_sample: grid_repeat {grid_repeat} against {ng} grids / {nin} inputs")
-        out = inp.new_empty(n_out, c, ho, wo)
+        if out is not None:
+            dst, grp, stride, off = out[0], int(out[1]), int(out[2]), int(out[3])
+            _lib.check_cuda(dst)
+            slots = ((n_out - 1) // grp) * stride + off + min(grp, n_out) if n_out > 0 else 0
+            if not dst.is_contiguous() or dst.dtype != inp.dtype or tuple(dst.shape[-3:]) != (c, ho, wo) or \
+                    dst.numel() < slots * c * ho * wo or grp < 1 or off < 0 or off + grp > stride:
+                raise _lib.WaldoHipError(f"grid_sample: out tensor {tuple(dst.shape)} does not hold slots "
+                                         f"(group {grp}, stride {stride}, offset {off}) of {n_out} maps of {(c, ho, wo)}")
+            res = dst
+        else:
+            grp, stride, off = max(n_out, 1), max(n_out, 1), 0
+            res = inp.new_empty(n_out, c, ho, wo)
         mask = inp.new_empty(n_out, 1, ho, wo) if return_mask else None
         with torch.cuda.device(inp.device):
-            if return_mask:
-                _lib.call("waldo_grid_sample2d_mask_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
-                          n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
+            if return_mask or out is not None:
+                _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(res), _lib.ptr(mask),
+                          n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, grp, stride, off,
+                          _lib.current_stream(inp.device))
             else:
-                _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n_out, c, hi, wi,
+                _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(res), n_out, c, hi, wi,
                           ho, wo, float(delta), od, inn, god, gin, _lib.current_stream(inp.device))
-        return (out, mask) if return_mask else out
+        return (res, mask) if return_mask else res
     od, inn = broadcast if broadcast is not None else (None, None)
     return _GridSample.apply(inp, grid, delta, od, inn, bool(return_mask))
 

@@ -164,9 +164,10 @@ class Warper(nn.Module):
         output = self.obj_to_output(obj, grid, delta_obj)
         return torch.cat([self.bg_to_output(bg, grid, delta_bg), output], dim=2)
 
-    def obj_to_output(self, obj, grid, delta_obj=1, return_mask=False):
+    def obj_to_output(self, obj, grid, delta_obj=1, return_mask=False, into=None):
         """Reference lvd.py:533-549.  ``return_mask``: also the warped all-ones canvas of the same grids,
-        ``obj_to_output(ones_like(obj[..., :1, :, :]), grid, delta_obj=0)`` -- a by-product of the taps."""
+        ``obj_to_output(ones_like(obj[..., :1, :, :]), grid, delta_obj=0)`` -- a by-product of the taps.
+        ``into``: a (frames, L, C+1, H, W) tensor whose layers 1 .. No receive the result (inference only)."""
         src_grid_obj = grid[1]
         c1 = obj.size(-3)
         ho, wo = self.tgt_shape
@@ -176,7 +177,9 @@ class Warper(nn.Module):
             b0, t, no = sg.shape[:3]
             out = WF.grid_sample(obj.reshape(b0 * rep * t * no, c1, ho, wo), sg.reshape(b0 * t * no, h, w, 2),
                                  delta=delta_obj, grid_repeat=(b0 * rep * t * no, rep * t * no, t * no),
-                                 return_mask=return_mask)
+                                 return_mask=return_mask, out=None if into is None else (into, no, no + 1, 1))
+            if into is not None:
+                return out[1].view(b0 * rep, t, no, 1, h, w) if return_mask else None
             if return_mask:
                 return out[0].view(b0 * rep, t, no, c1, h, w), out[1].view(b0 * rep, t, no, 1, h, w)
             return out.view(b0 * rep, t, no, c1, h, w)
@@ -191,7 +194,7 @@ class Warper(nn.Module):
             return out[0].view(b, t, no, c1, h, w), out[1].view(b, t, no, 1, h, w)
         return out.view(b, t, no, c1, h, w)
 
-    def bg_to_output(self, bg, grid, delta_bg=1, eps=1e-6):
+    def bg_to_output(self, bg, grid, delta_bg=1, eps=1e-6, into=None):
         src_grid_bg = grid[3]
         c1 = bg.size(-3)
         h, w = self.src_shape
@@ -199,7 +202,10 @@ class Warper(nn.Module):
             rep, sg = src_grid_bg.repeat, src_grid_bg.grid
             b0, t = sg.shape[:2]
             out = WF.grid_sample(bg.reshape(b0 * rep * t, c1, h, w), sg.reshape(b0 * t, h, w, 2), delta=delta_bg,
-                                 grid_repeat=(b0 * rep * t, rep * t, t))
+                                 grid_repeat=(b0 * rep * t, rep * t, t),
+                                 out=None if into is None else (into, 1, into.size(-4), 0))
+            if into is not None:
+                return None
             return out.view(b0 * rep, t, 1, c1, h, w)
         b, t = src_grid_bg.shape[:2]
         g = src_grid_bg.reshape(b * t, h, w, 2)
@@ -357,9 +363,14 @@ class Warper(nn.Module):
             # the warped all-ones canvas of the ghost test (lvd.py:785-791) comes out of the SAME grids the object
             # flows are warped with one statement later (lvd.py:792): a by-product of that call's taps instead of
             # a launch of its own over B * Tc * Tp * No maps
-            obj_part, is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True)
+            if isinstance(sgo, TimeRepeat):  # inference: both warps write straight into the concatenated tensor
+                flow_lr = input.new_empty(b * tc, tp, nl, 2, h, w)
+                is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True, into=flow_lr)
+                self.bg_to_output(bg_flow, gridp, 0, into=flow_lr)
+            else:
+                obj_part, is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True)
+                flow_lr = torch.cat([self.bg_to_output(bg_flow, gridp, 0), obj_part], dim=2)
             is_obj = is_obj.reshape(b * tc * tp, no, h, w)
-            flow_lr = torch.cat([self.bg_to_output(bg_flow, gridp, 0), obj_part], dim=2)
         else:
             flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
         if into_raw:
