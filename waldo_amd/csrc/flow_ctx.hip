@@ -146,6 +146,10 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 // the padding layers filled with those of layer L - 1.  A tap of a layer is then ONE ds_read_b128 at a
 // compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
 // ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
+#ifndef WALDO_FCW_WAVES
+#define WALDO_FCW_WAVES 5  // waves per SIMD the tall-tile kernel is compiled for up to 12 layers: 96 VGPRs with 26 spilled
+                           // dwords; at 4 (126 VGPRs, no spill) 7.03 against 6.80 ms per C5 pipeline step (A/B, one box)
+#endif
 #ifndef WALDO_FCW_ROWS
 #define WALDO_FCW_ROWS 4  // pixels per thread of flow_ctx_warp_kernel at scale >= 2 (tile = 4 WALDO_FCW_ROWS x 64 pixels)
 #endif
@@ -181,7 +185,7 @@ __device__ __forceinline__ float nan_max(float a, float b) { return __builtin_el
 // kernel's 7.8 ms per C5 pipeline step.  With R = 4 a 16 x 64 tile stages 6 x 18 cells where four 4 x 64 tiles staged
 // 4 x (3 x 18).
 template <int LP, bool SCORE, int R>
-__global__ __launch_bounds__(kBlock, (R > 1 && LP <= 17) ? 4 : 1) void flow_ctx_warp_kernel(
+__global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R > 1 && LP <= 17) ? 4 : 1)) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
