@@ -592,11 +592,12 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
-@pytest.mark.parametrize("amp_px", [10.0, 50.0])
+@pytest.mark.parametrize("amp_px", [10.0, 50.0, 150.0])
 def test_frame_warp_fuse_at_256x512(dev, amp_px):
-    """input_to_output at a 256 x 512 raster with smooth flows of 10 and 50 px amplitude (the regimes the C4 / C5
-    pipelines operate in; the small-raster test above cannot leave a tile's neighbourhood): forward against the
-    oracle in fp32 and fp64, backward (flow and alpha gradients) against the oracle's autograd."""
+    """input_to_output at a 256 x 512 raster with flows of 10 and 50 px amplitude, smooth over 32-pixel cells (the
+    regimes the C4 / C5 pipelines operate in; the small-raster test above cannot leave a tile's neighbourhood), and of
+    150 px (neighbouring cells land far apart: the folded warp of the pipelines' `--motion wild`, local stretch up to
+    ~10): forward against the oracle in fp32 and fp64, backward (flow and alpha gradients) against its autograd."""
     from waldo_amd import functional as WF
     b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 2, 5, 3, 256, 512
     opt = opt_ns(num_obj=nl - 1, dim=hd, aspect_ratio=2.0, load_dim=hd)
