@@ -147,8 +147,14 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
 // compile-time offset from the tap's cell (plane-major, as the planes lie in memory, it was three
 // ds_read_b32 with a run-time plane offset each: 36 samples x 13 VALU + 4 LDS instructions per pixel).
 #ifndef WALDO_FCW_WAVES
-#define WALDO_FCW_WAVES 5  // waves per SIMD the tall-tile kernel is compiled for up to 12 layers: 96 VGPRs with 26 spilled
-                           // dwords; at 4 (126 VGPRs, no spill) 7.03 against 6.80 ms per C5 pipeline step (A/B, one box)
+#define WALDO_FCW_WAVES 5  // waves per SIMD the tall-tile kernel is compiled for up to 12 layers (80 VGPRs, no spill, since the
+                           // unstaged path is compiled out of it and the flows are re-taken: 6.77 -> 5.49 ms per C5 pipeline
+                           // step, 3.45 -> 3.01 at C4; at 6, which 24 KB of LDS allow, the same 5.5 ms:
+                           // profiles/r04_ab_flow_ctx_warp_reflow_*.txt)
+#endif
+#ifndef WALDO_FCW_REFLOW
+#define WALDO_FCW_REFLOW 1  // the upsampled flow of a layer is taken AGAIN where its composited alpha is known (active layers only)
+                            // instead of kept per layer: 2 LP registers fewer across the occlusion product
 #endif
 #ifndef WALDO_FCW_ROWS
 #define WALDO_FCW_ROWS 4  // pixels per thread of flow_ctx_warp_kernel at scale >= 2 (tile = 4 WALDO_FCW_ROWS x 64 pixels)
@@ -157,11 +163,19 @@ constexpr int kFcwRows = WALDO_FCW_ROWS;
 #ifndef WALDO_FCW_CHUNK
 #define WALDO_FCW_CHUNK 4  // 4: 116 registers at L = 12 (four waves per SIMD) and 1.92 ms at the C5 size; 6: 140 and 2.04 ms
 #endif
-template <int LP>
+// floats of LDS for the staged low-resolution records of a tile with `rows` pixels per thread: 136 cells (4 x 64 tile
+// at x 2) up to L = 12; L <= 8: 204 cells (8 x 64 tile at x 2).  The 16 x 64 tile at 9-12 layers only ever fits at
+// x 4 and up (6 x 18 cells): sized for exactly that, 24 KB with the order, six workgroups per CU
+#ifndef WALDO_FCW_SMALL_LDS
+#define WALDO_FCW_SMALL_LDS 1
+#endif
+constexpr int fcw_cap(int lp, int rows) {
+  return lp <= 8 ? 7680 : (lp <= 12 ? ((WALDO_FCW_SMALL_LDS && rows == kFcwRows && kFcwRows == 4) ? 5632 : 7168) : 8192);
+}
+template <int LP, int R>
 struct FcwLds {
-  static constexpr int kCell = 4 * LP + 4;             // floats per cell (+ 4: cells of a row on different banks)
-  static constexpr int kCap = LP <= 8 ? 7680 : (LP <= 12 ? 7168 : 8192);  // floats: 136 cells (4 x 64 tile at x 2) up to L = 12;
-                                                                          // L <= 8: 204 cells (8 x 64 tile at x 2)
+  static constexpr int kCell = 4 * LP + 4;  // floats per cell (+ 4: cells of a row on different banks)
+  static constexpr int kCap = fcw_cap(LP, R);
 };
 
 // where the L planes of alpha_ctx[b, tc, tp] go: element strides of the three unit indices from `alpha_ctx` (the
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
     float* __restrict__ alpha_ctx, ActxLayout lay, float* __restrict__ score, float* __restrict__ disocc,
     float* __restrict__ alpha_max, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, int units,
     int tiles, int nbands) {
-  using G = FcwLds<LP>;
+  using G = FcwLds<LP, R>;
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
@@ -220,7 +234,12 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   lq.nrows = __builtin_amdgcn_readfirstlane(lq.nrows);
   lq.ncols = __builtin_amdgcn_readfirstlane(lq.ncols);
   const int area = lq.nrows * lq.ncols;
-  const bool staged = area <= kBlock && area * G::kCell <= G::kCap;  // uniform
+  // (uniform.  A tall tile is only launched where every tile's patch fits -- `fits` in flow_ctx_warp_launch bounds
+  // the patch of any tile -- so that R > 1 compiles WITHOUT the unstaged path: left in, its per-layer plane addresses
+  // were hoisted out of the row loop as 2 LP 64-bit registers and spilled there)
+  const bool fits_lds = area <= kBlock && area * G::kCell <= G::kCap;
+  if (R > 1 && !fits_lds) return;  // (never taken: see the launcher)
+  const bool staged = R > 1 ? true : fits_lds;
   bool flow_bad = false;
   if (staged) {
     // thread = (cell, layer group): kBlock / area groups share the layers of a cell
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   // "Exact" needs finite operands: 0 * inf would have been NaN.  A non-finite entry of the order or of the tile's
   // low-resolution flows (`dense`, voted at the barrier above) or a non-finite sampled alpha in any lane (`wild`,
   // below) switches everything back to all L layers and all L x L factors, so NaNs propagate exactly as before.
-  float a[LP], fx[LP], fy[LP];
+  float a[LP], fx[WALDO_FCW_REFLOW ? 1 : LP], fy[WALDO_FCW_REFLOW ? 1 : LP];
   float dis = -INFINITY;
   const float* ap0 = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer l: + min(l, L - 1) * HWd
   unsigned active = 0;  // wave-uniform: bit l = some lane has a[l] != 0
@@ -342,8 +361,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
             fyl = up_sample(fl + HW, ut);
           }
         }
-        fx[l] = fxl;
-        fy[l] = fyl;
+        if (!WALDO_FCW_REFLOW) fx[l] = fxl, fy[l] = fyl;
         if (want) {
           need |= 1u << k;
           pt[k] = pair_taps(gx0 + fxl, gy0 + fyl, Hd, Wd, inter[k]);
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
       __builtin_amdgcn_sched_barrier(0);  // one chunk's loads at a time
     }
   };
-  if (staged) layers(std::true_type{});
+  if (R > 1 || staged) layers(std::true_type{});
   else layers(std::false_type{});
   if (!WALDO_FCW_SPARSE || dense || wild) active = L >= 32 ? 0xffffffffu : (1u << L) - 1u;
   disocc[(int64_t)m * HWd + p] = dis;
@@ -413,10 +431,32 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (j + k >= LP) break;
-      if (!WALDO_FCW_CONST_OUT || (active & (1u << (j + k)))) {  // wave-uniform
+      if (!(WALDO_FCW_CONST_OUT || WALDO_FCW_REFLOW) || (active & (1u << (j + k)))) {  // wave-uniform
         const float v = a[j + k] * prd[k >> 1][k & 1];
-        ox += v * fx[j + k];
-        oy += v * fy[j + k];
+        if (WALDO_FCW_REFLOW) {
+          // the layer's upsampled flow again (the same expressions as in the sampling loop: the same bits), for the
+          // 2-4 layers present in this wavefront's pixels; every layer when the tile is dense / wild
+          asm volatile("");  // (a real branch, as above)
+          float fxl, fyl;
+          if (R > 1 || staged) {
+            const int lo = 4 * (j + k);
+            const f32x2_p v00 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o00 + lo);
+            const f32x2_p v01 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o01 + lo);
+            const f32x2_p v10 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o10 + lo);
+            const f32x2_p v11 = *reinterpret_cast<const f32x2_p*>(lrimg + lt.o11 + lo);
+            fxl = up_blend(ut, v00[0], v01[0], v10[0], v11[0]);
+            fyl = up_blend(ut, v00[1], v01[1], v10[1], v11[1]);
+          } else {
+            const float* fl = flow_lr + (((int64_t)m * L + min(j + k, L - 1)) * 2) * HW;
+            fxl = up_sample(fl, ut);
+            fyl = up_sample(fl + HW, ut);
+          }
+          ox += v * fxl;
+          oy += v * fyl;
+        } else {
+          ox += v * fx[j + k];
+          oy += v * fy[j + k];
+        }
 #ifndef WALDO_ABL_FCW_NOSTORE
         if (j + k < L) {
           const float av = v * 2.0f - 1.0f;
@@ -723,10 +763,10 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
   // is far slower: 5.9 against 4.0 ms per C4 pipeline step) -- there two pixels per thread (6 x 34 cells) if that
   // fits; otherwise the 4 x 64 tile of the other kernels
   const int lp = flow_ctx_pad_l(L);
-  const int cap = lp <= 8 ? 7680 : (lp <= 12 ? 7168 : 8192), cell_floats = 4 * lp + 4;  // FcwLds<LP>::kCap / kCell
+  const int cell_floats = 4 * lp + 4;  // FcwLds<LP, R>::kCell
   auto fits = [&](int r) {
     const int cells = ((kHdRows * r + scale - 1) / scale + 2) * ((kHdCols + scale - 1) / scale + 2);
-    return cells <= kBlock && cells * cell_floats <= cap;
+    return cells <= kBlock && cells * cell_floats <= fcw_cap(lp, r);
   };
   const int rows = scale < 2 ? 1 : (fits(kFcwRows) ? kFcwRows : (fits(2) ? 2 : 1));
   const HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
