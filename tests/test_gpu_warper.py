@@ -336,6 +336,7 @@ def _flow_ctx_warp_spelled_out(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s)
 
 
 @pytest.mark.parametrize("poison,hw", [("none", (32, 64)), ("occ", (32, 64)), ("flow", (32, 64)), ("alpha", (32, 64)),
+                                       ("soft", (32, 64)), ("mask", (32, 64)), ("soft", (9, 20)),
                                        ("none", (9, 20)), ("alpha", (9, 20))])  # 36 x 80: ragged 16 x 64 tiles
 def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison, hw):
     """The wavefront-level short cuts of flow_ctx_warp_kernel (a layer whose object mask is off in all 64 lanes is
@@ -354,6 +355,13 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison, hw):
     cy = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * h
     cx = torch.rand(m, nl - 1, 1, 1, generator=g, device=dev) * w
     isobj = (((yy - cy) ** 2 + (xx - cx) ** 2) < (36 if h >= 32 else 9)).float()
+    if poison == "soft":
+        # masks that fall off over a few cells: cells between the coarse row test's 0.5 and the 0.9 of lvd.py:785,
+        # upsampled values on both sides of 0.9 inside one wavefront
+        isobj = (1.3 - ((yy - cy) ** 2 + (xx - cx) ** 2).sqrt() / (6.0 if h >= 32 else 3.0)).clamp(0.0, 1.0)
+    elif poison == "mask":
+        isobj[1, 3, h // 2, :] = float("nan")       # NaN > 0.9 is false: the layer is dropped there, as if absent
+        isobj[2, 7, 2:5, 3:9] = float("nan")
     a01 = torch.rand(b * tw, nl, hd, wd, generator=g, device=dev)
     a01[:, 1:] *= (torch.rand(b * tw, nl - 1, hd, wd, generator=g, device=dev) > 0.5)   # exact zeros inside objects too
     occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
@@ -380,7 +388,7 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison, hw):
         assert torch.equal(torch.isinf(x[ok]), torch.isinf(y[ok])), f"{poison}: infinities of {name} differ"
         fin = ok & ~torch.isinf(y)
         close(x[fin], y[fin], what=f"{poison}: {name}")
-    if poison == "none":
+    if poison in ("none", "soft", "mask"):
         # absent layers come out as the exact constants
         gone = (actx == -1.0).float().mean().item()
         assert gone > 0.4, gone
