@@ -638,6 +638,40 @@ def test_frame_warp_fuse_at_256x512(dev, amp_px):
     close(a.grad, r32[3], rel=True, what=f"{amp_px} px: grad_alpha", exact=r64[3])
 
 
+@pytest.mark.parametrize("tc,include_self", [(4, False), (2, False), (3, True), (4, True)])
+@pytest.mark.parametrize("hw", [(64, 128), (37, 100), (8, 36), (128, 256)])
+@pytest.mark.parametrize("amp_px", [3.0, 40.0])
+def test_frame_warp_fuse_staged_boxes_same_bits(dev, tc, include_self, hw, amp_px):
+    """frame_warp_fuse with the contexts' footprint boxes staged in LDS (frame_warp_fuse_lds_kernel: rows that start on a
+    multiple of four texels from a 16-byte aligned base) against the pair gathers of frame_warp_fuse_kernel -- taken
+    when the frames' base address is NOT 16-byte aligned, which a view one float into a buffer arranges: the same bits
+    for `out` and `raw`, with four contexts (every vector-memory operation unconditional) and with fewer / the unwarped
+    frame itself as a context, on rasters with ragged tiles (threads past the edge duplicate the last pixel's stores),
+    under flows whose boxes fit (3 px) and flows of which some tiles' boxes do not (40 px over 16-pixel cells: those
+    tiles gather)."""
+    from waldo_amd import functional as WF
+    hd, wd = hw
+    b, t, c, nl = 2, 5, 6, 3
+    tp = t if include_self else 3
+    g = torch.Generator(device=dev).manual_seed(hd + tc)
+    buf = torch.randn(b * t * c * hd * wd + 1, generator=g, device=dev)
+    inp = buf[:-1].view(b, t, c, hd, wd)
+    inp_off = buf[1:].view(b, t, c, hd, wd)
+    inp_off.copy_(inp.clone())
+    inp = inp_off.clone()                                       # 16-byte aligned copy of the same values
+    assert inp.data_ptr() % 16 == 0 and inp_off.data_ptr() % 16 == 4
+    fl = (amp_px * 2 / wd) * torch.randn(b * tc * tp, 2, max(hd // 16, 1), max(wd // 16, 1), generator=g, device=dev)
+    flow = torch.nn.functional.interpolate(fl, size=(hd, wd), mode="bilinear").view(b, tc, tp, 2, hd, wd).contiguous()
+    flow[0, 0, 0, :, : hd // 2] += 2.5                          # a block of samples outside the frame
+    alpha = torch.rand(b, tc, tp, nl, hd, wd, generator=g, device=dev) * 2 - 1
+    ctx_ts = torch.randint(0, t, (b, tc, tp), generator=g, device=dev)
+    with torch.no_grad():
+        out, raw = WF.frame_warp_fuse(inp, flow, alpha, ctx_ts, include_self=include_self)
+        out_g, raw_g = WF.frame_warp_fuse(inp_off, flow, alpha, ctx_ts, include_self=include_self)
+    assert torch.equal(out, out_g), (out - out_g).abs().max().item()
+    assert torch.equal(raw, raw_g), (raw - raw_g).abs().max().item()
+
+
 @pytest.mark.parametrize("include_self", [False, True])
 @pytest.mark.parametrize("shape", [(2, 3, 2, 2, 7, 5, 4, 16, 32, 2, True), (1, 4, 4, 3, 23, 12, 8, 32, 4, 4, False),
                                    (1, 2, 5, 1, 4, 3, 8, 16, 1, 1, True)])

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
                            // step, 3.45 -> 3.01 at C4; at 6, which 24 KB of LDS allow, the same 5.5 ms:
                            // profiles/r04_ab_flow_ctx_warp_reflow_*.txt)
 #endif
+#ifndef WALDO_FCW_TP_INNER
+#define WALDO_FCW_TP_INNER 0  // the Tp units of a (clip, context) innermost in an XCD's tile walk (hd_pixel_rows_grouped)
+#endif
 #ifndef WALDO_FCW_REFLOW
 #define WALDO_FCW_REFLOW 1  // the upsampled flow of a layer is taken AGAIN where its composited alpha is known (active layers only)
                             // instead of kept per layer: 2 LP registers fewer across the occlusion product
@@ -211,7 +214,11 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
   int m, x, y_first;  // m = (b, tc, tp)
+#if WALDO_FCW_TP_INNER
+  if (!hd_pixel_rows_grouped<R>(units / Tp, Tp, Hd, Wd, tiles, nbands, m, x, y_first)) return;
+#else
   if (!hd_pixel_rows<R>(units, Hd, Wd, tiles, nbands, m, x, y_first)) return;
+#endif
   const int tp = m % Tp, b = m / (Tc * Tp);
   const float rscale = 1.0f / (float)scale;
   // frame of the context alpha (clamped: the index comes from device memory) and of the order
@@ -500,6 +507,9 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
 #ifndef WALDO_FWF_BANDS
 #define WALDO_FWF_BANDS 8
 #endif
+#ifndef WALDO_FWF_TP_INNER
+#define WALDO_FWF_TP_INNER 1  // the Tp predicted frames of a clip innermost in an XCD's tile walk (HdTile::pixel_grouped)
+#endif
 #ifndef WALDO_FWF_NT
 #define WALDO_FWF_NT 1  // non-temporal stores for out / raw (read next by another kernel, far larger than any cache): -3.5 %
 #endif
@@ -525,7 +535,11 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     int units, int tiles, int nbands) {
   const int64_t HWd = (int64_t)Hd * Wd;
   int n, x, y;  // n = (b, tp)
+#if WALDO_FWF_TP_INNER
+  if (!HdTile<WALDO_FWF_TILE_COLS>::pixel_grouped(units / Tp, Tp, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
+#else
   if (!HdTile<WALDO_FWF_TILE_COLS>::pixel(units, Hd, Wd, tiles, nbands, n, x, y) || x >= Wd || y >= Hd) return;
+#endif
   const int b = n / Tp, tp = n % Tp;
   const int64_t p = (int64_t)y * Wd + x;
   float gx0, gy0;
@@ -666,6 +680,248 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
   obase[(int64_t)C * HWd] = acc;
 }
 
+// The same pass with the contexts' FOOTPRINTS STAGED IN LDS.  Timing-only ablations of the kernel above at the Cityscapes
+// recipe (10.4 ms per pipeline step): 6.8 ms with one coalesced load in place of a context's two pair gathers, 6.5
+// without the per-context stores, 2.6 without both -- the stores run at the HBM write rate, the gathers cost as much
+// again although the bytes behind them are few (fetch 7.8 GB per launch against 11.7 GB written, rocprofv3): 184
+// divergent 8-byte gathers per wavefront, every one a handful of cache-line look-ups, the four wavefronts of a
+// tile each pulling the rows they share.  Here a workgroup (an 8 x 32 tile) takes, per context, the BOX of its
+// pixels' pair origins -- block-wide min / max of the clamped rows and columns, packed 16-bit, one barrier --
+// and, where the box holds at most 1024 texels (91 % of all (tile, context) pairs under real flows,
+// profiles/r04_fwf_boxes_*; per context and uniform: the others gather as above), loads it channel by channel as
+// ONE 16-byte load per thread (columns from a multiple of four: needs Wd % 4 == 0), parks it in a 4 KB LDS image and
+// reads the taps from there -- four coalesced loads per thread and channel instead of eight gathers, every line
+// requested once per tile.  Channel c + 1's loads are in flight while channel c is sampled and stored; two LDS-only
+// barriers per channel (no vmcnt wait: the stores keep draining).  Same taps, weights and arithmetic: same bits.
+#ifndef WALDO_FWF_LDS
+#define WALDO_FWF_LDS 1
+#endif
+constexpr int kFwfCap = 1024;  // texels of one context's staged box = one float4 per thread
+// FULL: Tc == TCP and no `include_self` -- every vector-memory operation of the channel loop is then unconditional,
+// and the wait for channel c + 1's box can leave channel c's stores in flight (with a store behind a branch the
+// compiler must assume it was not issued and waits for everything: gathers and stores take turns again).
+template <int TCP, bool FULL>
+__global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
+    const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
+    const float* __restrict__ score, const int64_t* __restrict__ ctx_ts, float* __restrict__ out,
+    float* __restrict__ raw, int T, int Tc_, int Tp, int C, int L, int Hd, int Wd, int include_self_, float eps,
+    int units, int tiles, int nbands) {
+  typedef float f32x2_fw __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  static_assert(kBlock * 4 == kFwfCap, "one float4 of the box per thread");
+  const int Tc = FULL ? TCP : Tc_;
+  const bool include_self = FULL ? false : include_self_ != 0;
+  const int64_t HWd = (int64_t)Hd * Wd;
+  int n, x, y;  // n = (b, tp)
+  if (!HdTile<32>::pixel_grouped(units / Tp, Tp, Hd, Wd, tiles, nbands, n, x, y)) return;  // (uniform)
+  // a thread beyond the right / bottom edge works on the tile's last pixel of its row / column: it computes and
+  // stores the same values to the same addresses as that pixel's own thread (no branch around the stores, every
+  // thread reaches the barriers, the box is that of the live pixels)
+  x = min(x, Wd - 1);
+  y = min(y, Hd - 1);
+  const int b = n / Tp, tp = n % Tp;
+  const int64_t p = (int64_t)y * Wd + x;
+  const int t = (int)threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+  float gx0, gy0;
+  identity_grid(x, y, Wd, Hd, gx0, gy0);
+  __shared__ __attribute__((aligned(16))) float img[TCP][kFwfCap];
+  __shared__ int wbox[kBlock / kWave][TCP][2];
+
+  const int Tcx = Tc + (include_self ? 1 : 0);
+  uint32_t ob0[TCP], ob1[TCP];  // byte offsets of the two pair origins: in the context's LDS image, or in the plane
+  int shift[TCP];
+  float w00[TCP], w01[TCP], w10[TCP], w11[TCP], sc[TCP];
+  int cyx0[TCP], cy1v[TCP];  // (clamped row y0, pair origin xb) packed; clamped row y1
+  const float* frame[TCP];
+  float ssum = 0.0f;
+  bool shifted = false;
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) {
+    const int tcc = min(tc, Tc - 1);  // (a padding context repeats context Tc - 1 and is never stored or summed)
+    const bool real = tc < Tc;
+    const int64_t m = ((int64_t)b * Tc + tcc) * Tp + tp;
+    const float* fl = flow + m * 2 * HWd + p;
+    const Taps tp4 = make_taps(gx0 + fl[0], gy0 + fl[HWd], Hd, Wd);
+    const int xb = min(max(tp4.x0, 0), Wd - 2);
+    const int cy0 = min(max(tp4.y0, 0), Hd - 1), cy1 = min(max(tp4.y0 + 1, 0), Hd - 1);
+    cyx0[tc] = (cy0 << 16) | xb;
+    cy1v[tc] = cy1;
+    shift[tc] = tp4.x0 - xb;
+    shifted |= shift[tc] != 0;
+    w00[tc] = tp4.w00;
+    w01[tc] = tp4.w01;
+    w10[tc] = tp4.w10;
+    w11[tc] = tp4.w11;
+    // the box of this wavefront: (row, column) pairs packed 16 + 16 bits (Hd, Wd < 32768), six exchange steps
+    s16x2 lo = {(short)cy0, (short)xb}, hi = {(short)cy1, (short)(xb + 1)};
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int olo = __shfl_xor(__builtin_bit_cast(int, lo), d, kWave), ohi = __shfl_xor(__builtin_bit_cast(int, hi), d, kWave);
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, olo));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, ohi));
+    }
+    if (lane == 0) {
+      wbox[wave][tc][0] = __builtin_bit_cast(int, lo);
+      wbox[wave][tc][1] = __builtin_bit_cast(int, hi);
+    }
+    const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)));  // wave-uniform
+    frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
+    float sv = 0.0f;
+    if (score != nullptr) {
+      sv = score[m * HWd + p];
+    } else {
+      const float* al = alpha + m * L * HWd + p;
+      float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + tcc) * (C + L) + C) * HWd + p;
+      for (int l = 0; l < L; ++l) {
+        const float av = al[(int64_t)l * HWd];
+        sv += (av + 1.0f) / 2.0f;
+        if (real) fwf_store(rw + (int64_t)l * HWd, av);
+      }
+    }
+    sc[tc] = sv;
+    ssum += real ? fabsf(sv + eps) : 0.0f;
+  }
+  if (include_self) {
+    float* rw = raw + ((((int64_t)b * Tp + tp) * Tcx + Tc) * (C + L) + C) * HWd + p;
+    for (int l = 0; l < L; ++l) fwf_store(rw + (int64_t)l * HWd, 1.0f);
+    ssum += fabsf(1.0f + eps);
+  }
+  lds_barrier();
+  // ---- per context (uniform): the tile's box, whether it fits, this thread's float4 of it
+  bool all_staged = true;  // (uniform) every context's box fits its image: otherwise the WHOLE tile gathers
+  unsigned mine = 0;       // bit tc: this thread's float4 lies inside the context's box (it is loaded all the same)
+  uint32_t goff[TCP];      // float index of that float4 in a plane of the context's frame
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) {
+    s16x2 lo = __builtin_bit_cast(s16x2, wbox[0][tc][0]), hi = __builtin_bit_cast(s16x2, wbox[0][tc][1]);
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, wbox[w][tc][0]));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, wbox[w][tc][1]));
+    }
+    const int ylo = __builtin_amdgcn_readfirstlane((int)lo[0]), xlo = __builtin_amdgcn_readfirstlane((int)lo[1]) & ~3;
+    const int yhi = __builtin_amdgcn_readfirstlane((int)hi[0]), xhi = __builtin_amdgcn_readfirstlane((int)hi[1]);
+    const int pitch4 = (xhi - xlo + 4) >> 2, nrows = yhi - ylo + 1;  // float4s per row (xlo + 4 pitch4 <= Wd: Wd % 4 == 0)
+    const int n4 = nrows * pitch4;
+    all_staged &= n4 <= kBlock;
+    // t < 256, the + 0.5: the approximate reciprocal gives the exact quotient (pitch4 <= 256 where it matters)
+    const int r = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)pitch4));
+    if (t < n4) mine |= 1u << tc;
+    // (a thread past the box re-reads a float4 of its last row: in bounds, never written to the image)
+    goff[tc] = (uint32_t)(__mul24(ylo + min(r, nrows - 1), Wd) + xlo + 4 * min(max(t - r * pitch4, 0), pitch4 - 1));
+    const int cy0 = cyx0[tc] >> 16, xb = cyx0[tc] & 0xffff, pitch = 4 * pitch4;
+    ob0[tc] = (uint32_t)(__mul24(cy0 - ylo, pitch) + (xb - xlo)) * 4u;
+    ob1[tc] = (uint32_t)(__mul24(cy1v[tc] - ylo, pitch) + (xb - xlo)) * 4u;
+  }
+  const float den = fmaxf(ssum, 1e-12f);
+  const float wself = (1.0f + eps) / den;
+  float wt[TCP];
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) wt[tc] = (tc < Tc) ? (sc[tc] + eps) / den : 0.0f;
+  const float* self = input + ((int64_t)b * T + min(tp, T - 1)) * C * HWd + p;
+  float* rbase = raw + ((int64_t)b * Tp + tp) * Tcx * (C + L) * HWd + p;  // context tc: + tc * (C+L) * HWd
+  float* obase = out + ((int64_t)b * Tp + tp) * (C + 1) * HWd + p;
+  const bool any_shift = __ballot(shifted) != 0ull;  // wave-uniform
+  // corners of the footprint from the pair elements (see the kernel above); a no-op for interior wavefronts
+  auto assign = [&](float (&v)[TCP][4]) {
+    if (any_shift) {
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) {
+        const float a0 = v[tc][0], a1 = v[tc][1], b0 = v[tc][2], b1 = v[tc][3];
+        v[tc][0] = shift[tc] > 0 ? a1 : a0;
+        v[tc][1] = shift[tc] < 0 ? a0 : a1;
+        v[tc][2] = shift[tc] > 0 ? b1 : b0;
+        v[tc][3] = shift[tc] < 0 ? b0 : b1;
+      }
+    }
+  };
+  auto fuse_store = [&](int c, const float (&v4)[TCP][4]) {
+    const float vself = include_self ? self[(int64_t)c * HWd] : 0.0f;
+    float acc = 0.0f;
+#pragma unroll
+    for (int tc = 0; tc < TCP; ++tc) {
+      const float v = fmaf(v4[tc][3], w11[tc], fmaf(v4[tc][2], w10[tc], fmaf(v4[tc][1], w01[tc], v4[tc][0] * w00[tc])));
+      if (FULL || tc < Tc) fwf_store(rbase + ((int64_t)tc * (C + L) + c) * HWd, v);
+      acc += v * wt[tc];
+    }
+    if (include_self) {
+      fwf_store(rbase + ((int64_t)Tc * (C + L) + c) * HWd, vself);
+      acc += vself * wself;
+    }
+    fwf_store(obase + (int64_t)c * HWd, acc);
+  };
+  if (all_staged) {
+    f32x4 box4[TCP];
+    auto issue = [&](int c) {  // this thread's float4 of every box, channel c
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) box4[tc] = *reinterpret_cast<const f32x4*>(frame[tc] + (int64_t)c * HWd + goff[tc]);
+    };
+    auto park = [&]() {
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc)
+        if ((mine >> tc) & 1u) *reinterpret_cast<f32x4*>(&img[tc][4 * t]) = box4[tc];
+    };
+    issue(0);
+    park();
+    lds_barrier();
+    for (int c = 0; c < C; ++c) {
+      issue(min(c + 1, C - 1));  // in flight while channel c is sampled and stored (the last trip re-reads its own)
+      float tv[TCP][4];
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) {
+        const char* im = reinterpret_cast<const char*>(&img[tc][0]);
+        tv[tc][0] = *reinterpret_cast<const float*>(im + ob0[tc]);
+        tv[tc][1] = *reinterpret_cast<const float*>(im + ob0[tc] + 4);
+        tv[tc][2] = *reinterpret_cast<const float*>(im + ob1[tc]);
+        tv[tc][3] = *reinterpret_cast<const float*>(im + ob1[tc] + 4);
+      }
+      assign(tv);
+      fuse_store(c, tv);
+      lds_barrier();  // every thread has read channel c's taps
+      park();         // (waits for the boxes of channel c + 1, not for channel c's stores)
+      lds_barrier();
+    }
+  } else {
+    // some context's box is too large for its image (a folded or strongly sheared warp): the pair gathers of the
+    // kernel above for the whole tile, software-pipelined the same way
+#pragma unroll
+    for (int tc = 0; tc < TCP; ++tc) {
+      const int cy0 = cyx0[tc] >> 16, xb = cyx0[tc] & 0xffff;
+      ob0[tc] = (uint32_t)(__mul24(cy0, Wd) + xb) * 4u;
+      ob1[tc] = (uint32_t)(__mul24(cy1v[tc], Wd) + xb) * 4u;
+    }
+    float tv[TCP][4];
+    auto load_taps = [&](int c, float (&v)[TCP][4]) {
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) {
+        const float* plane = frame[tc] + (int64_t)c * HWd;
+        const f32x2_fw top = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob0[tc]);
+        const f32x2_fw bot = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob1[tc]);
+        v[tc][0] = top[0];
+        v[tc][1] = top[1];
+        v[tc][2] = bot[0];
+        v[tc][3] = bot[1];
+      }
+    };
+    load_taps(0, tv);
+    for (int c = 0; c < C; ++c) {
+      float nv[TCP][4];
+      load_taps(min(c + 1, C - 1), nv);
+      assign(tv);
+      fuse_store(c, tv);
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[tc][k] = nv[tc][k];
+    }
+  }
+  float acc = 0.0f;  // the score channel
+#pragma unroll
+  for (int tc = 0; tc < TCP; ++tc) acc += (sc[tc] * 2.0f - 1.0f) * wt[tc];
+  if (include_self) acc += wself;  // (1 * 2 - 1) * w
+  obase[(int64_t)C * HWd] = acc;
+}
+
 static int check_flow_ctx(const char* fn, int64_t N, int L, int H, int W, int scale) {
   // (W * scale >= 2: the gathers read the two taps of a row as one 8-byte pair inside the row, pair_taps())
   if (N < 0 || L < 1 || L > 32 || H < 1 || W < 1 || scale < 1 || scale > 64 || (int64_t)W * scale < 2 ||
@@ -723,7 +979,7 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 }
 
 #define WALDO_FCW_LAUNCH(LPV, SC, RV)                                                                          \
-  hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,    \
+  hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV>), dim3((unsigned)fcw_grid), dim3(kBlock), 0, st,    \
                      flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc, alpha_max, \
                      T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
 #define WALDO_FCW_CASE(LPV)                                        \
@@ -769,7 +1025,17 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
     return cells <= kBlock && cells * cell_floats <= fcw_cap(lp, r);
   };
   const int rows = scale < 2 ? 1 : (fits(kFcwRows) ? kFcwRows : (fits(2) ? 2 : 1));
-  const HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
+  HdGeom geom = hd_geom_rows(N, H * scale, W * scale, rows);
+#if WALDO_FCW_TP_INNER
+  geom.nbands = 8;
+  const int64_t fcw_grid = xcd_grid_banded((int64_t)B * Tc, geom.nbands, geom.tiles, Tp);
+#else
+  const int64_t fcw_grid = hd_grid(N, geom);
+#endif
+  if (fcw_grid > 2147483647) {
+    set_error("%s: problem too large for one launch", fn);
+    return WALDO_EINVAL;
+  }
   switch (flow_ctx_pad_l(L)) {
     WALDO_FCW_CASE(4)
     WALDO_FCW_CASE(8)
@@ -831,16 +1097,32 @@ static int frame_warp_fuse_launch(const char* fn, const float* input, const floa
   // closely (the frames of one clip, 193 MB at the Cityscapes recipe, are what the 256 MiB Infinity Cache can hold).
   // A/B on one box: 10.94 -> 10.59 ms per C5 pipeline step (-3 %).
   geom.nbands = WALDO_FWF_BANDS;
-  if (hd_grid(units, geom) > 2147483647) {
+  if (hd_grid(units, geom) > 2147483647 || xcd_grid_banded(B, geom.nbands, geom.tiles, Tp) > 2147483647) {
     set_error("%s: problem too large for one launch", fn);
     return WALDO_EINVAL;
   }
-  if (B == 0) return WALDO_OK;
+  if (units == 0) return WALDO_OK;
   if (!input || !flow || (!alpha && !score) || !ctx_ts || !out || !raw) {
     set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
   }
+#if WALDO_FWF_TP_INNER
+  const dim3 grid((unsigned)xcd_grid_banded(B, geom.nbands, geom.tiles, Tp));
+#else
   const dim3 grid((unsigned)hd_grid(units, geom));
+#endif
+#if WALDO_FWF_LDS && WALDO_FWF_TP_INNER && WALDO_FWF_TILE_COLS == 32
+  // (16-byte loads of the boxes: rows that start on a multiple of four texels from a 16-byte aligned base)
+  if (Wd % 4 == 0 && (reinterpret_cast<uintptr_t>(input) & 15) == 0 && Tc <= 4) {
+    if (Tc == 4 && !include_self)
+      hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<4, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                         alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+    else
+      hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<4, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                         alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+    return launch_status(fn);
+  }
+#endif
   if (Tc <= 4)
     hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
                        alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);

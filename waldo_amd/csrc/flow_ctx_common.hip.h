@@ -205,6 +205,21 @@ __device__ __forceinline__ bool hd_pixel_rows(int units, int Hd, int Wd, int til
   return true;
 }
 
+// (units in groups of `inner` that share their sources, the members innermost in an XCD's tile walk: see
+// HdTile::pixel_grouped)
+template <int R>
+__device__ __forceinline__ bool hd_pixel_rows_grouped(int groups, int inner, int Hd, int Wd, int tiles, int nbands,
+                                                      int& unit, int& x, int& y) {
+  int tile, member, grp;
+  if (!xcd_decode_banded(blockIdx.x, groups, nbands, tiles, inner, grp, tile, member)) return false;
+  unit = grp * inner + member;
+  const int ntx = (Wd + kHdCols - 1) / kHdCols;
+  const int ty = tile / ntx;
+  x = (tile - ty * ntx) * kHdCols + (int)(threadIdx.x & (kWave - 1));
+  y = ty * (kHdRows * R) + (int)(threadIdx.x >> 6);
+  return true;
+}
+
 // The same with a workgroup of (256 / TC) x TC pixels, a wavefront covering 64 / TC rows of TC columns
 // (frame_warp_fuse: WALDO_FWF_TILE_COLS).
 template <int TC>
@@ -221,6 +236,21 @@ struct HdTile {
                                                int& y) {
     int tile, rest_;
     if (!xcd_decode_banded(blockIdx.x, units, nbands, tiles, 1, unit, tile, rest_)) return false;
+    const int ntx = (Wd + kCols - 1) / kCols;
+    const int ty = tile / ntx;
+    x = (tile - ty * ntx) * kCols + (int)(threadIdx.x & (kCols - 1));
+    y = ty * kRows + (int)(threadIdx.x / kCols);
+    return true;
+  }
+  // The same with the units in GROUPS of `inner` that share their sources (frame_warp_fuse: the Tp predicted frames of
+  // a clip gather from the same Tc context frames): a band of a group's tiles is pinned to an XCD and walked tile by
+  // tile with the group's members INNERMOST, so that the `inner` workgroups that read the same footprints run side
+  // by side behind one L2.  unit = group * inner + member.
+  __device__ static __forceinline__ bool pixel_grouped(int groups, int inner, int Hd, int Wd, int tiles, int nbands,
+                                                       int& unit, int& x, int& y) {
+    int tile, member, grp;
+    if (!xcd_decode_banded(blockIdx.x, groups, nbands, tiles, inner, grp, tile, member)) return false;
+    unit = grp * inner + member;
     const int ntx = (Wd + kCols - 1) / kCols;
     const int ty = tile / ntx;
     x = (tile - ty * ntx) * kCols + (int)(threadIdx.x & (kCols - 1));
