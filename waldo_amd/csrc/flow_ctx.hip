@@ -700,8 +700,15 @@ constexpr int kFwfCap = 1024;  // texels of one context's staged box = one float
 // FULL: Tc == TCP and no `include_self` -- every vector-memory operation of the channel loop is then unconditional,
 // and the wait for channel c + 1's box can leave channel c's stores in flight (with a store behind a branch the
 // compiler must assume it was not issued and waits for everything: gathers and stores take turns again).
+#ifndef WALDO_FWF_LDS_WAVES
+#define WALDO_FWF_LDS_WAVES 5
+#endif
+#ifndef WALDO_FWF_LDS_DB
+#define WALDO_FWF_LDS_DB 0  // 1: two sets of images, alternating by channel: one barrier per channel instead of two, 33 KB and four
+                            // waves per SIMD -- 9.17-9.42 against 9.09-9.19 ms per C5 step with one set at five waves (A/B)
+#endif
 template <int TCP, bool FULL>
-__global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
+__global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_lds_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
     const float* __restrict__ score, const int64_t* __restrict__ ctx_ts, float* __restrict__ out,
     float* __restrict__ raw, int T, int Tc_, int Tp, int C, int L, int Hd, int Wd, int include_self_, float eps,
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
   const int t = (int)threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
   float gx0, gy0;
   identity_grid(x, y, Wd, Hd, gx0, gy0);
-  __shared__ __attribute__((aligned(16))) float img[TCP][kFwfCap];
+  __shared__ __attribute__((aligned(16))) float img[WALDO_FWF_LDS_DB ? 2 : 1][TCP][kFwfCap];
   __shared__ int wbox[kBlock / kWave][TCP][2];
 
   const int Tcx = Tc + (include_self ? 1 : 0);
@@ -841,7 +848,9 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
 #pragma unroll
     for (int tc = 0; tc < TCP; ++tc) {
       const float v = fmaf(v4[tc][3], w11[tc], fmaf(v4[tc][2], w10[tc], fmaf(v4[tc][1], w01[tc], v4[tc][0] * w00[tc])));
+#ifndef WALDO_ABL_FWF_NORAW
       if (FULL || tc < Tc) fwf_store(rbase + ((int64_t)tc * (C + L) + c) * HWd, v);
+#endif
       acc += v * wt[tc];
     }
     if (include_self) {
@@ -850,26 +859,30 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
     }
     fwf_store(obase + (int64_t)c * HWd, acc);
   };
+#ifdef WALDO_ABL_FWF_ALLSTAGED  // timing-only ablation: no tile gathers (wrong values where a box does not fit)
+  all_staged = true;
+#endif
   if (all_staged) {
     f32x4 box4[TCP];
     auto issue = [&](int c) {  // this thread's float4 of every box, channel c
 #pragma unroll
       for (int tc = 0; tc < TCP; ++tc) box4[tc] = *reinterpret_cast<const f32x4*>(frame[tc] + (int64_t)c * HWd + goff[tc]);
     };
-    auto park = [&]() {
+    auto park = [&](int set) {
 #pragma unroll
       for (int tc = 0; tc < TCP; ++tc)
-        if ((mine >> tc) & 1u) *reinterpret_cast<f32x4*>(&img[tc][4 * t]) = box4[tc];
+        if ((mine >> tc) & 1u) *reinterpret_cast<f32x4*>(&img[set][tc][4 * t]) = box4[tc];
     };
     issue(0);
-    park();
+    park(0);
     lds_barrier();
     for (int c = 0; c < C; ++c) {
       issue(min(c + 1, C - 1));  // in flight while channel c is sampled and stored (the last trip re-reads its own)
+      const int set = WALDO_FWF_LDS_DB ? (c & 1) : 0;
       float tv[TCP][4];
 #pragma unroll
       for (int tc = 0; tc < TCP; ++tc) {
-        const char* im = reinterpret_cast<const char*>(&img[tc][0]);
+        const char* im = reinterpret_cast<const char*>(&img[set][tc][0]);
         tv[tc][0] = *reinterpret_cast<const float*>(im + ob0[tc]);
         tv[tc][1] = *reinterpret_cast<const float*>(im + ob0[tc] + 4);
         tv[tc][2] = *reinterpret_cast<const float*>(im + ob1[tc]);
@@ -877,8 +890,9 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_lds_kernel(
       }
       assign(tv);
       fuse_store(c, tv);
-      lds_barrier();  // every thread has read channel c's taps
-      park();         // (waits for the boxes of channel c + 1, not for channel c's stores)
+      if (!WALDO_FWF_LDS_DB) lds_barrier();  // every thread has read channel c's taps
+      park(WALDO_FWF_LDS_DB ? (set ^ 1) : 0);  // (waits for the boxes of channel c + 1, not for channel c's stores; the other
+                                               // set was last read before the previous trip's barrier)
       lds_barrier();
     }
   } else {
