@@ -249,6 +249,8 @@ int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, con
  *                             (B,Tc',Tp,...) tensor is the view raw.permute(0,2,1,3,4,5) (strides, no
  *                             copy), and WIF.forward's own permute + contiguous (wif.py:39) -- a copy of
  *                             the largest tensor of the pipeline -- finds it already in place
+ * Any Wd >= 2 and any alignment give the same bits; with Wd % 4 == 0, a 16-byte aligned `input` and Tc <= 4 the
+ * contexts' footprints are staged in LDS (16-byte loads) instead of gathered tap by tap.
  * ------------------------------------------------------------------------------------- */
 int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
                               const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
