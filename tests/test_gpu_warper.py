@@ -394,6 +394,34 @@ def test_flow_ctx_warp_skips_absent_layers_exactly(dev, poison, hw):
         assert gone > 0.4, gone
 
 
+@pytest.mark.parametrize("nl", [2, 4, 8, 12, 13, 17, 24])
+@pytest.mark.parametrize("scale,hw", [(1, (20, 70)), (2, (19, 40)), (3, (11, 30)), (4, (9, 20)), (5, (7, 15)), (8, (5, 9))])
+def test_flow_ctx_warp_tile_shapes_agree_with_the_launcher(dev, nl, scale, hw):
+    """flow_ctx_warp over the scales and layer counts that make its launcher pick different tiles (16 x 64, 8 x 64 or
+    4 x 64 pixels per workgroup, staged or not: `fits` in flow_ctx_warp_launch against the kernels' LDS images, which
+    the tall-tile instances take on trust) on rasters with ragged tiles: every output against the spelled-out
+    expression."""
+    from waldo_amd import functional as WF
+    h, w = hw
+    b, t, tc, tp, tw = 1, 3, 2, 2, 2
+    hd, wd = h * scale, w * scale
+    g = torch.Generator(device=dev).manual_seed(100 * nl + scale)
+    m = b * tc * tp
+    flow_lr = 0.05 * torch.randn(m, nl, 2, h, w, generator=g, device=dev)
+    isobj = (torch.rand(m, nl - 1, h, w, generator=g, device=dev) > 0.6).float() if nl > 1 else None
+    a01 = torch.rand(b * tw, nl, hd, wd, generator=g, device=dev)
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    ctx_ts = torch.randint(0, tw, (b, tc, tp), generator=g, device=dev)
+    pred_ts = torch.tensor([2, 0], device=dev)
+    with torch.no_grad():
+        flow, actx, dis, amax = WF.flow_ctx_warp(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=True)
+        rflow, ractx, rdis = _flow_ctx_warp_spelled_out(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, scale)
+    close(flow, rflow, what="flow")
+    close(actx, ractx, what="alpha_ctx")
+    close(dis, rdis, what="disocc")
+    close(amax, ractx.amax(dim=1), what="max")
+
+
 @pytest.mark.parametrize("poison", ["none", "occ", "dist", "logits", "alpha"])
 def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
     """The same short cuts in flow_ctx_alpha_kernel (layers whose upsampled alpha is 0 in all 64 lanes skip their
