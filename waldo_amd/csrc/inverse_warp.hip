@@ -358,20 +358,55 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   }
   __syncthreads();
   // ---- mask (1 = filled), erosion passes; kOut counts as filled (it is not part of the raster)
-  for (int c = threadIdx.x; c < cells; c += kBlock) m0[c] = fi[c] != 255;
+  // ROWS AS BITS where a region row has at most 64 cells (niter <= 7): row i of the mask is one 64-bit word (bit j =
+  // cell (i, j)), a second word marks its kOut cells, and an erosion pass is `m & (kout | (up & down & m << 1 & m >> 1))`
+  // on RH words -- the byte form below walks all ~2900 cells of the region per pass with six byte reads each
+  // (timing ablation at the KITTI recipe: 0.55 of the inversion's 2.5 ms per pipeline step were these passes).
+  // The same cells erode in the same passes: the same mask.  (The region's border cells are kOut: no row or column
+  // outside the words is ever needed.)
+  const bool bits = RW <= kWave;  // (uniform)
+  unsigned long long* rowm = reinterpret_cast<unsigned long long*>(m0 + ((8 - ((size_t)(m0 - smem) & 7)) & 7));
+  unsigned long long* rowk = rowm + 2 * RH;  // [2][RH] mask rows in turn, [RH] kOut rows: 24 RH bytes of the 2 cells
   unsigned char* mi = m0;
   unsigned char* mo = m1;
-  if (erode) {
-    for (int it = 0; it < n_pass; ++it) {
-      __syncthreads();
-      for (int c = threadIdx.x; c < cells; c += kBlock) {
-        unsigned char v = mi[c];
-        if (v && fi[c] != kOut && !(mi[c - RW] && mi[c + RW] && mi[c - 1] && mi[c + 1])) v = 0;
-        mo[c] = v;
+  int cur = 0;
+  if (bits) {
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int i = threadIdx.x >> 6; i < RH; i += kBlock / kWave) {
+      const unsigned char f = lane < RW ? fi[i * RW + lane] : (unsigned char)255;
+      const unsigned long long mrow = __ballot(lane < RW && f != 255), krow = __ballot(lane < RW && f == kOut);
+      if (lane == 0) {
+        rowm[i] = mrow;
+        rowk[i] = krow;
       }
-      unsigned char* t = mi;
-      mi = mo;
-      mo = t;
+    }
+    if (erode) {
+      for (int it = 0; it < n_pass; ++it) {
+        __syncthreads();
+        const int i = threadIdx.x;
+        if (i < RH) {
+          unsigned long long m = rowm[cur * RH + i];
+          if (i > 0 && i < RH - 1)
+            m &= rowk[i] | (rowm[cur * RH + i - 1] & rowm[cur * RH + i + 1] & (m << 1) & (m >> 1));
+          rowm[(cur ^ 1) * RH + i] = m;
+        }
+        cur ^= 1;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < cells; c += kBlock) m0[c] = fi[c] != 255;
+    if (erode) {
+      for (int it = 0; it < n_pass; ++it) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < cells; c += kBlock) {
+          unsigned char v = mi[c];
+          if (v && fi[c] != kOut && !(mi[c - RW] && mi[c + RW] && mi[c - 1] && mi[c + 1])) v = 0;
+          mo[c] = v;
+        }
+        unsigned char* t = mi;
+        mi = mo;
+        mo = t;
+      }
     }
   }
   __syncthreads();
@@ -381,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
     if (yp >= Hp || xp >= Wp) continue;
     const int c = (yp - oy) * RW + (xp - ox);
     fill_iter[b * HWp + yp * Wp + xp] = fi[c];
-    const bool m = mi[c] != 0;
+    const bool m = bits ? ((rowm[cur * RH + (yp - oy)] >> (xp - ox)) & 1ull) != 0 : mi[c] != 0;
     mask[b * HWp + yp * Wp + xp] = m ? 1 : 0;
     const int y = yp - pad, x = xp - pad;
     if (y >= 0 && y < H && x >= 0 && x < W) {
