@@ -302,9 +302,53 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   // (the two mask buffers, 2 * cells bytes, are not in use yet; fewer than cells - 1 cells can be on a ring)
   unsigned short* ring_list = reinterpret_cast<unsigned short*>(m0 + ((size_t)(m0 - smem) & 1));
   __shared__ int ring_count;
+  // The collection itself on BIT ROWS where a region row has at most 64 cells (see the erosion below): one word per row
+  // for the cells filled before the pass, one for the unfilled ones, and the ring of a pass is
+  // `unfilled & (filled << 1 | filled >> 1 | filled above | filled below)` -- three word reads per row instead of five
+  // byte reads per cell; a quarter row per thread then appends its set bits to the list.  The rows live behind the
+  // list in the two mask buffers: a ring holds at most 4/5 of the region's interior (every ring cell needs a filled
+  // neighbour, a filled cell has four), which leaves room for them from niter = 3 up (checked; else the byte scan).
+  const bool bits = RW <= kWave;  // (uniform)
+  unsigned long long* frow = reinterpret_cast<unsigned long long*>(m0 + ((2 * cells - 24 * RH) & ~7) - ((size_t)(m0 - smem) & 7));
+  unsigned long long* urow = frow + RH;  // frow: filled before this pass; urow: unfilled; rrow: this pass's ring
+  unsigned long long* rrow = urow + RH;
+  const int ring_cap = (int)((reinterpret_cast<unsigned char*>(frow) - reinterpret_cast<unsigned char*>(ring_list)) / 2);
+  const bool bit_rings = bits && 4 * RH <= kBlock && 5 * ring_cap >= 4 * (RW - 2) * (RH - 2) &&
+                         reinterpret_cast<unsigned char*>(rrow + RH) <= m0 + 2 * cells;  // (uniform)
+  if (bit_rings && n_pass > 0) {
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int i = threadIdx.x >> 6; i < RH; i += kBlock / kWave) {
+      const unsigned char f = lane < RW ? fi[i * RW + lane] : kOut;
+      const unsigned long long fr = __ballot(f == 0), ur = __ballot(f == 255);
+      if (lane == 0) {
+        frow[i] = fr;
+        urow[i] = ur;
+      }
+    }
+  }
   for (int it = 1; it <= n_pass; ++it) {
     if (threadIdx.x == 0) ring_count = 0;
     __syncthreads();
+    if (bit_rings) {
+      const int i = threadIdx.x >> 2, q = threadIdx.x & 3;
+      if (i > 0 && i < RH - 1) {  // (the border rows are kOut: never unfilled)
+        const unsigned long long f = frow[i];
+        const unsigned long long ring = urow[i] & ((f << 1) | (f >> 1) | frow[i - 1] | frow[i + 1]);
+        if (q == 0) rrow[i] = ring;
+        unsigned seg = (unsigned)(ring >> (16 * q)) & 0xffffu;
+        if (seg) {
+          int at = atomicAdd(&ring_count, __popc(seg));
+          while (seg) {
+            const int j = __ffs((int)seg) - 1;
+            seg &= seg - 1;
+            if (at < ring_cap) ring_list[at] = (unsigned short)(i * RW + 16 * q + j);  // (the bound holds: see above)
+            ++at;
+          }
+        }
+      } else if (q == 0 && i < RH) {
+        rrow[i] = 0ull;
+      }
+    } else
     for (int c0 = threadIdx.x; c0 < cells; c0 += kBlock * kLB) {
       unsigned char s0[kLB], sn[kLB][4];
 #pragma unroll
@@ -326,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
       }
     }
     __syncthreads();
-    const int nring = ring_count;
+    const int nring = bit_rings ? min(ring_count, ring_cap) : ring_count;
     for (int e = threadIdx.x; e < nring; e += kBlock) {
       const int c = ring_list[e];
       unsigned char nf[9];
@@ -355,6 +399,11 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nring; e += kBlock) fi[ring_list[e]] = (unsigned char)it;
+    if (bit_rings && (int)threadIdx.x < RH) {  // the cells of this pass count as filled from the next one on
+      const unsigned long long ring = rrow[threadIdx.x];
+      frow[threadIdx.x] |= ring;
+      urow[threadIdx.x] &= ~ring;
+    }
   }
   __syncthreads();
   // ---- mask (1 = filled), erosion passes; kOut counts as filled (it is not part of the raster)
@@ -364,7 +413,6 @@ __global__ __launch_bounds__(kBlock) void iw_fused_kernel(
   // (timing ablation at the KITTI recipe: 0.55 of the inversion's 2.5 ms per pipeline step were these passes).
   // The same cells erode in the same passes: the same mask.  (The region's border cells are kOut: no row or column
   // outside the words is ever needed.)
-  const bool bits = RW <= kWave;  // (uniform)
   unsigned long long* rowm = reinterpret_cast<unsigned long long*>(m0 + ((8 - ((size_t)(m0 - smem) & 7)) & 7));
   unsigned long long* rowk = rowm + 2 * RH;  // [2][RH] mask rows in turn, [RH] kOut rows: 24 RH bytes of the 2 cells
   unsigned char* mi = m0;
