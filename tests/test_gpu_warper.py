@@ -84,11 +84,15 @@ def test_inverse_warp_num_perm_random(dev):
 
 
 @pytest.mark.parametrize("cfg", [(8, 8, 16, 32, 5, True), (16, 32, 16, 32, 5, False), (64, 64, 128, 256, 5, True),
-                                 (7, 9, 13, 21, 3, True), (8, 8, 8, 8, 0, False), (4, 4, 40, 40, 8, True)])
+                                 (7, 9, 13, 21, 3, True), (8, 8, 8, 8, 0, False), (4, 4, 40, 40, 8, True),
+                                 (16, 16, 40, 70, 1, True), (16, 32, 40, 70, 2, True), (8, 8, 40, 70, 6, True),
+                                 (6, 6, 70, 40, 7, True)])
 def test_inverse_warp_random(dev, cfg):
     """Object- and background-shaped maps (incl. the recipe's 64x64 -> 128x256), ragged sizes,
     niter 0 and > 5, strong shrink (most of the target unfilled) -- bit-level cell decisions
-    (round-half-even, lowest index wins) make any slip an O(1) error."""
+    (round-half-even, lowest index wins) make any slip an O(1) error.  niter 1 .. 8 cover the forms the one-launch
+    kernel takes its passes in: bit rows for the erosion and the rings (3 .. 7), bit rows for the erosion alone
+    (1, 2: the rings' rows do not fit behind the list), bytes (8: a region row is wider than 64 cells)."""
     import waldo_amd
     hs, ws, ht, wt, niter, erode = cfg
     torch.manual_seed(hs * 31 + wt)
