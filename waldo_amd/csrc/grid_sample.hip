@@ -111,6 +111,41 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
 // (93 % of them at the LVD recipe), alone or per step of the four-pixel form, changes nothing either (56 us): the
 // kernel is not waiting for its taps.  Per pixel the arithmetic is that of the kernel above.
 typedef float f32x4_gs __attribute__((ext_vector_type(4)));
+typedef float f32x2_gs __attribute__((ext_vector_type(2)));
+
+// Round 4, two things about the taps.  (1) The two taps of a row are ONE 8-byte load at the pair origin xb =
+// clamp(x0, 0, Wi - 2) (4-byte aligned: gfx950 takes unaligned dwordx2 loads): half the gather instructions; within one
+// texel of the left / right border the pair sits a column off the footprint and its elements are re-assigned to the
+// corners (pair_value() of flow_ctx_common.hip.h, restated on a Taps: the same bits as tap_sample()).  (2) A wavefront
+// none of whose 256 pixels has a corner inside the input -- object canvases warped into the frame cover a part of it
+// -- loads nothing: zeros-padding gives exactly `- delta` there.  At the KITTI recipe the warp of the object flows
+// writes 1.3 GB per call and took 0.55 ms.
+#ifndef WALDO_GS_PAIRS
+#define WALDO_GS_PAIRS 1
+#endif
+struct PairOff {
+  uint32_t ob0, ob1;
+  int shift;  // x0 - xb: -1 / 0 / +1 (beyond that every corner is invalid)
+};
+__device__ __forceinline__ PairOff pair_off(const Taps& t, int Hi, int Wi) {
+  const int xb = min(max(t.x0, 0), Wi - 2);
+  const int cy0 = min(max(t.y0, 0), Hi - 1), cy1 = min(max(t.y0 + 1, 0), Hi - 1);
+  PairOff q;
+  q.ob0 = (uint32_t)(__mul24(cy0, Wi) + xb) * 4u;
+  q.ob1 = (uint32_t)(__mul24(cy1, Wi) + xb) * 4u;
+  q.shift = t.x0 - xb;
+  return q;
+}
+// tap_sample(plane, t) from the two pairs: the corner values picked from the pair elements, then its operations
+__device__ __forceinline__ float pair_sample(const f32x2_gs a, const f32x2_gs b, const Taps& t, int shift) {
+  const float p00 = shift > 0 ? a[1] : a[0], p01 = shift < 0 ? a[0] : a[1];
+  const float p10 = shift > 0 ? b[1] : b[0], p11 = shift < 0 ? b[0] : b[1];
+  const float v00 = p00 * (t.vx0 * t.vy0), v01 = p01 * (t.vx1 * t.vy0);
+  const float v10 = p10 * (t.vx0 * t.vy1), v11 = p11 * (t.vx1 * t.vy1);
+  const float top = fmaf(t.fx, v01 - v00, v00);
+  const float bot = fmaf(t.fx, v11 - v10, v10);
+  return fmaf(t.fy, bot - top, top);
+}
 
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
@@ -130,16 +165,44 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
   const float* in = input + in_index(n, outer_div, inner) * C * HWi;
   float* out = output + os.slot(n) * C * HWo + p;
   float shift[4];
+  bool touches = false;  // some corner of some pixel of this lane lies inside the input
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float wsum = (t[q].w00 + t[q].w01) + (t[q].w10 + t[q].w11);
     shift[q] = fmaf(delta, wsum, -delta);
+    touches |= (t[q].vx0 + t[q].vx1) * (t[q].vy0 + t[q].vy1) != 0.0f;
   }
-  for (int c = 0; c < C; ++c) {
-    f32x4_gs o;
+  const bool pairs = WALDO_GS_PAIRS && Wi >= 2;  // (uniform)
+  if (pairs && __ballot(touches) == 0ull) {      // (wave-uniform) every corner outside: 0 * texel + shift
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = (f32x4_gs){shift[0], shift[1], shift[2], shift[3]};
+    if (mask_out != nullptr) *reinterpret_cast<f32x4_gs*>(mask_out + n * HWo + p) = (f32x4_gs){0.0f, 0.0f, 0.0f, 0.0f};
+    return;
+  }
+  if (pairs) {
+    PairOff po[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = tap_sample(in + (int64_t)c * HWi, t[q]) + shift[q];
-    *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
+    for (int q = 0; q < 4; ++q) po[q] = pair_off(t[q], Hi, Wi);
+    for (int c = 0; c < C; ++c) {
+      const char* plane = reinterpret_cast<const char*>(in + (int64_t)c * HWi);
+      f32x2_gs a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = *reinterpret_cast<const f32x2_gs*>(plane + po[q].ob0);
+        b[q] = *reinterpret_cast<const f32x2_gs*>(plane + po[q].ob1);
+      }
+      f32x4_gs o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = pair_sample(a[q], b[q], t[q], po[q].shift) + shift[q];
+      *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
+    }
+  } else {
+    for (int c = 0; c < C; ++c) {
+      f32x4_gs o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = tap_sample(in + (int64_t)c * HWi, t[q]) + shift[q];
+      *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
+    }
   }
   if (mask_out != nullptr) {
     f32x4_gs o;
