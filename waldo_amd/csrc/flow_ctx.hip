@@ -301,7 +301,10 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   // "Exact" needs finite operands: 0 * inf would have been NaN.  A non-finite entry of the order or of the tile's
   // low-resolution flows (`dense`, voted at the barrier above) or a non-finite sampled alpha in any lane (`wild`,
   // below) switches everything back to all L layers and all L x L factors, so NaNs propagate exactly as before.
-  float a[LP], fx[WALDO_FCW_REFLOW ? 1 : LP], fy[WALDO_FCW_REFLOW ? 1 : LP];
+  // (the tall tiles only: at one pixel per thread the low-resolution taps may come from memory -- the LVD recipe, where
+  // every layer is active -- and taking them twice costs 34 more loads per pixel: 55 -> 71 us per call there)
+  constexpr bool kReflow = WALDO_FCW_REFLOW && R > 1;
+  float a[LP], fx[kReflow ? 1 : LP], fy[kReflow ? 1 : LP];
   float dis = -INFINITY;
   const float* ap0 = a01 + (((int64_t)b * Tw + ts) * L) * HWd;  // plane of layer l: + min(l, L - 1) * HWd
   unsigned active = 0;  // wave-uniform: bit l = some lane has a[l] != 0
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
             fyl = up_sample(fl + HW, ut);
           }
         }
-        if (!WALDO_FCW_REFLOW) fx[l] = fxl, fy[l] = fyl;
+        if (!kReflow) fx[l] = fxl, fy[l] = fyl;
         if (want) {
           need |= 1u << k;
           pt[k] = pair_taps(gx0 + fxl, gy0 + fyl, Hd, Wd, inter[k]);
@@ -438,9 +441,9 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (j + k >= LP) break;
-      if (!(WALDO_FCW_CONST_OUT || WALDO_FCW_REFLOW) || (active & (1u << (j + k)))) {  // wave-uniform
+      if (!(WALDO_FCW_CONST_OUT || kReflow) || (active & (1u << (j + k)))) {  // wave-uniform
         const float v = a[j + k] * prd[k >> 1][k & 1];
-        if (WALDO_FCW_REFLOW) {
+        if (kReflow) {
           // the layer's upsampled flow again (the same expressions as in the sampling loop: the same bits), for the
           // 2-4 layers present in this wavefront's pixels; every layer when the tile is dense / wild
           asm volatile("");  // (a real branch, as above)

@@ -50,14 +50,36 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
   for (int c = 0; c < C; ++c) out[(int64_t)c * HWo] = tap_sample(in + (int64_t)c * HWi, t) + shift;
 }
 
+// Sum of v over the lanes from this one to the end of its RUN (consecutive lanes with the same scatter address;
+// `stop`: the run ends at this lane -- lane 63 always).  After the step of distance d a lane that has not met its
+// run's end has summed d more lanes, all of its run, so lane + d exists: no range check.
+__device__ __forceinline__ float run_sum(float v, bool stop) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const float vo = __shfl_down(v, d, kWave);
+    const int so = __shfl_down((int)stop, d, kWave);
+    if (!stop) {
+      v += vo;
+      stop = so != 0;
+    }
+  }
+  return v;
+}
+
+#ifndef WALDO_GS_RUNS
+#define WALDO_GS_RUNS 1  // the scatter of grad_input summed over runs of equal addresses inside a wavefront first
+#endif
 __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid,
     const float* __restrict__ grad_output, float* __restrict__ grad_input,
     float* __restrict__ grad_grid, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles,
     float delta, int64_t outer_div, int64_t inner) {
   const int64_t n = blockIdx.x / tiles;
-  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
-  if (p >= HWo) return;
+  const int64_t p_ = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  // (a thread past the last pixel works on the last one with zero weights: it takes part in the wavefront's sums)
+  const bool live = p_ < HWo;
+  if (!WALDO_GS_RUNS && !live) return;
+  const int64_t p = live ? p_ : HWo - 1;
   const float2 g = *reinterpret_cast<const float2*>(grid + (n * HWo + p) * 2);
   const Taps t = make_taps(g.x, g.y, Hi, Wi);
   const int64_t HWi = (int64_t)Hi * Wi;
@@ -66,6 +88,26 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
   const float* go = grad_output + n * C * HWo + p;
   float gix = 0.0f, giy = 0.0f;
   const float m00 = t.vx0 * t.vy0, m01 = t.vx1 * t.vy0, m10 = t.vx0 * t.vy1, m11 = t.vx1 * t.vy1;
+  // ---- the scatter.  A wavefront is 64 consecutive output pixels; where the output is finer than the input (object
+  // canvases of 64 x 64 warped into a 128 x 256 frame) neighbouring pixels hit the same input texel and their float
+  // atomics queue up at one address: the kernel is bound by them (58 us per call at the LVD recipe, 18 with the
+  // scatter compiled out).  Runs of equal addresses in consecutive lanes are summed with shuffles first and the
+  // run's first lane issues ONE atomic (an address that comes back later in the wavefront starts a new run: still
+  // correct).  Sums in a different order than one atomic per lane -- which had no fixed order either.
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t key[4] = {t.o00, t.o01, t.o10, t.o11};
+  const float wq[4] = {live ? t.w00 : 0.0f, live ? t.w01 : 0.0f, live ? t.w10 : 0.0f, live ? t.w11 : 0.0f};
+  bool stop[4], head[4];
+  const bool scatter = grad_input != nullptr &&
+                       (!WALDO_GS_RUNS || __ballot(wq[0] != 0.0f || wq[1] != 0.0f || wq[2] != 0.0f || wq[3] != 0.0f) != 0ull);
+  if (WALDO_GS_RUNS && scatter) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t nxt = (uint32_t)__shfl_down((int)key[q], 1, kWave), prv = (uint32_t)__shfl_up((int)key[q], 1, kWave);
+      stop[q] = lane == kWave - 1 || nxt != key[q];
+      head[q] = lane == 0 || prv != key[q];
+    }
+  }
   for (int c = 0; c < C; ++c) {
     const float gv = go[(int64_t)c * HWo];
     if (grad_grid != nullptr) {
@@ -79,16 +121,21 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
       giy = fmaf(gv, bot - top, giy);
     }
 #ifndef WALDO_ABL_GS_NOATOMIC  // timing-only ablation: without the scatter
-    if (grad_input != nullptr) {
+    if (scatter) {  // (wave-uniform)
       float* gp = grad_input + (nin * C + c) * HWi;
-      if (t.w00 != 0.0f) atomicAdd(gp + (t.o00 >> 2), gv * t.w00);
-      if (t.w01 != 0.0f) atomicAdd(gp + (t.o01 >> 2), gv * t.w01);
-      if (t.w10 != 0.0f) atomicAdd(gp + (t.o10 >> 2), gv * t.w10);
-      if (t.w11 != 0.0f) atomicAdd(gp + (t.o11 >> 2), gv * t.w11);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (WALDO_GS_RUNS) {
+          const float sum = run_sum(gv * wq[q], stop[q]);
+          if (head[q] && sum != 0.0f) atomicAdd(gp + (key[q] >> 2), sum);
+        } else if (wq[q] != 0.0f) {
+          atomicAdd(gp + (key[q] >> 2), gv * wq[q]);
+        }
+      }
     }
 #endif
   }
-  if (grad_grid != nullptr) {
+  if (grad_grid != nullptr && live) {
     float2* o = reinterpret_cast<float2*>(grad_grid + (n * HWo + p) * 2);
     *o = make_float2(gix * (0.5f * (float)Wi), giy * (0.5f * (float)Hi));
   }
