@@ -544,7 +544,8 @@ constexpr int kBwdTH = 32, kBwdTW = 32;
 __global__ __launch_bounds__(kBlock) void iw_bwd_fused_kernel(
     const float* __restrict__ gout, const unsigned char* __restrict__ mask,
     const unsigned char* __restrict__ fill_iter, const float* __restrict__ denom,
-    const float* __restrict__ kern, float* __restrict__ gfield, int H, int W, int niter, int tiles_x, int tiles) {
+    const float* __restrict__ kern, float* __restrict__ gfield, int H, int W, int niter, int tiles_x, int tiles,
+    int sink_lists) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int pad = niter + 1, halo = niter;
   const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp, HW = H * W;
@@ -602,26 +603,76 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fused_kernel(
   }
   // a region without a single filled cell: nothing moves
   const int n_pass = __syncthreads_or(any) ? niter : 0;
-  for (int it = n_pass; it >= 1; --it) {
-    for (int c = threadIdx.x; c < cells; c += kBlock) {
-      if (fi[c] >= it) continue;  // only earlier-filled cells fed pass `it` (border cells: 255)
-      float ax = 0.0f, ay = 0.0f;
+  // what a cell filled before pass `it` collects from the cells of pass `it` around it
+  auto collect = [&](int c, int it) {
+    float ax = 0.0f, ay = 0.0f;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int n = c + dy * RW + dx;
-          if (fi[n] == it) {
-            // this cell sits at offset (-dy, -dx) in n's stencil; the Gaussian is symmetric
-            const float k = k9[(1 - dy) * 3 + (1 - dx)] / rd[n];
-            ax = fmaf(k, gx[n], ax);
-            ay = fmaf(k, gy[n], ay);
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int n = c + dy * RW + dx;
+        if (fi[n] == it) {
+          // this cell sits at offset (-dy, -dx) in n's stencil; the Gaussian is symmetric
+          const float k = k9[(1 - dy) * 3 + (1 - dx)] / rd[n];
+          ax = fmaf(k, gx[n], ax);
+          ay = fmaf(k, gy[n], ay);
+        }
+      }
+    gx[c] += ax;  // cells of pass `it` are only read here, cells before it only written: in place
+    gy[c] += ay;
+  };
+  if (sink_lists && n_pass > 0) {
+    // The cells that collect anything in pass `it` -- filled before it, with a cell of pass `it` among their eight
+    // neighbours -- are few: they come from BIT ROWS (one 64-bit word per region row and fill state, as the forward
+    // kernel's rings) into a list, and the 3 x 3 sums run over the list with every lane busy.  Walking all cells, every
+    // earlier-filled one (most of a background region) paid nine byte reads per pass to find nothing.  A cell left
+    // off the list would have added 0.
+    unsigned long long* srow = reinterpret_cast<unsigned long long*>(smem + (((size_t)cells * 13 + 7) & ~(size_t)7));
+    unsigned short* list = reinterpret_cast<unsigned short*>(srow + (niter + 1) * RH);
+    __shared__ int list_count;
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int i = threadIdx.x >> 6; i < RH; i += kBlock / kWave) {
+      const unsigned char f = lane < RW ? fi[i * RW + lane] : (unsigned char)255;
+      for (int k = 0; k <= niter; ++k) {
+        const unsigned long long row = __ballot(f == k);
+        if (lane == 0) srow[k * RH + i] = row;
+      }
+    }
+    for (int it = n_pass; it >= 1; --it) {
+      if (threadIdx.x == 0) list_count = 0;
+      __syncthreads();
+      const int i = threadIdx.x >> 2, q = threadIdx.x & 3;
+      if (i > 0 && i < RH - 1) {
+        unsigned long long before = 0ull, around = 0ull;
+        for (int k = 0; k < it; ++k) before |= srow[k * RH + i];
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+          const unsigned long long sr = srow[it * RH + i + d];
+          around |= sr | (sr << 1) | (sr >> 1);
+        }
+        unsigned seg = (unsigned)((before & around) >> (16 * q)) & 0xffffu;
+        if (seg) {
+          int at = atomicAdd(&list_count, __popc(seg));
+          while (seg) {
+            const int j = __ffs((int)seg) - 1;
+            seg &= seg - 1;
+            list[at++] = (unsigned short)(i * RW + 16 * q + j);  // (at most `cells` entries: the buffer's size)
           }
         }
-      gx[c] += ax;  // cells of pass `it` are only read here, cells before it only written: in place
-      gy[c] += ay;
+      }
+      __syncthreads();
+      const int nl = list_count;
+      for (int e = threadIdx.x; e < nl; e += kBlock) collect(list[e], it);
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int it = n_pass; it >= 1; --it) {
+      for (int c = threadIdx.x; c < cells; c += kBlock) {
+        if (fi[c] >= it) continue;  // only earlier-filled cells fed pass `it` (border cells: 255)
+        collect(c, it);
+      }
+      __syncthreads();
+    }
   }
   // ---- the tile's own cells
   for (int e = threadIdx.x; e < kBwdTH * kBwdTW; e += kBlock) {
@@ -832,11 +883,17 @@ extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3
   const int HW = H * W, HWp = Hp * Wp;
   dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
   const int bw_rw = kBwdTW + 2 * niter + 2, bw_rh = kBwdTH + 2 * niter + 2;
-  const size_t bw_lds = (size_t)bw_rw * bw_rh * 13;
+  size_t bw_lds = (size_t)bw_rw * bw_rh * 13;
+  // (the rows of bits and the list of iw_bwd_fused_kernel's passes, where a region row fits a 64-bit word, a quarter
+  // row a thread, and the LDS the lot)
+  const size_t bw_lists = (((size_t)bw_rw * bw_rh * 13 + 7) & ~(size_t)7) + (size_t)(niter + 1) * bw_rh * 8 +
+                          (size_t)bw_rw * bw_rh * 2;
+  const int sink_lists = bw_rw <= 64 && 4 * bw_rh <= kBlock && bw_lists <= kFusedMaxLds;
+  if (sink_lists) bw_lds = bw_lists;
   const int btx = (Wp + kBwdTW - 1) / kBwdTW, bty = (Hp + kBwdTH - 1) / kBwdTH;
   if (!debug_option(WALDO_DEBUG_IW_PASSES) && bw_lds <= kFusedMaxLds && B * btx * bty <= 2147483647ll) {
     hipLaunchKernelGGL(iw_bwd_fused_kernel, dim3((unsigned)(B * btx * bty)), dim3(kBlock), bw_lds, st, grad_out,
-                       mask, fill_iter, denom, gauss3x3, gfield, H, W, niter, btx, btx * bty);
+                       mask, fill_iter, denom, gauss3x3, gfield, H, W, niter, btx, btx * bty, sink_lists);
   } else {
     hipLaunchKernelGGL(iw_bwd_init_kernel, gp, dim3(kBlock), 0, st, grad_out, mask, gfield, H, W, pad);
     for (int it = niter; it >= 1; --it)
