@@ -82,24 +82,26 @@ __global__ __launch_bounds__(kBlock) void time_gather_bwd_kernel(
 // framework spelled it as a contiguous copy of the channel slice (the slice is strided) and the interpolation
 // over that copy: three passes over the 20 full-resolution layout planes of every frame; this reads the two
 // middle rows of every block once.
+// (one workgroup = 256 consecutive output pixels of ONE plane: the plane's (b, t, c) come from the block index with
+// 32-bit arithmetic -- as one flat 64-bit index per thread the five divisions by run-time values made it 184 vector
+// instructions per pixel, VALU issue 100 %: a copy kernel bound by integer division)
 __global__ __launch_bounds__(kBlock) void downscale_frames_kernel(const float* __restrict__ input,
                                                                   float* __restrict__ out, int T, int Tw, int C,
-                                                                  int c0, int H, int W, int S, int64_t total) {
+                                                                  int c0, int H, int W, int S, int tiles) {
   typedef float f32x2_d __attribute__((ext_vector_type(2)));
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= total) return;
-  const int x = (int)(e % W);
-  const int y = (int)((e / W) % H);
-  const int64_t pl = e / ((int64_t)W * H);  // (b, t, c) of the output
-  const int Cs = C - c0;
-  const int c = (int)(pl % Cs);
-  const int t = (int)((pl / Cs) % Tw);
-  const int64_t b = pl / ((int64_t)Cs * Tw);
+  const unsigned pl = blockIdx.x / (unsigned)tiles;  // (b, t, c) of the output
+  const unsigned e = (blockIdx.x - pl * (unsigned)tiles) * kBlock + threadIdx.x;
+  if (e >= (unsigned)(H * W)) return;
+  const unsigned y = e / (unsigned)W, x = e - y * (unsigned)W;
+  const unsigned Cs = (unsigned)(C - c0);
+  const unsigned c = pl % Cs, bt = pl / Cs;
+  const unsigned t = bt % (unsigned)Tw;
+  const int64_t b = bt / (unsigned)Tw;
   const int64_t Wd = (int64_t)W * S, Hd = (int64_t)H * S;
   const float* src = input + (((b * T + t) * C + c0 + c) * Hd + ((int64_t)y * S + S / 2 - 1)) * Wd + (int64_t)x * S + S / 2 - 1;
   const f32x2_d r0 = *reinterpret_cast<const f32x2_d*>(src);
   const f32x2_d r1 = *reinterpret_cast<const f32x2_d*>(src + Wd);
-  out[e] = 0.5f * (0.5f * r0[0] + 0.5f * r0[1]) + 0.5f * (0.5f * r1[0] + 0.5f * r1[1]);
+  out[(int64_t)pl * H * W + e] = 0.5f * (0.5f * r0[0] + 0.5f * r0[1]) + 0.5f * (0.5f * r1[0] + 0.5f * r1[1]);
 }
 
 static int check_time_gather(const char* fn, const void* x, const void* pred_ts, const void* out, int B, int T,
@@ -184,11 +186,12 @@ extern "C" int waldo_downscale_frames_fwd(const float* input, float* out, int B,
     set_error("waldo_downscale_frames_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  if ((total + kBlock - 1) / kBlock > 2147483647) {
+  const int64_t tiles = ((int64_t)H * W + kBlock - 1) / kBlock, planes = (int64_t)B * Tw * (C - c0);
+  if (planes * tiles > 2147483647 || (int64_t)H * W > 2147483647) {
     set_error("waldo_downscale_frames_fwd: problem too large for one launch");
     return WALDO_EINVAL;
   }
-  downscale_frames_kernel<<<dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-      input, out, T, Tw, C, c0, H, W, S, total);
+  downscale_frames_kernel<<<dim3((unsigned)(planes * tiles)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+      input, out, T, Tw, C, c0, H, W, S, (int)tiles);
   return launch_status("waldo_downscale_frames_fwd");
 }
