@@ -10,7 +10,8 @@ Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): per rank B clips x T=1
 L=8 layers of 4x256x512 (RGB+alpha in [-1,1]), 16 TPS control points per layer,
 occ = compute_occ(randn).  One step = one pass of the hot path over that batch:
   fwd  rgb = warp_composite(layers, pts, occ)      (TPS grid -> bilinear warp -> reduce_comp)
-  bwd  rgb.square().mean().backward()              grads on layers and control points
+  bwd  rgb.square().mean().backward()              grads on layers and control points (the loss as written: autograd's
+                                                   own gradient chain is inside the timed step)
 Inputs are resident in HBM when the timed region starts.  Frames are independent, so ranks shard
 them with no data-path collective ("scaling": "weak", per-GPU work fixed).
 
@@ -38,7 +39,12 @@ import os
 import sys
 import time
 
-import torch
+if len(sys.argv) > 7 and sys.argv[1] == "--cpu-baseline-child" and hasattr(os, "sched_setaffinity"):
+    # the CPU-baseline child pins itself BEFORE torch is imported (its thread pools size themselves from the mask)
+    _allowed = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, set(_allowed[:max(1, min(int(sys.argv[7]), len(_allowed)))]))
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -121,10 +127,7 @@ def cpu_baseline_child(argv):
     its own, pinned BEFORE torch starts (affinity mask of THREADS CPUs, OMP_PROC_BIND / OMP_PLACES from the parent's
     environment), printing one JSON object: seconds of every repetition after a warm-up.  Never touches the GPU."""
     nl, h, w, frames, reps, threads = (int(x) for x in argv)
-    if hasattr(os, "sched_setaffinity"):
-        allowed = sorted(os.sched_getaffinity(0))
-        os.sched_setaffinity(0, set(allowed[:max(1, min(threads, len(allowed)))]))
-    torch.set_num_threads(threads)
+    torch.set_num_threads(threads)  # (the affinity mask was set at the top of this file, before `import torch`)
     from oracle import wif_oracle as O
     layers, pts, occ, inv, rep = O.make_synthetic(frames, nl, h, w, seed=0)
     lay, pt = layers.clone().requires_grad_(), pts.clone().requires_grad_()
@@ -146,8 +149,9 @@ def cpu_baseline(nl, h, w, frames, reps):
     Every measurement runs in a CHILD process that is pinned before torch starts (OMP_NUM_THREADS, OMP_PROC_BIND=close,
     OMP_PLACES=cores, an affinity mask of as many CPUs as threads), with thread counts that fit the CPU time the box
     really grants (`cpu_budget`: affinity cut to the cgroup quota).  The thread count is the best median of three
-    on a quarter of the sample among a FIXED list; the figure is the median of `reps` runs at that count with best /
-    worst beside it, and `unstable: true` when worst / best exceeds 1.5."""
+    on the same sample among a FIXED list; the figure is the median of `reps` runs at that count with best /
+    worst beside it, and `unstable: true` when worst / best exceeds 1.5 or when the probe's median at that thread count
+    and the measurement's disagree by more than 1.5x (the same configuration on the same sample, minutes apart)."""
     import subprocess
     budget = cpu_budget()
 
@@ -165,23 +169,25 @@ def cpu_baseline(nl, h, w, frames, reps):
         return xs[len(xs) // 2]
 
     cands = [c for c in (4, 8, 16, 32) if c <= budget] or [budget]
-    nprobe = max(1, frames // 4)
-    probe = {c: median(child(nprobe, 3, c)) for c in cands}
+    probe = {c: median(child(frames, 3, c)) for c in cands}  # the SAME sample as the measurement
     cores = min(probe, key=probe.get)
     times = sorted(child(frames, max(reps, 3), cores))
     med = median(times)
     f1 = max(1, min(4, frames))
     t1 = median(child(f1, 3, 1))
+    disagree = max(med, probe[cores]) / min(med, probe[cores])  # two runs of one configuration, minutes apart
     out = {"value": round(frames / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
            "value_best": round(frames / times[0], 3), "value_worst": round(frames / times[-1], 3),
-           "unstable": bool(times[-1] / times[0] > 1.5),
+           "unstable": bool(times[-1] / times[0] > 1.5 or disagree > 1.5),
+           "probe_over_measurement": round(probe[cores] / med, 3),
            "value_1_thread": round(f1 / t1, 3), "cpu_budget": budget,
-           "thread_probe_frames_per_s": {str(c): round(nprobe / t, 3) for c, t in probe.items()},
+           "thread_probe_frames_per_s": {str(c): round(frames / t, 3) for c, t in probe.items()},
            "sample": f"{frames} frames of the same workload ({nl}x4x{h}x{w}, fwd+bwd), "
                      f"median of {len(times)} after warm-up (best / worst beside it), torch {torch.__version__} "
                      f"CPU in a pinned child process (OMP_PROC_BIND=close, affinity = {cores} CPUs), {cores} threads = "
-                     f"best median of 3 on {nprobe} frames among {cands} (CPU budget {budget} of {os.cpu_count()} logical "
-                     f"CPUs); value_1_thread: {f1} frames, median of 3"}
+                     f"best median of 3 on the same {frames} frames among {cands} (CPU budget {budget} of "
+                     f"{os.cpu_count()} logical CPUs); unstable = worst / best > 1.5 or the probe and the measurement at "
+                     f"{cores} threads disagree by more than 1.5x; value_1_thread: {f1} frames, median of 3"}
     return out
 
 
@@ -223,14 +229,13 @@ def settle_interpreter():
 def spawn_ranks(n):
     """One process per GPU, as the reference's launch scripts do (scripts/cityscapes/demo.sh:6-12: torchrun around
     the helper; tools/engine.py:28-35 reads the rank from the environment): the same command line under
-    ``python -m torch.distributed.run`` on 127.0.0.1 with a free port.  Returns the launcher's exit code."""
-    import socket
+    ``python -m torch.distributed.run`` on 127.0.0.1.  Returns the launcher's exit code."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # the launcher picks the rendezvous port itself (c10d store on 127.0.0.1, port 0): no bind-close-reuse race when
+    # several benches or tests start at once
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--local-addr=127.0.0.1",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / tensor sharing between the ranks
     return subprocess.run(cmd, env=env).returncode
@@ -262,6 +267,14 @@ def main():
                     help="C4 / C5 only: the whole chain of Synthesizer.predict around the path (producers -> "
                          "Warper.forward -> decode_output -> WIF fusion) on whole clips, instead of the synthetic "
                          "fused forward (waldo_amd/tools/pipeline.py)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="--pipeline: weak = every rank keeps its own `clips` whole clips (per-GPU work fixed); strong = "
+                         "the config's clips are ONE job whose (b, t) output frames are dealt over the ranks in "
+                         "contiguous blocks (context frames replicated, one all-gather of the predicted frames), so that "
+                         "a single clip uses every GPU (waldo_amd/tools/demo.py:predict_sharded)")
+    ap.add_argument("--shard", default=None, metavar="R/W",
+                    help="--pipeline --scaling strong on ONE GPU: time rank R's share of a W-rank job without any "
+                         "collective (what a rank of the 8-GPU node would compute; tools_dev/strong_projection.py)")
     ap.add_argument("--motion", choices=["calibrated", "wild"], default="calibrated",
                     help="--pipeline: background motion of the stand-in pose heads (waldo_amd/tools/demo.py:BG_MOTION); "
                          "'wild' is the folded warp rounds 1-3 benchmarked on, 'calibrated' keeps the local stretch of "
@@ -297,7 +310,7 @@ def main():
                   f"python -m torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
-        print("bench.py: needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        print(f"bench.py: rank {rank} of {world} needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(1)
     if args.dist_backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU in the smoke test
@@ -343,6 +356,9 @@ def main():
         graphed = GraphedCall(lambda l, p, o: WF.warp_composite(l, p, o, tps.inverse_kernel, tps.basis_t),
                               layers, pts, occ)
 
+    def square_mean(rgb):  # the loss exactly as SURVEY 8(d) writes it: autograd's own gradient chain
+        return rgb.square().mean()
+
     def step(loss=None):
         if mode == "fwd":
             with torch.no_grad():
@@ -358,7 +374,7 @@ def main():
         layers.grad = None
         pts.grad = None
         rgb = WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
-        (loss or _SquareMean.apply)(rgb).backward()
+        (loss or square_mean)(rgb).backward()
 
     def fence():
         if pending[0] is not None:  # every gather started inside a timed region ends inside it
@@ -385,18 +401,18 @@ def main():
         t = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    # the same step with the loss written as the specification has it, rgb.square().mean(), and
-    # autograd's own four-pass gradient chain for it: reported next to the headline, never as it
+    # the same step with the loss gradient 2 * rgb / N written as ONE elementwise kernel (_SquareMean) instead of
+    # autograd's four-pass chain: reported next to the headline, never as it
     loss_variants = None
     if mode == "train" and world == 1:
         n = max(5, min(args.steps, 20))
-        plain = lambda rgb: rgb.square().mean()  # noqa: E731
         for _ in range(2):
-            step(loss=plain)
-        loss_variants = {"one_pass_loss_gradient_ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                         "autograd_loss_ms_per_step": round(timed(n, loss=plain) / n * 1e3, 4),
-                         "note": "value / ms_per_step use _SquareMean (same numbers, gradient 2*rgb/N in one "
-                                 "elementwise pass); the second line is out.square().mean().backward() as is"}
+            step(loss=_SquareMean.apply)
+        loss_variants = {"autograd_loss_ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                         "one_pass_loss_gradient_ms_per_step": round(timed(n, loss=_SquareMean.apply) / n * 1e3, 4),
+                         "note": "value / ms_per_step use out.square().mean().backward() as it is written in SURVEY "
+                                 "8(d); the second line is the same step with the loss gradient 2*rgb/N in one "
+                                 "elementwise pass (bench.py:_SquareMean, same numbers)"}
 
     # launch-bound shapes: what part of a replay is kernel, what part the floor of launching a graph
     launch_split = None
@@ -502,8 +518,8 @@ def main():
         }
         if loss_variants is not None:
             out["loss_variants"] = loss_variants
-            # the same workload with the loss exactly as SURVEY 8(d) writes it (autograd's own gradient chain)
-            out["value_literal_loss"] = round(total_frames / (loss_variants["autograd_loss_ms_per_step"] * 1e-3), 2)
+            out["value_one_pass_loss_gradient"] = round(
+                total_frames / (loss_variants["one_pass_loss_gradient_ms_per_step"] * 1e-3), 2)
         if launch_split is not None:
             out["launch_split"] = launch_split
         if world == 1 and not args.no_cpu_baseline:
@@ -590,19 +606,41 @@ def run_lvd(args, clips, world, rank, device, dist):
 
 
 def run_pipeline(args, clips, world, rank, device, dist):
-    """BASELINE configs C4 / C5 as the reference runs them (models/synthesizer.py:434-472): every rank
-    keeps `clips` whole clips (clips are independent: no data-path collective until the end), runs
-    predict() on them and the ranks all-gather the inpainted predicted frames."""
+    """BASELINE configs C4 / C5 as the reference runs them (models/synthesizer.py:434-472).
+
+    weak scaling (default): every rank keeps `clips` whole clips of its own (clips are independent: no data-path
+    collective until the end), runs predict() on them and the ranks all-gather the inpainted predicted frames.
+    strong scaling (--scaling strong): the `clips` clips are ONE job; its (b, t) output frames are dealt over the
+    ranks in contiguous blocks (predict_sharded: the context frames and what is computed from them replicated per
+    rank, no collective inside), and ONE all-gather of the inpainted predicted frames ends the step."""
     from waldo_amd import _lib
     from waldo_amd.dist import all_gather_frames_async
     from waldo_amd.tools.pipeline import Pipeline
-    pipe = Pipeline(args.config, clips, device, seed=rank, motion=args.motion)
+    strong = args.scaling == "strong"
+    shard = None
+    emulated = None
+    if strong:
+        shard = (rank, world)
+        if args.shard:
+            if world != 1:
+                print("bench.py: --shard R/W emulates one rank of a W-rank job on ONE GPU", file=sys.stderr)
+                sys.exit(2)
+            emulated = tuple(int(x) for x in args.shard.split("/"))
+            shard = emulated
+    pipe = Pipeline(args.config, clips, device, seed=0 if strong else rank, motion=args.motion, shard=shard)
     t, hd, wd = pipe.frames, pipe.vid.shape[-2], pipe.vid.shape[-1]
+    tp = t - pipe.ctx_len
     pending = [None]  # the previous step's all-gather: over xGMI while this step's kernels run
 
     def step():
-        out = pipe()["inp_pred_vid"]
-        prev, pending[0] = pending[0], all_gather_frames_async(out.reshape(clips * t, 3, hd, wd), clips * t * world)
+        if strong:
+            out = pipe()["inp_pred_vid"]  # this rank's block of the B * Tp predicted frames
+            if emulated is not None:
+                return
+            prev, pending[0] = pending[0], all_gather_frames_async(out, clips * tp)
+        else:
+            out = pipe()["inp_pred_vid"]
+            prev, pending[0] = pending[0], all_gather_frames_async(out.reshape(clips * t, 3, hd, wd), clips * t * world)
         if prev is not None:
             prev.wait()
 
@@ -630,8 +668,8 @@ def run_pipeline(args, clips, world, rank, device, dist):
         elapsed = tt.item()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        alg = pipe.hd_algorithmic_bytes()
         table = {}
+        alg = {} if strong else pipe.hd_algorithmic_bytes()  # (a rank's share of a split job: no per-kernel roofline)
         for name, (n, ms) in sorted(kt.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             per_step = n * ms / args.steps
             row = {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(per_step, 4)}
@@ -641,32 +679,57 @@ def run_pipeline(args, clips, world, rank, device, dist):
                 row["frac"] = round(row["GBps"] / HBM_PEAK_GBS, 4)
             table[name] = row
         in_lib = sum(r["ms_per_step"] for r in table.values())
-        dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
         o = pipe.opt
+        if strong:
+            dom = max(table, key=lambda k: table[k]["ms_per_step"])
+            roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "ms_per_launch": table[dom]["ms_per_step"],
+                    "note": "rank 0's share of a split job; the per-kernel roofline of the whole job is the weak-scaling "
+                            "line's (same kernels, same shapes per unit)"}
+            u0, u1 = pipe.local_units("pred")
+            r0, r1 = pipe.local_units("rec")
+            total_frames = clips * t
+            workload = (f"{args.config} pipeline, ONE job of {clips} clips x {t} frames ({pipe.ctx_len} context) split over "
+                        f"{emulated[1] if emulated else world} ranks by (b, t) output units: rank "
+                        f"{emulated[0] if emulated else 0} reconstructs units [{r0}, {r1}) of {clips * t} and predicts "
+                        f"[{u0}, {u1}) of {clips * tp}")
+            par = (f"(b, t) units sharded x{emulated[1] if emulated else world}, context frames and their grids / "
+                   f"composited alphas replicated, "
+                   + ("NO collective (one emulated rank on one GPU)" if emulated else
+                      "one all-gather of the inpainted predicted frames per step, overlapped with the next step's kernels"))
+        else:
+            dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
+            roof = {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
+                    "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]}
+            total_frames = clips * t * world
+            workload = f"{args.config} pipeline: {clips} clips x {t} frames per GPU ({pipe.ctx_len} context)"
+            par = (f"clips sharded x{world}, one all-gather of the inpainted predicted frames per step, "
+                   f"overlapped with the next step's kernels")
         out = {
             "metric": f"WIF inference frames/sec at {hd}x{wd}, {o.num_obj + 1} layers, {t}-frame clips; full "
                       f"LVD->FLP->WIF pipeline around the hot path (not the headline metric)",
-            "value": round(clips * t * world / (elapsed / args.steps), 2), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config} pipeline: {clips} clips x {t} frames per GPU ({pipe.ctx_len} context), "
-                                   f"layers at {o.dim}x{int(o.dim * o.aspect_ratio)}, frames at {hd}x{wd}, "
+            "value": round(total_frames / (elapsed / args.steps), 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload + f", layers at {o.dim}x{int(o.dim * o.aspect_ratio)}, frames at {hd}x{wd}, "
                                    f"{o.num_obj} objects + background, {o.num_lyt} layout classes; "
                                    f"Synthesizer.predict's call order: reconstruction of all {t} frames and prediction "
-                                   f"of the last {t - pipe.ctx_len}; networks outside the path replaced by seeded "
+                                   f"of the last {tp}; networks outside the path replaced by seeded "
                                    f"stand-ins (UNet stand-in costs nothing), background motion '{pipe.motion}'",
-                       "frames_per_gpu": clips * t, "layers": o.num_obj + 1, "height": hd, "width": wd,
-                       "parallelism": f"clips sharded x{world}, one all-gather of the inpainted predicted frames per step, "
-                                      f"overlapped with the next step's kernels"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
-                         "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]},
+                       "frames_per_gpu": clips * t if not strong else round(clips * t / (emulated[1] if emulated else world), 2),
+                       "layers": o.num_obj + 1, "height": hd, "width": wd, "parallelism": par},
+            "roofline": roof,
             "pipeline": {"ms_in_library_calls": round(in_lib, 4),
                          "ms_outside": round(ms_per_step - in_lib, 4),
                          "note": "per C-ABI entry point, event pairs on the launch stream; ms_outside = framework "
                                  "kernels and launch gaps between the calls (indexing, permutes, the stand-ins)",
                          "entry_points": table},
         }
+        if emulated:
+            out["emulated_shard"] = {"rank": emulated[0], "world": emulated[1],
+                                     "note": "value = the WHOLE job's frames / this one rank's step time: what the "
+                                             "job would reach if every rank took this long and the gather were free"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -92,13 +92,11 @@ def load():
         setattr(modules, name, getattr(src, name))
     lvd = _load("models.nets.lvd", "models/nets/lvd.py")
 
-    # WIF.__init__ calls .cuda() on a buffer (models/nets/wif.py:31); make it a no-op on CPU
-    orig_cuda = torch.Tensor.cuda
-    torch.Tensor.cuda = lambda self, *a, **k: self
-    try:
+    # WIF.__init__ calls .cuda() on a buffer (models/nets/wif.py:31): a no-op while the file is executed, put back
+    # afterwards (the callers build WIF with __new__ and never run that constructor; `cuda_is_noop` is there for one
+    # that would)
+    with cuda_is_noop():
         wif = _load("models.nets.wif", "models/nets/wif.py")
-    finally:
-        pass
     flp = _load("models.nets.flp", "models/nets/flp.py")
     ns = types.SimpleNamespace(
         PoseDecoder=flp.PoseDecoder,
@@ -106,7 +104,7 @@ def load():
         Warper=lvd.Warper, LVD=lvd.LVD, ImageDecoder=lvd.ImageDecoder, get_circle=lvd.get_circle,
         gather_time=lvd.gather_time, scale=lvd.scale,
         WIF=wif.WIF, UNet=conv.UNet, get_grid=utils.get_grid,
-        get_gaussian_kernel=utils.get_gaussian_kernel, expand=utils.expand, _orig_cuda=orig_cuda)
+        get_gaussian_kernel=utils.get_gaussian_kernel, expand=utils.expand)
     _cache["ns"] = ns
     # keep the stubs out of the way of real imports done later by the test session
     for k in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.io",
@@ -127,6 +125,22 @@ def warper_opt(**over):
              weight_cls=False, min_cls=0.0, include_self=False, no_filter=False, allow_ghost=False)
     d.update(over)
     return types.SimpleNamespace(**d)
+
+
+class cuda_is_noop:
+    """Context manager: ``Tensor.cuda`` returns the tensor itself (this container has no GPU); the original method is
+    put back on exit, whatever happened inside."""
+
+    def __enter__(self):
+        import torch
+        self._orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.Tensor.cuda = self._orig
+        return False
 
 
 class stable_sort:

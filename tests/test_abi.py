@@ -88,3 +88,39 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_timing_only_ablations_cannot_reach_a_product_build(tmp_path):
+    """A WALDO_ABL_* switch (timing-only, may compute wrong values) without -DWALDO_TIMING_ONLY_BUILD does not get
+    past the preprocessor; with it, the library reports version 0."""
+    import subprocess
+    from waldo_amd import build
+    src = os.path.join(build.CSRC, "runtime.hip")
+    base = [build.HIPCC, "-E", "--offload-arch=gfx950", "--cuda-host-only", f"-I{build.INCLUDE}"]
+    bad = subprocess.run(base + ["-DWALDO_ABL_REC_ALIAS=2", src], capture_output=True, text=True)
+    assert bad.returncode != 0 and "WALDO_TIMING_ONLY_BUILD" in bad.stderr
+    ok = subprocess.run(base + ["-DWALDO_ABL_REC_ALIAS=2", "-DWALDO_TIMING_ONLY_BUILD", src], capture_output=True,
+                        text=True)
+    assert ok.returncode == 0, ok.stderr[-500:]
+    assert re.search(r"waldo_version\(void\)\s*\{\s*return 0;", ok.stdout)
+    assert not re.search(r"waldo_version\(void\)\s*\{\s*return 1\d\d\d;", ok.stdout)
+
+
+def test_binding_refuses_a_version_0_library_unless_named_explicitly(tmp_path):
+    """What a timing-only build looks like to the binding: waldo_version() == 0.  The default path refuses it."""
+    import subprocess
+    import sys
+    csrc = tmp_path / "v0.c"
+    csrc.write_text("int waldo_version(void) { return 0; }\n")
+    so = tmp_path / "libwaldo_hip.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(csrc)], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from waldo_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "try:\n"
+            "    _lib.load()\n"
+            "except _lib.WaldoHipError as e:\n"
+            "    assert 'ABI version 0' in str(e), e\n"
+            "    print('refused')\n") % (ROOT, str(so))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "refused" in r.stdout, (r.stdout, r.stderr[-800:])

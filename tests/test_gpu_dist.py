@@ -130,3 +130,69 @@ def test_bench_starts_its_own_ranks(extra):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     per_rank = out["config"]["frames_per_gpu"]
     assert abs(out["value"] - 2 * per_rank / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]  # whole-job aggregate
+
+
+def _predict_rank(rank, world, port, name, clips, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from waldo_amd.dist import init_distributed
+    from waldo_amd.tools.pipeline import Pipeline
+    init_distributed(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    pipe = Pipeline(name, clips, dev, seed=6, shard=(rank, world))
+    local = pipe()
+    got = pipe.gather(local, keys=("inp_pred_vid", "pred_flow", "pred_disocc"))
+    torch.cuda.synchronize()
+    q.put((rank, pipe.local_units("pred"), {k: v.cpu().numpy() for k, v in got.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_predict_sharded_two_ranks_one_gpu(dev):
+    """ONE KITTI-recipe clip (256 x 832, 9 frames, 4 contexts: 5 predicted frames, a ragged 3 + 2 split) decoded by
+    two ranks that share this box's GPU: each runs `predict_sharded` on its block of (b, t) units and the ranks
+    all-gather (gloo here, RCCL on the node); `inp_pred_vid`, `pred_flow` and `pred_disocc` are bit-equal to the
+    single-rank `predict` on every rank.  Reference: tools/engine.py:31-35,63-64 (process group, data-parallel split),
+    models/synthesizer.py:434-472 (the calls being split)."""
+    from waldo_amd.tools.pipeline import Pipeline
+    name, clips = "C4", 1
+    single = Pipeline(name, clips, dev, seed=6)()
+    want = {k: single[k].cpu() for k in ("inp_pred_vid", "pred_flow", "pred_disocc")}
+    del single
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_rank, args=(r, 2, port, name, clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(0, 3), (3, 5)]
+    for rank, _, got in res:
+        for k, v in want.items():
+            g = torch.from_numpy(got[k])
+            assert g.shape == v.shape, (rank, k, g.shape, v.shape)
+            assert torch.equal(g, v), f"rank {rank}: {k} differs from the single-rank predict"
+
+
+def test_bench_strong_scaling_line():
+    """`bench.py --config C5 --pipeline --gpus 2 --scaling strong`: one job (here one Cityscapes clip) split over two
+    ranks by output frames; ONE JSON line, "scaling": "strong", value = the job's frames over the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--config", "C5", "--pipeline", "--scaling", "strong", "--clips", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert abs(out["value"] - 14 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]  # the job's 14 frames, once

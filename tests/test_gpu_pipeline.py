@@ -90,3 +90,41 @@ def test_predict_replays_from_one_hip_graph(dev):
             eager = run(vid, lyt)
             for x, y in zip(graphed(vid, lyt), eager):
                 assert torch.equal(x, y)
+
+
+def _assemble(pipe_full, blocks, key):
+    """The ranks' unit blocks of one key, in rank order, shaped as predict() returns that key."""
+    from waldo_amd.tools import demo
+    b, t, ctx = pipe_full.clips, pipe_full.frames, pipe_full.ctx_len
+    full = torch.cat([blk[key] for blk in blocks], dim=0)
+    per_clip = t if key in demo.UNIT_KEYS["rec"] else t - ctx
+    assert full.shape[0] == b * per_clip, (key, full.shape)
+    full = full.view(b, per_clip, *full.shape[1:])
+    if key == "pred_flow":
+        hd, wd = full.shape[-2:]
+        return full.view(b, per_clip, -1, 2, hd, wd).permute(0, 2, 1, 3, 4, 5)
+    if key in ("pred_vid", "inp_pred_vid"):
+        return torch.cat([pipe_full.vid[:, :ctx], full], dim=1)
+    return full
+
+
+@pytest.mark.parametrize("name,clips,worlds", [("C4", 1, (2, 5, 8)), ("C4", 2, (3, 4)), ("C5", 1, (8,))])
+def test_predict_split_by_output_frames_has_the_same_bits(dev, name, clips, worlds):
+    """One job split over `world` ranks by (b, t) output units (demo.predict_sharded): every rank decodes
+    its contiguous block from the clip's context frames and its OWN frames' poses only, and the blocks put together
+    are bit for bit what the single-rank predict() returns -- ragged splits (5 predicted frames over 2 ranks, 9
+    reconstructed over 8, ranks with no unit at all) and blocks that cross a clip boundary (2 clips over 3 ranks)
+    included.  All ranks run one after the other in this process; the collective is tests/test_gpu_dist.py's."""
+    from waldo_amd.tools.pipeline import Pipeline
+    full = Pipeline(name, clips, dev, seed=4)
+    ref = full()
+    for world in worlds:
+        blocks = []
+        for r in range(world):
+            full.shard = (r, world)  # (the same job, another rank's share)
+            blocks.append(full())
+        full.shard = None
+        for key, want in ref.items():
+            got = _assemble(full, blocks, key)
+            assert got.shape == want.shape, (world, key, got.shape, want.shape)
+            assert torch.equal(got, want), (world, key, (got - want).abs().max().item())

@@ -1,6 +1,11 @@
 """dev: build a variant of the library with extra compiler flags for A/B timing.
 
-    python tools_dev/build_variant.py NAME [--only unit,unit] -DWALDO_STAGE_AHEAD=3 ...   ->  waldo_amd/lib/abl/NAME.so
+    python tools_dev/build_variant.py NAME [--only unit,unit] -DWALDO_STAGE_AHEAD=3 ...   ->  tools_dev/_variants/NAME.so
+
+Variants live under tools_dev/_variants/ (git-ignored), never next to the product library.  A -DWALDO_ABL_* flag
+(a timing-only ablation, may compute wrong values: csrc/waldo_common.hip.h) adds -DWALDO_TIMING_ONLY_BUILD and
+recompiles csrc/runtime.hip with it, so that the variant reports waldo_version() == 0 and only loads through
+use_library() / bench.py --lib.
 
 --only: recompile just those translation units (e.g. warp_composite_lp8,warp_composite_splat) with the
 flags and link them with the PRODUCT objects of every other unit (build the product first).
@@ -16,10 +21,14 @@ name, flags = sys.argv[1], sys.argv[2:]
 only = None
 if flags and flags[0] == "--only":
     only, flags = flags[1].split(","), flags[2:]
+if any(f.startswith("-DWALDO_ABL_") for f in flags):
+    flags = flags + ["-DWALDO_TIMING_ONLY_BUILD"]
+    if only is not None and "runtime" not in only:
+        only = only + ["runtime"]
 prod_obj, prod_cflags = B.OBJ, list(B.CFLAGS)
 B.CFLAGS = B.CFLAGS + flags
 B.OBJ = os.path.join("/tmp", "waldo_variants", name)  # objects stay out of the tree (gpurun ships the tree)
-B.LIB = os.path.join(B.LIBDIR, "abl", name + ".so")
+B.LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_variants", name + ".so")
 os.makedirs(B.OBJ, exist_ok=True)
 os.makedirs(os.path.dirname(B.LIB), exist_ok=True)
 if only is None:

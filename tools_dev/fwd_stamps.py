@@ -2,7 +2,7 @@
 one tile-frame each) from the s_memtime stamps of a -DWALDO_FWD_STAMPS build:
 
     python tools_dev/build_variant.py fstamps --only warp_composite_lp8,warp_composite -DWALDO_FWD_STAMPS
-    python tools_dev/fwd_stamps.py waldo_amd/lib/abl/fstamps.so
+    python tools_dev/fwd_stamps.py tools_dev/_variants/fstamps.so
 
 Prints, over the workgroups: the spread of their start times, and the median / p90 duration of every phase."""
 import ctypes

@@ -1,5 +1,5 @@
 """dev: phase timeline of K1 from the s_memtime stamps of a -DWALDO_K1_STAMPS build
-(waldo_amd/lib/abl/stamps.so): median cycles between phase boundaries over the workgroups, for the
+(tools_dev/_variants/stamps.so): median cycles between phase boundaries over the workgroups, for the
 last frame of each workgroup's chunk, while the whole chip runs the headline launch."""
 import ctypes
 import os
@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, '.')
 import waldo_amd  # noqa: E402
 from waldo_amd import _lib, functional as WF  # noqa: E402
-_lib.use_library(sys.argv[1] if len(sys.argv) > 1 else "waldo_amd/lib/abl/stamps.so")
+_lib.use_library(sys.argv[1] if len(sys.argv) > 1 else "tools_dev/_variants/stamps.so")
 from waldo_amd.tools.utils import get_grid  # noqa: E402
 
 dev = torch.device("cuda:0")

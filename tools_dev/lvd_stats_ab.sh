@@ -1,8 +1,8 @@
 #!/bin/bash
-# dev helper: per-kernel times of the LVD-recipe step with each variant library under waldo_amd/lib/abl/
+# dev helper: per-kernel times of the LVD-recipe step with each variant library under tools_dev/_variants/
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$GRAFT_REPO_ROOT
-for so in $GRAFT_REPO_ROOT/waldo_amd/lib/abl/*.so; do
+for so in $GRAFT_REPO_ROOT/tools_dev/_variants/*.so; do
   n=$(basename $so .so)
   rm -rf /tmp/st_$n
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$n -- python3 $GRAFT_REPO_ROOT/tools_dev/bench_lvd_step.py --lib $so 2 10 > /tmp/st_$n.log 2>&1

@@ -5,5 +5,5 @@ mkdir -p gpurun_out
 python -m pytest tests/test_gpu_warper.py -q -k inverse_warp 2>&1 | tail -5
 for f in 4 8 16 28 56 112; do
   echo "== F=$f"
-  python tools_dev/ab_bench.py --shape $f,8,256,512 --iters 20 --rounds 2 waldo_amd/lib/abl/cur.so 2>&1 | tail -3
+  python tools_dev/ab_bench.py --shape $f,8,256,512 --iters 20 --rounds 2 tools_dev/_variants/cur.so 2>&1 | tail -3
 done

@@ -83,6 +83,7 @@ DEBUG_BWD_GENERIC = 2
 
 _lock = threading.Lock()
 _lib = None
+_explicit = False  # the library was named by use_library(): the only way a timing-only ablation build is accepted
 
 
 class WaldoHipError(RuntimeError):
@@ -92,11 +93,12 @@ class WaldoHipError(RuntimeError):
 def use_library(path):
     """Bind another build of the library (developer A/B runs: tools_dev/).  Only before the first call
     of any op -- the process keeps ONE library; nothing reads the environment."""
-    global LIB_PATH
+    global LIB_PATH, _explicit
     with _lock:
         if _lib is not None:
             raise WaldoHipError(f"use_library({path!r}): {LIB_PATH} is already loaded")
         LIB_PATH = os.path.abspath(path)
+        _explicit = True
 
 
 def load():
@@ -114,7 +116,13 @@ def load():
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
         lib.waldo_version.restype = _int
         lib.waldo_version.argtypes = []
-        if lib.waldo_version() != ABI_VERSION:
+        if lib.waldo_version() == 0 and _explicit:
+            # a timing-only ablation build (csrc/waldo_common.hip.h: WALDO_ABL_*, may compute WRONG values): only ever
+            # bound when a developer named it with use_library() / bench.py --lib, and never silently
+            import sys
+            print(f"waldo_amd: {LIB_PATH} is a TIMING-ONLY ablation build (waldo_version() == 0): its results are "
+                  "not the product's", file=sys.stderr)
+        elif lib.waldo_version() != ABI_VERSION:
             raise WaldoHipError(
                 f"{LIB_PATH} has ABI version {lib.waldo_version()}, this binding needs {ABI_VERSION}: "
                 "rebuild it with `python -m waldo_amd.build --force`")

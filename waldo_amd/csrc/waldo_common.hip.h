@@ -9,6 +9,20 @@
 #include "../../include/waldo_hip.h"
 #include "warp_composite_layout.hip.h"
 
+// The WALDO_ABL_* switches below and in the kernels are TIMING-ONLY ablations: several of them compute wrong values
+// on purpose (aliased frames, stores or gathers compiled out).  None of them may reach a product build: a translation
+// unit compiled with one of them and without -DWALDO_TIMING_ONLY_BUILD does not compile, and a library built with
+// that flag reports waldo_version() == 0 (csrc/runtime.hip), which waldo_amd._lib.load() refuses unless the library
+// was named explicitly (use_library / bench.py --lib).  tools_dev/build_variant.py passes the flag by itself.
+#if (defined(WALDO_ABL_NOFALLBACK) || defined(WALDO_ABL_FPB) || defined(WALDO_ABL_FCW_NOGATHER) ||              \
+     defined(WALDO_ABL_FCW_NOOCC) || defined(WALDO_ABL_FCW_NOSTORE) || defined(WALDO_ABL_FWF_NOGATHER) ||       \
+     defined(WALDO_ABL_FWF_NORAW) || defined(WALDO_ABL_FWF_ALLSTAGED) || defined(WALDO_ABL_FCB_NOATOMIC) ||     \
+     defined(WALDO_ABL_GS_NOATOMIC) || defined(WALDO_ABL_REC_ALIAS) || defined(WALDO_ABL_LAYER_ALIAS) ||        \
+     defined(WALDO_ABL_K1_LDS_PAD) || defined(WALDO_ABL_NO_REC_STORE)) &&                                       \
+    !defined(WALDO_TIMING_ONLY_BUILD)
+#error "WALDO_ABL_* timing-only ablations need -DWALDO_TIMING_ONLY_BUILD (tools_dev/build_variant.py): not a product build"
+#endif
+
 namespace waldo {
 
 void set_error(const char* fmt, ...);

@@ -303,6 +303,19 @@ class Warper(nn.Module):
                 and self.src_shape_hd[0] == self.src_shape[0] * int(s)
                 and self.src_shape_hd[1] == self.src_shape[1] * int(s))
 
+    def _clip_length(self, input, occ, nl, ctx_only):
+        """Frames per clip T on the time axis that ``grid`` / ``occ`` / ``pred_ts`` share.  The reference hands
+        ``decode_output`` an ``input`` of all T frames (synthesizer.py:439-445) of which the ``restrict_to_ctx`` path
+        reads the first Tc only (lvd.py:716-745, 837); a caller that shards the predicted frames over ranks
+        (tools/demo.py:predict_sharded) passes just those context frames: T then comes from ``occ`` (B, T, L, L)."""
+        t = input.size(1)
+        if occ.ndim == 4 and occ.size(1) != t:
+            if not ctx_only or self.include_self:
+                raise ValueError(f"input holds {t} frames per clip, occ {occ.size(1)}: an input of the context "
+                                 "frames alone needs restrict_to_ctx and no include_self")
+            t = occ.size(1)
+        return t
+
     def _layer_flows(self, grid, ctx_ts, pred_ts):
         """The layer-space flows between the context and the predicted frames and the predicted frames'
         source grids repeated over the contexts (lvd.py:660-668 / 780-787):
@@ -336,8 +349,9 @@ class Warper(nn.Module):
         input_to_output's ``raw`` tensor and comes back as a view of it (WF.flow_ctx_warp_into_raw)."""
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
-        tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
+        tc, tp = ctx_ts.size(1), pred_ts.size(0)
         nl = no + 1
+        t = self._clip_length(input, occ, nl, ctx_only)
         h, w = self.src_shape
         hd, wd = self.src_shape_hd
         ho, wo = self.tgt_shape
@@ -354,7 +368,9 @@ class Warper(nn.Module):
                 lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
             dist = self._lyt_dist(alpha, lyt, cls)
         occ = occ.reshape(b, t, nl, nl)
-        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ, tw, 3, s)
+        # (an input of the context frames alone -- _clip_length -- goes with the occlusion matrices of those frames)
+        occ_in = occ if input.size(1) == t else occ[:, :input.size(1)]
+        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s)
 
         obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
@@ -400,8 +416,9 @@ class Warper(nn.Module):
         self.alpha_ctx_max = None  # (only the fused pass produces it)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
-        tc, tp, t = ctx_ts.size(1), pred_ts.size(0), input.size(1)
+        tc, tp = ctx_ts.size(1), pred_ts.size(0)
         nl = no + 1
+        t = self._clip_length(input, occ, nl, ctx_only)
         h, w = self.src_shape
         hd, wd = self.src_shape_hd
         ho, wo = self.tgt_shape

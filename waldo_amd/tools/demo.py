@@ -151,76 +151,193 @@ def _obj_alpha_mask(opt, device):
     return m.view(1, 1, 1, ho, wo)
 
 
+def _cached_index(values, device):
+    """A small index tensor on the device, made once (a fresh host-to-device copy per call would stall the
+    launch queue: see _cached)."""
+    key = ("index", str(device), tuple(values))
+    if key not in _CONSTANTS:
+        _CONSTANTS[key] = torch.tensor(list(values), device=device, dtype=torch.int64)
+    return _CONSTANTS[key]
+
+
+def _block_net(opt, net, b, t, b0, b1, sel, device):
+    """The stand-ins' outputs for clips b0:b1 at the frames ``sel`` (ascending) of the clip's T."""
+    if (b0, b1) == (0, b) and len(sel) == t:
+        return net
+    no = opt.num_obj
+    idx = _cached_index(sel, device)
+
+    def frames(x):  # (B * T, ...) -> (nb * T', ...)
+        x = x.view(b, t, *x.shape[1:])[b0:b1]
+        return x.index_select(1, idx).reshape(-1, *x.shape[2:])
+
+    return dict(raw=net["raw"][b0 * no:b1 * no], pred_obj_pose=frames(net["pred_obj_pose"]),
+                pred_bg_pose=frames(net["pred_bg_pose"]), occ_score=net["occ_score"][b0:b1].index_select(1, idx),
+                cls=net["cls"][b0:b1])
+
+
+def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames):
+    """One decode of predict() (estimate_alpha_grid_occ -> decode_output -> disocclusion test -> WIF fusion,
+    synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (ascending frame numbers: the
+    context frames 0 .. ctx_len - 1 and the frames to decode), producing the frames ``frames`` (a contiguous run of
+    ``sel``).  ``net`` holds the stand-ins' outputs for exactly those clips and frames (_block_net); ``real_input``
+    (nb, >= ctx_len, C, Hd, Wd) at least the context frames.  Returns (output (nb, n, 3, Hd, Wd), disocc (nb, n, 1, Hd,
+    Wd), inpainted (nb, n, 3, Hd, Wd), flow (nb, Tc, n, 2, Hd, Wd)).  Every kernel of the chain works per (b, t)
+    unit (the layout filter's class distribution per clip, over its context frames), so the bits of a frame do not
+    depend on which other frames or clips are decoded beside it (tests/test_gpu_pipeline.py)."""
+    no = opt.num_obj
+    lo = opt.obj_shape[0] * opt.obj_shape[1]
+    lb = opt.latent_shape[0] * opt.latent_shape[1]
+    dev = real_input.device
+    nt, n = len(sel), len(frames)
+    buf = pose_buffers(opt, dev)
+    mask = obj_alpha_mask(opt, dev)
+    bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
+    # pose heads' affine (flp.py:259-273), decoder tail (lvd.py:245-254), then
+    # LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135)
+    obj_pose = flp.obj_pose_to_points(net["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+    bg_pose = flp.bg_pose_to_points(net["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"])
+    obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
+    obj_alpha = obj_alpha.view(nb, no, 1, *obj_alpha.shape[-2:])
+    occ, obj_alpha, bga, grid = estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(nb, nt, no, lo, 2),
+                                                        bg_pose.view(nb, nt, 1, lb, 2), net["occ_score"],
+                                                        obj_alpha_mask=mask)
+    ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
+    if opt.last_n_ctx > 0:
+        ctx_ts = ctx_ts[:, -opt.last_n_ctx:].contiguous()
+    first = sel.index(frames[0])
+    pred_ts = torch.arange(first, first + n, device=dev, dtype=torch.int64)
+    # decode_output + max_l alpha_ctx, which the fused flow pass produces as a by-product (the warper's switch and its
+    # result are restored / cleared afterwards: no state is left on the module)
+    prev = warper.keep_alpha_ctx_max
+    warper.keep_alpha_ctx_max = True
+    try:
+        output, flow, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
+                                                                     net["cls"], ctx_ts, pred_ts)
+        mx = warper.alpha_ctx_max
+    finally:
+        warper.keep_alpha_ctx_max = prev
+        warper.alpha_ctx_max = None
+    # synthesizer.py:447-450
+    if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the pass over alpha_ctx
+        mx = alpha_ctx.amax(dim=3)
+    dmin, dmax = torch.aminmax(mx, dim=1)  # (one pass for both reductions of synthesizer.py:447-448)
+    dmax[dmax - dmin > 1] = 0
+    return output[:, :, :3], dmax.unsqueeze(2), wif(raw_output), flow  # (wif: synthesizer.py:460)
+
+
 @torch.no_grad()
 def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     """The hot-path part of Synthesizer.predict (models/synthesizer.py:434-480).  real_vid
     (B, T, 3, H, W), real_lyt (B, T, Nl, H, W); ``net`` = synthetic_network_outputs(...).
     Returns a dict of the tensors predict produces."""
     b, t = real_vid.shape[:2]
-    no = opt.num_obj
-    lo = opt.obj_shape[0] * opt.obj_shape[1]
-    lb = opt.latent_shape[0] * opt.latent_shape[1]
-    dev = real_vid.device
-    buf = pose_buffers(opt, dev)
-    mask = obj_alpha_mask(opt, dev)
-    bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
-
-    def alpha_grid_occ(pred_obj_pose, pred_bg_pose, occ_score, nt):
-        # pose heads' affine (flp.py:259-273), decoder tail (lvd.py:245-254), then
-        # LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135)
-        obj_pose = flp.obj_pose_to_points(pred_obj_pose, buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
-        bg_pose = flp.bg_pose_to_points(pred_bg_pose, buf["tgt_pts_bg"], buf["bias_bg"])
-        obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
-        obj_alpha = obj_alpha.view(b, no, 1, *obj_alpha.shape[-2:])
-        return estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(b, nt, no, lo, 2),
-                                       bg_pose.view(b, nt, 1, lb, 2), occ_score, obj_alpha_mask=mask)
-
-    def decode(*args):
-        """decode_output + max_l alpha_ctx, which the fused flow pass produces as a by-product (the warper's
-        switch and its result are restored / cleared before returning: no state is left on the module)."""
-        prev = warper.keep_alpha_ctx_max
-        warper.keep_alpha_ctx_max = True
-        try:
-            res = decode_output(warper, *args)
-            return res, warper.alpha_ctx_max
-        finally:
-            warper.keep_alpha_ctx_max = prev
-            warper.alpha_ctx_max = None
-
-    def disocc(alpha_ctx, mx):  # synthesizer.py:447-450
-        if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the pass over alpha_ctx
-            mx = alpha_ctx.amax(dim=3)
-        dmin, dmax = torch.aminmax(mx, dim=1)  # (one pass for both reductions of synthesizer.py:447-448)
-        dmax[dmax - dmin > 1] = 0
-        return dmax.unsqueeze(2)
-
+    every = list(range(t))
     out = {}
-    occ, obj_alpha, bga, grid = alpha_grid_occ(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
     # reconstruct video (synthesizer.py:436-445)
-    ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(b, -1, t)
-    if opt.last_n_ctx > 0:
-        ctx_ts = ctx_ts[:, -opt.last_n_ctx:].contiguous()
-    pred_ts = torch.arange(t, device=dev, dtype=torch.int64)
     real_input = torch.cat([real_vid, real_lyt], dim=2)
-    (rec_output, _, _, _, _, raw_output, alpha_ctx), mx = decode(real_input, grid, occ, obj_alpha, bga, net["cls"],
-                                                                 ctx_ts, pred_ts)
-    out["rec_vid"] = rec_output[:, :, :3]
-    out["rec_disocc"] = disocc(alpha_ctx, mx)
-    out["inp_rec_vid"] = wif(raw_output)  # synthesizer.py:460
+    rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every)
+    out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
     if not opt.no_future:
         # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
         # poses as they came in, the future ones predicted (flp.py:275-290) -- here the synthetic poses
         # of all T frames stand for them (synthesizer.py:464-472)
-        tp = t - ctx_len
-        pred_ts = torch.arange(ctx_len, t, device=dev, dtype=torch.int64)
-        ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(b, -1, tp)
-        occ, obj_alpha, bga, grid = alpha_grid_occ(net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], t)
-        (pred_output, pred_flow, _, alpha, _, raw_output, alpha_ctx), mx = decode(
-            real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_ts, pred_ts)
-        out["pred_disocc"] = disocc(alpha_ctx, mx)
-        out["pred_flow"] = pred_flow
-        out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred_output[:, :, :3]], dim=1)
-        out["inp_pred_vid"] = torch.cat([real_vid[:, :ctx_len], wif(raw_output)], dim=1)
+        pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every[ctx_len:])
+        out["pred_disocc"] = dis
+        out["pred_flow"] = flow
+        out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred], dim=1)
+        out["inp_pred_vid"] = torch.cat([real_vid[:, :ctx_len], inp], dim=1)
+    return out
+
+
+def unit_segments(u0, u1, per_clip):
+    """The (b, t) units u = b * per_clip + f of the block [u0, u1) as runs of clips that decode the SAME frames:
+    [(b0, b1, f0, f1)] in unit order -- a partial first clip, the whole clips in the middle as one batch, a partial
+    last clip."""
+    segs, u = [], u0
+    while u < u1:
+        b, f = divmod(u, per_clip)
+        if f == 0 and u1 - u >= per_clip:
+            nb = (u1 - u) // per_clip
+            segs.append((b, b + nb, 0, per_clip))
+            u += nb * per_clip
+        else:
+            f1 = min(per_clip, f + (u1 - u))
+            segs.append((b, b + 1, f, f1))
+            u += f1 - f
+    return segs
+
+
+UNIT_KEYS = {"rec": ("rec_vid", "rec_disocc", "inp_rec_vid"), "pred": ("pred_vid", "pred_disocc", "inp_pred_vid",
+                                                                      "pred_flow")}
+
+
+@torch.no_grad()
+def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, world, phases=("rec", "pred")):
+    """This rank's share of predict() when ONE job (B clips) is split over ``world`` ranks: the
+    (b, t) output units of each decode -- B * T reconstructed frames, B * (T - Tc) predicted ones -- are dealt in
+    contiguous blocks (dist.shard_range).  A rank keeps the context frames of the clips its block touches and their
+    stand-in network outputs, runs the producers and Warper.forward for the context frames and ITS frames only (the
+    context part -- Tc of a clip's grids, the layout filter's class distribution, the first occlusion product: 0.8 of
+    C5's 22 ms -- is replicated on every rank that shares the clip, which needs no collective), and decodes its block.
+    Returns {key: (units, C, Hd, Wd)} with the rank's units in order, for the keys of UNIT_KEYS (``pred_vid`` /
+    ``inp_pred_vid``: the predicted frames only; ``pred_flow``: Tc * 2 channels); ``gather_predict`` puts the ranks'
+    blocks together into predict()'s dict.  Reference: the data-parallel split of tools/engine.py:63-64, here over
+    frames instead of clips so that one clip can use every GPU."""
+    from ..dist import shard_range
+    if opt.include_self:
+        raise ValueError("predict_sharded: include_self appends the predicted frame itself as a context "
+                         "(lvd.py:842-845): every rank would need every frame")
+    b, t = real_vid.shape[:2]
+    dev = real_vid.device
+    hd, wd = real_vid.shape[-2:]
+    out = {}
+    inputs = {}  # clips b0:b1 -> cat of their context frames and layouts (shared by the phases)
+    for phase in phases:
+        if phase == "pred" and opt.no_future:
+            continue
+        first = 0 if phase == "rec" else ctx_len
+        per_clip = t - first
+        u0, u1 = shard_range(b * per_clip, rank, world)
+        parts = {k: [] for k in UNIT_KEYS[phase]}
+        for b0, b1, f0, f1 in unit_segments(u0, u1, per_clip):
+            frames = list(range(first + f0, first + f1))
+            sel = sorted(set(range(ctx_len)) | set(frames))
+            if (b0, b1) not in inputs:
+                inputs[(b0, b1)] = torch.cat([real_vid[b0:b1, :ctx_len], real_lyt[b0:b1, :ctx_len]], dim=2)
+            blk = _block_net(opt, net, b, t, b0, b1, sel, dev)
+            vid, dis, inp, flow = _decode_block(opt, warper, wif, inputs[(b0, b1)], blk, ctx_len, b1 - b0, sel, frames)
+            n = f1 - f0
+            parts[phase + "_vid"].append(vid.reshape(-1, 3, hd, wd))
+            parts[phase + "_disocc"].append(dis.reshape(-1, 1, hd, wd))
+            parts["inp_" + phase + "_vid"].append(inp.reshape(-1, 3, hd, wd))
+            if phase == "pred":  # (nb, Tc, n, 2, Hd, Wd) -> units x (Tc * 2)
+                parts["pred_flow"].append(flow.permute(0, 2, 1, 3, 4, 5).reshape((b1 - b0) * n, -1, hd, wd))
+        for k, v in parts.items():
+            if v:
+                out[k] = v[0] if len(v) == 1 else torch.cat(v, dim=0)
+            else:  # a rank past the end of a short job holds no unit
+                ch = {"disocc": 1, "flow": 2 * (opt.last_n_ctx or ctx_len)}.get(k.split("_")[-1], 3)
+                out[k] = real_vid.new_empty(0, ch, hd, wd)
+    return out
+
+
+def gather_predict(local, real_vid, ctx_len, keys=None, group=None):
+    """All-gather the ranks' blocks of ``predict_sharded`` (one collective per key, dist.all_gather_frames: RCCL over
+    xGMI, or gloo in the tests) and shape them as predict() returns them."""
+    from ..dist import all_gather_frames
+    b, t = real_vid.shape[:2]
+    hd, wd = real_vid.shape[-2:]
+    out = {}
+    for k in (keys or local.keys()):
+        per_clip = t if k in UNIT_KEYS["rec"] else t - ctx_len
+        full = all_gather_frames(local[k], b * per_clip, group=group, collective_for_one=False)
+        full = full.view(b, per_clip, *full.shape[1:])
+        if k == "pred_flow":  # units x (Tc * 2) -> (B, Tc, Tp, 2, Hd, Wd)
+            full = full.view(b, per_clip, -1, 2, hd, wd).permute(0, 2, 1, 3, 4, 5).contiguous()
+        elif k in ("pred_vid", "inp_pred_vid"):
+            full = torch.cat([real_vid[:, :ctx_len], full], dim=1)
+        out[k] = full
     return out
 
 

@@ -47,10 +47,15 @@ def synthetic_clip(opt, clips, frames, seed, device):
 
 class Pipeline:
     """One rank's share of a C4 / C5 run: ``clips`` clips resident on ``device``; ``__call__`` runs
-    ``predict`` on them and returns its dict (``inp_pred_vid`` (B, T, 3, Hd, Wd) is the product)."""
+    ``predict`` on them and returns its dict (``inp_pred_vid`` (B, T, 3, Hd, Wd) is the product).
 
-    def __init__(self, name, clips, device, seed=0, motion="calibrated"):
+    ``shard=(rank, world)``: the ``clips`` clips are ONE job split over ``world`` ranks by (b, t) output units
+    (``demo.predict_sharded``; every rank builds the same job from the same seed); ``__call__`` then returns this
+    rank's unit blocks, ``gather`` the assembled dict on every rank."""
+
+    def __init__(self, name, clips, device, seed=0, motion="calibrated", shard=None):
         self.name = name
+        self.shard = shard
         self.motion = motion  # background motion of the stand-ins: demo.BG_MOTION
         self.opt = recipe_opt(name)
         self.frames, self.ctx_len = RECIPES[name][5], RECIPES[name][6]
@@ -61,8 +66,21 @@ class Pipeline:
                                                   motion=motion)
         self.vid, self.lyt = synthetic_clip(self.opt, clips, self.frames, seed, device)
 
-    def __call__(self):
+    def __call__(self, phases=("rec", "pred")):
+        if self.shard is not None:
+            return demo.predict_sharded(self.opt, self.warper, self.wif, self.vid, self.lyt, self.net, self.ctx_len,
+                                        *self.shard, phases=phases)
         return demo.predict(self.opt, self.warper, self.wif, self.vid, self.lyt, self.net, self.ctx_len)
+
+    def gather(self, local, keys=None, group=None):
+        return demo.gather_predict(local, self.vid, self.ctx_len, keys=keys, group=group)
+
+    def local_units(self, phase="pred"):
+        """[start, stop) of this rank's (b, t) units of a phase ("rec": B * T, "pred": B * (T - Tc))."""
+        from ..dist import shard_range
+        per_clip = self.frames if phase == "rec" else self.frames - self.ctx_len
+        rank, world = self.shard if self.shard is not None else (0, 1)
+        return shard_range(self.clips * per_clip, rank, world)
 
     def hd_algorithmic_bytes(self):
         """Bytes the full-resolution entry points have to move per ``predict`` (each input read once,
