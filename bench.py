@@ -272,6 +272,8 @@ def main():
                          "the config's clips are ONE job whose (b, t) output frames are dealt over the ranks in "
                          "contiguous blocks (context frames replicated, one all-gather of the predicted frames), so that "
                          "a single clip uses every GPU (waldo_amd/tools/demo.py:predict_sharded)")
+    ap.add_argument("--graph", action="store_true",
+                    help="--pipeline: replay the rank's whole step from ONE HIP graph (the collective stays outside it)")
     ap.add_argument("--shard", default=None, metavar="R/W",
                     help="--pipeline --scaling strong on ONE GPU: time rank R's share of a W-rank job without any "
                          "collective (what a rank of the 8-GPU node would compute; tools_dev/strong_projection.py)")
@@ -632,14 +634,20 @@ def run_pipeline(args, clips, world, rank, device, dist):
     tp = t - pipe.ctx_len
     pending = [None]  # the previous step's all-gather: over xGMI while this step's kernels run
 
+    graph = pipe.graphed() if args.graph else None
+
     def step():
-        if strong:
-            out = pipe()["inp_pred_vid"]  # this rank's block of the B * Tp predicted frames
+        if graph is not None:
+            out = graph(*graph.inputs)
+            if dist is not None:
+                out = out.clone()  # the graph's static buffer: the next replay overwrites it while the gather runs
+        else:
+            out = pipe()["inp_pred_vid"]
+        if strong:  # out: this rank's block of the B * Tp predicted frames
             if emulated is not None:
                 return
             prev, pending[0] = pending[0], all_gather_frames_async(out, clips * tp)
         else:
-            out = pipe()["inp_pred_vid"]
             prev, pending[0] = pending[0], all_gather_frames_async(out.reshape(clips * t, 3, hd, wd), clips * t * world)
         if prev is not None:
             prev.wait()
@@ -680,12 +688,14 @@ def run_pipeline(args, clips, world, rank, device, dist):
             table[name] = row
         in_lib = sum(r["ms_per_step"] for r in table.values())
         o = pipe.opt
-        if strong:
-            dom = max(table, key=lambda k: table[k]["ms_per_step"])
+        if strong or not table:  # (inside a HIP graph the per-call events are not recorded: no table)
+            dom = max(table, key=lambda k: table[k]["ms_per_step"]) if table else None
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": None, "ms_per_launch": table[dom]["ms_per_step"],
-                    "note": "rank 0's share of a split job; the per-kernel roofline of the whole job is the weak-scaling "
-                            "line's (same kernels, same shapes per unit)"}
+                    "traffic": None, "ms_per_launch": table[dom]["ms_per_step"] if table else None,
+                    "note": ("rank 0's share of a split job; the per-kernel roofline of the whole job is the weak-scaling "
+                             "line's (same kernels, same shapes per unit)") if strong else
+                            "replayed from one HIP graph: no per-call events; the eager line has the per-kernel table"}
+        if strong:
             u0, u1 = pipe.local_units("pred")
             r0, r1 = pipe.local_units("rec")
             total_frames = clips * t
@@ -695,13 +705,15 @@ def run_pipeline(args, clips, world, rank, device, dist):
                         f"[{u0}, {u1}) of {clips * tp}")
             par = (f"(b, t) units sharded x{emulated[1] if emulated else world}, context frames and their grids / "
                    f"composited alphas replicated, "
+                   + ("the step replayed from one HIP graph, " if args.graph else "")
                    + ("NO collective (one emulated rank on one GPU)" if emulated else
                       "one all-gather of the inpainted predicted frames per step, overlapped with the next step's kernels"))
         else:
-            dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
-            roof = {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
-                    "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]}
+            if table:
+                dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
+                roof = {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
+                        "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]}
             total_frames = clips * t * world
             workload = f"{args.config} pipeline: {clips} clips x {t} frames per GPU ({pipe.ctx_len} context)"
             par = (f"clips sharded x{world}, one all-gather of the inpainted predicted frames per step, "

@@ -67,10 +67,21 @@ class Pipeline:
         self.vid, self.lyt = synthetic_clip(self.opt, clips, self.frames, seed, device)
 
     def __call__(self, phases=("rec", "pred")):
+        return self.run(self.vid, self.lyt, phases)
+
+    def run(self, vid, lyt, phases=("rec", "pred")):
+        """predict() (or this rank's share of it) on another clip of the same shape."""
         if self.shard is not None:
-            return demo.predict_sharded(self.opt, self.warper, self.wif, self.vid, self.lyt, self.net, self.ctx_len,
+            return demo.predict_sharded(self.opt, self.warper, self.wif, vid, lyt, self.net, self.ctx_len,
                                         *self.shard, phases=phases)
-        return demo.predict(self.opt, self.warper, self.wif, self.vid, self.lyt, self.net, self.ctx_len)
+        return demo.predict(self.opt, self.warper, self.wif, vid, lyt, self.net, self.ctx_len)
+
+    def graphed(self, key="inp_pred_vid"):
+        """The whole step as ONE HIP graph (waldo_amd.graphs.GraphedCall): a rank's share of a split job is a
+        couple of hundred launches of a few microseconds each, queued slower than they run.  Returns a callable
+        (vid, lyt) -> the step's ``key`` tensor, a static buffer the next replay overwrites."""
+        from ..graphs import GraphedCall
+        return GraphedCall(lambda vid, lyt: self.run(vid, lyt)[key], self.vid, self.lyt)
 
     def gather(self, local, keys=None, group=None):
         return demo.gather_predict(local, self.vid, self.ctx_len, keys=keys, group=group)
