@@ -43,7 +43,9 @@ int waldo_max_layers(void);
 #define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
 #define WALDO_DEBUG_BWD_GENERIC 2 /* fused backward: the generic per-tap-atomics kernel for every shape
                                      (waldo_warp_composite_bwd_workspace_bytes answers 0) */
-#define WALDO_DEBUG_COUNT 3
+#define WALDO_DEBUG_FWD_PIPELINED 3 /* fused forward, staged, L in {4, 8} layers: the frame loop software-pipelined
+                                       (round 5's experiment, bit-identical and 2.5 % slower: DESIGN.md) */
+#define WALDO_DEBUG_COUNT 4
 int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------
@@ -192,6 +194,12 @@ int waldo_pose_affine_fwd(const float* pose, const float* mul6, const float* bia
 int waldo_pose_affine_bwd(const float* pose, const float* mul6, const float* bias6,
                           const float* base_pts, const float* grad_out, float* grad_pose, int64_t R,
                           int P, float mul_delta, float pts_mul, waldo_stream_t stream);
+/* waldo_disocc_test_fwd: the disocclusion test of Synthesizer.predict (models/synthesizer.py:447-450, 475-478)
+ *   on layer_max (B,Tc,Tp,HW) = alpha_ctx.max(dim=3)[0] (the `alpha_max` by-product of waldo_flow_ctx_warp_*):
+ *   dmax = max over Tc, dmin = min over Tc (NaN-propagating, as torch's);  out (B,Tp,HW) = dmax, 0 where
+ *   dmax - dmin > 1.  Inference only (the reference runs it under no_grad). */
+int waldo_disocc_test_fwd(const float* layer_max, float* out, int64_t B, int Tc, int Tp, int64_t HW,
+                          waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A9: the two full-resolution passes of Warper.grid_to_flow_ctx / grid_to_flow

@@ -19,12 +19,17 @@ from waldo_amd.tools.utils import get_grid  # noqa: E402
 
 dev = torch.device("cuda:0")
 F, L, H, W = 8, 8, 128, 128
+if len(sys.argv) > 2 and sys.argv[2] == "C3":  # the headline shape: 7 frames per workgroup, steady-state stamps 8 .. 12
+    F, L, H, W = 112, 8, 256, 512
+
 g = torch.Generator(device=dev).manual_seed(0)
 layers = torch.rand(F, L, 4, H, W, generator=g, device=dev) * 2 - 1
 pts = get_grid(4, 4).view(1, 16, 2).to(dev) + 0.05 * torch.randn(F * L, 16, 2, generator=g, device=dev)
 occ = torch.rand(F, L, L, generator=g, device=dev) * 0.5
 tps = waldo_amd.TPSWarp(H, W, get_grid(4, 4).view(-1, 2)).to(dev)
 lib = _lib.load()
+if len(sys.argv) > 3:  # e.g. 3 = WALDO_DEBUG_FWD_PIPELINED
+    assert lib.waldo_set_debug_option(int(sys.argv[3]), 1) == 0
 with torch.no_grad():
     for _ in range(5):
         WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
@@ -48,3 +53,14 @@ for i in (1, 2, 3, 5, 6):
     print(f"  {names[i]:56s} median {np.median(d):6.0f}  p90 {np.percentile(d, 90):6.0f}")
     prev = i
 print(f"  workgroup lifetime median {np.median(st[:, 6] - st[:, 0]):.0f}")
+if F > 8:
+    s2 = st[st[:, 12] > st[:, 8]]
+    print(f"second frame of the chunk ({len(s2)} workgroups): top of the loop -> all layers sampled -> end of the frame")
+    for a, b, what in ((8, 9, "grid, ranges, transposition + barrier (serial kernel only)"),
+                       (9, 10, "boxes, first loads issued (serial kernel only)"),
+                       (8, 11, "top of the frame -> every layer sampled"), (11, 12, "composite, stores (+ closing barrier)"),
+                       (8, 12, "whole frame")):
+        ok = s2[(s2[:, b] >= s2[:, a]) & (s2[:, a] > 0)]
+        if len(ok):
+            d = ok[:, b] - ok[:, a]
+            print(f"  {what:64s} median {np.median(d):6.0f}  p90 {np.percentile(d, 90):6.0f}")

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1010
+ABI_VERSION = 1011
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -46,6 +46,7 @@ SIGNATURES = {
     "waldo_alpha_head_bwd": [_c_f] * 5 + [_i64, _int, _int, _int, _int, _flt, _int, _int, _stream],
     "waldo_pose_affine_fwd": [_c_f] * 5 + [_i64, _int, _flt, _flt, _stream],
     "waldo_pose_affine_bwd": [_c_f] * 6 + [_i64, _int, _flt, _flt, _stream],
+    "waldo_disocc_test_fwd": [_c_f, _c_f, _i64, _int, _int, _i64, _stream],
     "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_fwd": [_c_f] * 10 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
@@ -80,6 +81,7 @@ PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
 DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
 DEBUG_BWD_GENERIC = 2
+DEBUG_FWD_PIPELINED = 3
 
 _lock = threading.Lock()
 _lib = None

@@ -311,6 +311,37 @@ extern "C" int waldo_alpha_head_bwd(const float* x, const float* prior, const fl
   return launch_status("waldo_alpha_head_bwd");
 }
 
+// Synthesizer.predict's disocclusion test (models/synthesizer.py:447-450 and 475-478) on the by-product of the fused
+// flow pass, m = alpha_ctx.max(dim=3)[0] (B, Tc, Tp, HW):
+//   dmax = m.max(dim=1)[0];  dmin = m.min(dim=1)[0];  dmax[dmax - dmin > 1] = 0      -> (B, Tp, HW)
+// One pass (Tc planes read, one written) instead of torch's aminmax + subtract + compare + masked_fill over
+// (B, Tp, HW) temporaries.  torch.max / min return NaN when any element is NaN and `NaN > 1` is false: IEEE
+// maximum / minimum (v_maximum3_f32 / v_minimum3_f32) keep both.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void disocc_test_kernel(const V* __restrict__ m, V* __restrict__ out, int Tc,
+                                                             int Tp, int64_t hw, int tiles) {
+  const int64_t u = blockIdx.x / tiles;  // (b, tp)
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= hw) return;
+  const int64_t b = u / Tp, tp = u - b * Tp;
+  const V* src = m + (b * Tc * Tp + tp) * hw + p;
+  V mx = src[0], mn = mx;
+  for (int t = 1; t < Tc; ++t) {
+    const V v = src[(int64_t)t * Tp * hw];
+    mx = __builtin_elementwise_maximum(mx, v);
+    mn = __builtin_elementwise_minimum(mn, v);
+  }
+  const V d = mx - mn;
+  if constexpr (sizeof(V) == 4) {
+    out[u * hw + p] = d > 1.0f ? 0.0f : mx;
+  } else {
+    V r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = d[i] > 1.0f ? 0.0f : mx[i];
+    out[u * hw + p] = r;
+  }
+}
+
 static int check_pose(const char* fn, int64_t R, int P) {
   if (R < 0 || P < 1 || P > 4096 || R * (int64_t)(6 + 2 * P) > 2147483647ll * kBlock) {
     set_error("%s: bad shape R=%lld P=%d", fn, (long long)R, P);
@@ -347,4 +378,29 @@ extern "C" int waldo_pose_affine_bwd(const float* pose, const float* mul6, const
                      (hipStream_t)stream, pose, mul6, bias6, base_pts, grad_out, grad_pose, R, P, mul_delta,
                      pts_mul);
   return launch_status("waldo_pose_affine_bwd");
+}
+
+extern "C" int waldo_disocc_test_fwd(const float* layer_max, float* out, int64_t B, int Tc, int Tp, int64_t HW,
+                                     waldo_stream_t stream) {
+  if (B < 0 || Tc < 1 || Tp < 1 || HW < 1 || B * Tp * ((HW + kBlock - 1) / kBlock) > 2147483647ll) {
+    set_error("waldo_disocc_test_fwd: bad shape B=%lld Tc=%d Tp=%d HW=%lld", (long long)B, Tc, Tp, (long long)HW);
+    return WALDO_EINVAL;
+  }
+  if (B == 0) return WALDO_OK;
+  if (!layer_max || !out) {
+    set_error("waldo_disocc_test_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  typedef float f32x4_d __attribute__((ext_vector_type(4)));
+  const bool wide = HW % 4 == 0 && ((uintptr_t)layer_max % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const int64_t n = wide ? HW / 4 : HW;
+  const int tiles = (int)((n + kBlock - 1) / kBlock);
+  if (wide)
+    hipLaunchKernelGGL(disocc_test_kernel<f32x4_d>, dim3((unsigned)(B * Tp * tiles)), dim3(kBlock), 0,
+                       (hipStream_t)stream, reinterpret_cast<const f32x4_d*>(layer_max),
+                       reinterpret_cast<f32x4_d*>(out), Tc, Tp, n, tiles);
+  else
+    hipLaunchKernelGGL(disocc_test_kernel<float>, dim3((unsigned)(B * Tp * tiles)), dim3(kBlock), 0,
+                       (hipStream_t)stream, layer_max, out, Tc, Tp, n, tiles);
+  return launch_status("waldo_disocc_test_fwd");
 }

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
     // base + constant that it then keeps live across the whole frame loop, or spills).
     int lane = lane_k, arow = arow_k, kk = kk_k;
     asm volatile("" : "+v"(lane), "+v"(arow), "+v"(kk));
+    if (f == f0 + 1) WALDO_FSTAMP(8);  // (stamps 8 .. 12: the SECOND frame of the chunk, the loop's steady state)
     // ---- (A) TPS grid of every layer on the matrix pipe, in pixel units (scaled_map):
     // D[pixel][(layer, xy)] = sum_k basis[pixel][k] * mapping[k][(layer, xy)]
     f32x4 acc[4][NT];
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
     }
     __syncthreads();  // ranges of all waves visible; the slices (inside the image) are free again
     if (f == f0) WALDO_FSTAMP(2);  // grid on MFMA, ranges, transposition
+    if (f == f0 + 1) WALDO_FSTAMP(9);
     // ---- (D) box of the 2x2 blocks of every layer: lanes 0..15 of every wave turn the range of
     // "their" column into block origins, then the corners go to SGPRs
     int lo_t[NT], hi_t[NT];
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
     if (f == f0) WALDO_FSTAMP(3);  // boxes, first loads issued
+    if (f == f0 + 1) WALDO_FSTAMP(10);
     {
 #pragma unroll
       for (int l = 0; l < LP; ++l) {
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
     }
 
     if (f == f0) WALDO_FSTAMP(5);  // every layer sampled
+    if (f == f0 + 1) WALDO_FSTAMP(11);
     // ---- composite: a_0 = 1 (lvd.py:105), a_l = (s_l3 + 1) / 2
     float a[LP];
 #pragma unroll
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
     }
     __syncthreads();  // boxred and the image buffers are re-used by the next frame
     if (f == f0) WALDO_FSTAMP(6);  // composite, stores issued, closing barrier
+    if (f == f0 + 1) WALDO_FSTAMP(12);
   }
 }
 

@@ -368,6 +368,7 @@ void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
 }  // namespace waldo
 
 #include "warp_composite_fwd_lds.hip.h"
+#include "warp_composite_fwd_pipe.hip.h"
 #include "warp_composite_bwd_px16.hip.h"
 
 namespace waldo {
@@ -434,6 +435,21 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
       };
       using T = std::true_type;
       using N = std::false_type;
+      if constexpr (WALDO_FWD_PIPE != 0 && NW == 4 && LP >= 2 && LP <= 8) {
+        // round 5's experiment (warp_composite_fwd_pipe.hip.h): the frame loop software-pipelined; same bits, measured
+        // 2.5 % SLOWER at the headline shape, so only behind the debug switch (bench.py --debug-option 3)
+        if (L == LP && debug_option(WALDO_DEBUG_FWD_PIPELINED)) {
+          if (src_pts != nullptr)
+            hipLaunchKernelGGL((warp_composite_fwd_pipe_kernel<LP, true>), grid16, dim3(NW * kWave), 0, st, layers,
+                               basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, H, W, fpb, ntx16, nt16,
+                               nchunks, nbands, delta);
+          else
+            hipLaunchKernelGGL((warp_composite_fwd_pipe_kernel<LP, false>), grid16, dim3(NW * kWave), 0, st, layers,
+                               basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, H, W, fpb, ntx16, nt16,
+                               nchunks, nbands, delta);
+          return;
+        }
+      }
       if (src_pts != nullptr) {
         if (L == LP) go(T{}, T{}); else go(N{}, T{});
       } else {

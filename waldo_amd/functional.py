@@ -456,6 +456,22 @@ class _AlphaHead(torch.autograd.Function):
         return gx, None, None, None, None, None, None
 
 
+def disocc_test(layer_max):
+    """Synthesizer.predict's disocclusion test (models/synthesizer.py:447-450): ``layer_max`` (B, Tc, Tp, H, W) =
+    ``alpha_ctx.max(dim=3)[0]`` -> ``dmax`` (B, Tp, H, W) with ``dmax[dmax - dmin > 1] = 0``, max / min over the
+    contexts (NaN-propagating as torch's).  One pass; inference only."""
+    _lib.check_cuda(layer_max)
+    if layer_max.ndim != 5:
+        raise _lib.WaldoHipError(f"disocc_test: layer_max {tuple(layer_max.shape)} is not (B, Tc, Tp, H, W)")
+    layer_max = _c(layer_max.detach())
+    b, tc, tp, h, w = layer_max.shape
+    out = layer_max.new_empty(b, tp, h, w)
+    with torch.cuda.device(layer_max.device):
+        _lib.call("waldo_disocc_test_fwd", _lib.ptr(layer_max), _lib.ptr(out), b, tc, tp, h * w,
+                  _lib.current_stream(layer_max.device))
+    return out
+
+
 def alpha_head(img, prior=None, mask=None, scale=1, bias=0.0, has_alpha=True, remove=False, freeze=False):
     """ImageDecoder.forward's tail (models/nets/lvd.py:245-254: ``+ init_bias``, ``tanh`` and the
     ``circle`` prior on the last channel, ``scale(img, scale_factor)``) fused with the alpha

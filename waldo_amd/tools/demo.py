@@ -20,6 +20,7 @@ import types
 import torch
 import torch.nn as nn
 
+from .. import functional as WF
 from ..nets import flp
 from ..nets.lvd import Warper, decode_output, decoder_tail, estimate_alpha_grid_occ
 from ..nets.wif import WIF
@@ -218,11 +219,11 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames):
     finally:
         warper.keep_alpha_ctx_max = prev
         warper.alpha_ctx_max = None
-    # synthesizer.py:447-450
-    if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the pass over alpha_ctx
+    # synthesizer.py:447-450: max / min over the contexts of max_l alpha_ctx, dmax[dmax - dmin > 1] = 0 -- one pass
+    # over the flow pass's by-product (torch: aminmax, subtract, compare, masked_fill)
+    if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the fused pass's by-product
         mx = alpha_ctx.amax(dim=3)
-    dmin, dmax = torch.aminmax(mx, dim=1)  # (one pass for both reductions of synthesizer.py:447-448)
-    dmax[dmax - dmin > 1] = 0
+    dmax = WF.disocc_test(mx)
     return output[:, :, :3], dmax.unsqueeze(2), wif(raw_output), flow  # (wif: synthesizer.py:460)
 
 
