@@ -45,7 +45,10 @@ int waldo_max_layers(void);
                                      (waldo_warp_composite_bwd_workspace_bytes answers 0) */
 #define WALDO_DEBUG_FWD_PIPELINED 3 /* fused forward, staged, L in {4, 8} layers: the frame loop software-pipelined
                                        (round 5's experiment, bit-identical and 2.5 % slower: DESIGN.md) */
-#define WALDO_DEBUG_COUNT 4
+#define WALDO_DEBUG_FCB_ROWS 4      /* backward of the full-resolution flow passes, 9 .. 17 layers: the lane-layer kernels
+                                       (csrc/flow_ctx_bwd_rows.hip.h: round 5's experiment, same gradients, no faster)
+                                       instead of the one-pixel-per-lane ones */
+#define WALDO_DEBUG_COUNT 5
 int waldo_set_debug_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------

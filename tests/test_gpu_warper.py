@@ -482,6 +482,11 @@ def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
     (dict(num_obj=5, dim=16, load_dim=48, allow_ghost=True), True, False),   # x3
     (dict(num_obj=3, dim=16, load_dim=32, no_filter=True), False, False),    # no layout filter
     (dict(num_obj=4, dim=16, load_dim=16, weight_cls=True, min_cls=0.05), False, True),
+    # 9 .. 17 layers: the lane-layer kernels (csrc/flow_ctx_bwd_rows.hip.h) -- padding lanes (L = 11), the layout filter
+    # with weighted classes, x2 and x1, ghost mask on and off
+    (dict(num_obj=10, dim=16, load_dim=32, use_lyt_filtering=True, weight_cls=True, min_cls=0.05), True, False),
+    (dict(num_obj=16, obj_shape=[2, 2], dim=16, load_dim=0, use_lyt_filtering=True, use_lyt_opacity=True), False, True),
+    (dict(num_obj=8, dim=16, load_dim=16, no_filter=True), False, False),
 ])
 def test_fused_hd_backward(dev, over, ctx_only, include_self):
     """Backward of the fused full-resolution passes (csrc/flow_ctx_bwd.hip) against the CPU oracle's
@@ -548,6 +553,24 @@ def _hd_backward_case(dev, opt, ctx_only, include_self, b, t, nl, seed, per_op=T
         fh = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
         grads[fused], _ = run(fh, wp.input_to_output, dev, lh)
     wp.fuse_hd = True
+    if 9 <= cfg.num_obj + 1 <= 17:
+        # the same chain with the lane-layer kernels (WALDO_DEBUG_FCB_ROWS; csrc/flow_ctx_bwd_rows.hip.h: round 5's
+        # experiment): they form the occlusion products in butterfly order instead of layer order -- rounding apart,
+        # the same gradients, held to the oracle bound as well
+        from waldo_amd import _lib
+        assert _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 1) == 0
+        try:
+            g_px, _ = run(fh, wp.input_to_output, dev, [x.clone().to(dev).requires_grad_() for x in base])
+        finally:
+            _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 0)
+        for i, name in enumerate(names):
+            if g_o[i] is not None:
+                close(g_px[i], g_o[i], rel=True, what=f"lane-layer kernels vs oracle: grad {name}", exact=g_64[i])
+            if g_px[i] is not None:
+                # (grad cls sums +-g over pixels by the SIGN of dist - pr: where the two kernels' class probabilities
+                # differ in the last bit a term flips)
+                close(grads[True][i], g_px[i], tol=2e-4 if name == "cls" else 2e-5, rel=True,
+                      what=f"per-pixel vs lane-layer kernels: grad {name}")
     for i, name in enumerate(names):
         if g_o[i] is None:
             assert grads[True][i] is None or grads[True][i].abs().max() == 0, name
@@ -952,3 +975,4 @@ def test_wif_fuse_random(dev, shape, ab):
     (out * wgt.to(dev)).sum().backward()
     close(v2.grad, vid.grad, rel=True, what="grad_vid")
     close(n2.grad, net.grad, rel=True, what="grad_net")
+

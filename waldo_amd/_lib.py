@@ -82,6 +82,7 @@ DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
 DEBUG_BWD_GENERIC = 2
 DEBUG_FWD_PIPELINED = 3
+DEBUG_FCB_ROWS = 4
 
 _lock = threading.Lock()
 _lib = None

@@ -18,7 +18,7 @@
      defined(WALDO_ABL_FCW_NOOCC) || defined(WALDO_ABL_FCW_NOSTORE) || defined(WALDO_ABL_FWF_NOGATHER) ||       \
      defined(WALDO_ABL_FWF_NORAW) || defined(WALDO_ABL_FWF_ALLSTAGED) || defined(WALDO_ABL_FCB_NOATOMIC) ||     \
      defined(WALDO_ABL_GS_NOATOMIC) || defined(WALDO_ABL_REC_ALIAS) || defined(WALDO_ABL_LAYER_ALIAS) ||        \
-     defined(WALDO_ABL_K1_LDS_PAD) || defined(WALDO_ABL_NO_REC_STORE)) &&                                       \
+     defined(WALDO_ABL_K1_LDS_PAD) || defined(WALDO_ABL_NO_REC_STORE) || defined(WALDO_ABL_ROWS_NOP2)) &&                                       \
     !defined(WALDO_TIMING_ONLY_BUILD)
 #error "WALDO_ABL_* timing-only ablations need -DWALDO_TIMING_ONLY_BUILD (tools_dev/build_variant.py): not a product build"
 #endif
