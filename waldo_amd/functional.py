@@ -58,10 +58,12 @@ def normalise_time_index(ts):
     range in the cache instead of converting an expanded view (synthesizer.py:438) into a fresh temporary --
     and reading it back -- per op.  Under ``torch.inference_mode()`` the result is always a private copy."""
     out = _c(ts.long())
-    if out.numel() == 0 or torch.cuda.is_current_stream_capturing():
+    if out.numel() == 0 or (out.is_cuda and torch.cuda.is_current_stream_capturing()):
         return out
     if out.is_inference():
         if out is ts:
+            if "private" in _index_entry(ts):
+                return ts  # already the private copy an earlier call of the same decode made: no clone, no read-back
             out = ts.clone()
         _index_range(out, private=True)
     else:
@@ -793,13 +795,19 @@ class RawSlots:
         self.raw, self.score, self.channels, self.include_self = raw, score, channels, include_self
         self.version = _index_version(alpha_view)
         self.ptr, self.strides = alpha_view.data_ptr(), alpha_view.stride()
+        self.vouched = False  # set by a caller that hands the view straight on, unmodified (decode_output)
 
     def still_describes(self, alpha):
         """``alpha`` is the view this was made for and nobody wrote to it since (a write went into ``raw``
-        as well, but the sums in ``score`` would be stale).  Inference tensors have no version counter: the one
-        caller that asks for this path, ``decode_output``, removes the attribute before it hands the view out."""
-        return (alpha.data_ptr() == self.ptr and alpha.stride() == self.strides
-                and _index_version(alpha) == self.version)
+        as well, but the sums in ``score`` would be stale).  A tensor made under ``torch.inference_mode()`` has no
+        version counter, so a write in between cannot be seen: it takes the short way only when the caller that
+        kept it in its own hands says so (``vouched``: decode_output); otherwise frame_warp_fuse reads and copies it."""
+        if alpha.data_ptr() != self.ptr or alpha.stride() != self.strides:
+            return False
+        ver = _index_version(alpha)
+        if ver is None:
+            return self.vouched and self.version is None
+        return ver == self.version
 
 
 def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self,

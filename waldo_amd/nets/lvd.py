@@ -539,14 +539,24 @@ def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pr
                   use_disocc=False):
     """``LVD.forward(mode="decode_output")`` (lvd.py:141-153): flow / alpha synthesis, frame warp and
     temporal fusion, the ``use_disocc`` concatenation (lvd.py:148-151) and the split of the score
-    channel.  Returns ``(output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx)``."""
+    channel.  Returns ``(output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx)``.
+
+    ``input`` holds all T frames as in the reference -- or, with ``restrict_to_ctx`` and no ``include_self``, just the
+    context frames the path reads (``Warper._clip_length``).  Without autograd and without ``use_disocc``, ``alpha_ctx``
+    is a strided VIEW into ``raw_output``'s storage (the reference returns two tensors; the values are the same): an
+    in-place write to either shows in the other, and the view keeps the whole buffer alive -- clone it to detach."""
     ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)  # shared by both calls
     # (without autograd the context alphas are composited straight into raw_output's slots: into_raw)
     flow, alpha_unflt, alpha, alpha_ctx, disocc = warper._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts,
                                                                       pred_ts, restrict_to_ctx, into_raw=True)
-    output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
-    if hasattr(alpha_ctx, "_waldo_raw"):
-        del alpha_ctx._waldo_raw  # the view goes to the caller as a plain tensor
+    slots = getattr(alpha_ctx, "_waldo_raw", None)
+    try:
+        if slots is not None:
+            slots.vouched = True  # the view goes from the flow pass to the frame warp in this function's hands
+        output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
+    finally:
+        if slots is not None:
+            del alpha_ctx._waldo_raw  # the view goes to the caller as a plain tensor, whatever happened above
     # (ONE split instead of two slices of `output`: backward is a concatenation of the two gradients, where two
     # SliceBackward nodes each zero-fill a buffer of the full size and autograd adds them)
     output, raw_alpha = torch.split(output, [output.size(2) - 1, 1], dim=2)
