@@ -124,3 +124,13 @@ def test_binding_refuses_a_version_0_library_unless_named_explicitly(tmp_path):
             "    print('refused')\n") % (ROOT, str(so))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "refused" in r.stdout, (r.stdout, r.stderr[-800:])
+
+
+def test_entry_points_issue_no_memset_or_memcpy_nodes():
+    """Fills and copies inside the library are kernels (waldo_common.hip.h: fill_words / copy_bytes): captured into a HIP
+    graph a hipMemsetAsync becomes a memset NODE, and replaying a graph with the grid inversion's 107 MB one after an eager
+    kernel faulted on ROCm 7.2 (round 5, tools_dev/repro_graph_parts.py)."""
+    from waldo_amd import build
+    for src in build.sources() + build._deps():
+        text = re.sub(r"//[^\n]*", "", open(src).read())
+        assert "hipMemsetAsync" not in text and "hipMemcpyAsync" not in text and "hipMemset(" not in text, src

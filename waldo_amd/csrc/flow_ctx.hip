@@ -704,7 +704,11 @@ constexpr int kFwfCap = 1024;  // texels of one context's staged box = one float
 // and the wait for channel c + 1's box can leave channel c's stores in flight (with a store behind a branch the
 // compiler must assume it was not issued and waits for everything: gathers and stores take turns again).
 #ifndef WALDO_FWF_LDS_WAVES
-#define WALDO_FWF_LDS_WAVES 5
+#define WALDO_FWF_LDS_WAVES 4  // 116 VGPRs, NO scratch.  (Five waves -- 96 VGPRs -- measured the same speed in round 4 and spilled two
+                               // dwords: a kernel with scratch inside a replayed HIP graph faulted on this stack)
+#endif
+#ifndef WALDO_FWF_PER_CONTEXT
+#define WALDO_FWF_PER_CONTEXT 1  // Tc = 4: a context whose box does not fit gathers ALONE (0: the whole tile, as in round 4)
 #endif
 #ifndef WALDO_FWF_LDS_DB
 #define WALDO_FWF_LDS_DB 0  // 1: two sets of images, alternating by channel: one barrier per channel instead of two, 33 KB and four
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_l
   }
   lds_barrier();
   // ---- per context (uniform): the tile's box, whether it fits, this thread's float4 of it
-  bool all_staged = true;  // (uniform) every context's box fits its image: otherwise the WHOLE tile gathers
+  unsigned stage_mask = 0;  // (uniform) bit tc: the context's box fits its image; the other contexts gather
   unsigned mine = 0;       // bit tc: this thread's float4 lies inside the context's box (it is loaded all the same)
   uint32_t goff[TCP];      // float index of that float4 in a plane of the context's frame
 #pragma unroll
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_l
     const int yhi = __builtin_amdgcn_readfirstlane((int)hi[0]), xhi = __builtin_amdgcn_readfirstlane((int)hi[1]);
     const int pitch4 = (xhi - xlo + 4) >> 2, nrows = yhi - ylo + 1;  // float4s per row (xlo + 4 pitch4 <= Wd: Wd % 4 == 0)
     const int n4 = nrows * pitch4;
-    all_staged &= n4 <= kBlock;
+    if (n4 <= kBlock) stage_mask |= 1u << tc;
     // t < 256, the + 0.5: the approximate reciprocal gives the exact quotient (pitch4 <= 256 where it matters)
     const int r = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)pitch4));
     if (t < n4) mine |= 1u << tc;
@@ -863,74 +867,98 @@ __global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_l
     fwf_store(obase + (int64_t)c * HWd, acc);
   };
 #ifdef WALDO_ABL_FWF_ALLSTAGED  // timing-only ablation: no tile gathers (wrong values where a box does not fit)
-  all_staged = true;
+  stage_mask = (1u << TCP) - 1u;
 #endif
-  if (all_staged) {
-    f32x4 box4[TCP];
-    auto issue = [&](int c) {  // this thread's float4 of every box, channel c
+  // The channel loop for a compile-time set of staged contexts (bit tc of MASK): a staged context's taps come from
+  // its LDS image (one float4 of its box per thread and channel, loaded a channel ahead), the others' straight from
+  // memory as two 8-byte pairs, also a channel ahead.  Round 4 had two loops -- every context staged, or the WHOLE
+  // tile gathering as soon as one box was too large; under a folded warp (--motion wild) half of all tiles took the
+  // second although most of their contexts fit.  Every vector-memory operation of an instance is unconditional (see
+  // FULL above), which is why the set is a template parameter and not a run-time test per context.
+  auto channel_loop = [&](auto mask_c) {
+    constexpr unsigned MASK = decltype(mask_c)::value;
+    constexpr bool kAny = MASK != 0;
 #pragma unroll
-      for (int tc = 0; tc < TCP; ++tc) box4[tc] = *reinterpret_cast<const f32x4*>(frame[tc] + (int64_t)c * HWd + goff[tc]);
+    for (int tc = 0; tc < TCP; ++tc)
+      if (!((MASK >> tc) & 1u)) {  // a gathering context: byte offsets of its pair origins in the plane
+        const int cy0 = cyx0[tc] >> 16, xb = cyx0[tc] & 0xffff;
+        ob0[tc] = (uint32_t)(__mul24(cy0, Wd) + xb) * 4u;
+        ob1[tc] = (uint32_t)(__mul24(cy1v[tc], Wd) + xb) * 4u;
+      }
+    f32x4 box4[TCP];
+    float gv[TCP][4], nv[TCP][4];
+    auto issue = [&](int c) {  // channel c: this thread's float4 of every staged box, the pairs of the others
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc) {
+        const float* plane = frame[tc] + (int64_t)c * HWd;
+        if ((MASK >> tc) & 1u) {
+          box4[tc] = *reinterpret_cast<const f32x4*>(plane + goff[tc]);
+        } else {
+          const f32x2_fw top = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob0[tc]);
+          const f32x2_fw bot = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob1[tc]);
+          nv[tc][0] = top[0];
+          nv[tc][1] = top[1];
+          nv[tc][2] = bot[0];
+          nv[tc][3] = bot[1];
+        }
+      }
     };
     auto park = [&](int set) {
 #pragma unroll
       for (int tc = 0; tc < TCP; ++tc)
-        if ((mine >> tc) & 1u) *reinterpret_cast<f32x4*>(&img[set][tc][4 * t]) = box4[tc];
+        if (((MASK >> tc) & 1u) && ((mine >> tc) & 1u)) *reinterpret_cast<f32x4*>(&img[set][tc][4 * t]) = box4[tc];
+    };
+    auto take = [&]() {  // the pairs loaded a channel ahead become this channel's
+#pragma unroll
+      for (int tc = 0; tc < TCP; ++tc)
+        if (!((MASK >> tc) & 1u)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gv[tc][k] = nv[tc][k];
+        }
     };
     issue(0);
     park(0);
-    lds_barrier();
+    take();
+    if (kAny) lds_barrier();
     for (int c = 0; c < C; ++c) {
       issue(min(c + 1, C - 1));  // in flight while channel c is sampled and stored (the last trip re-reads its own)
       const int set = WALDO_FWF_LDS_DB ? (c & 1) : 0;
       float tv[TCP][4];
 #pragma unroll
       for (int tc = 0; tc < TCP; ++tc) {
-        const char* im = reinterpret_cast<const char*>(&img[set][tc][0]);
-        tv[tc][0] = *reinterpret_cast<const float*>(im + ob0[tc]);
-        tv[tc][1] = *reinterpret_cast<const float*>(im + ob0[tc] + 4);
-        tv[tc][2] = *reinterpret_cast<const float*>(im + ob1[tc]);
-        tv[tc][3] = *reinterpret_cast<const float*>(im + ob1[tc] + 4);
+        if ((MASK >> tc) & 1u) {
+          const char* im = reinterpret_cast<const char*>(&img[set][tc][0]);
+          tv[tc][0] = *reinterpret_cast<const float*>(im + ob0[tc]);
+          tv[tc][1] = *reinterpret_cast<const float*>(im + ob0[tc] + 4);
+          tv[tc][2] = *reinterpret_cast<const float*>(im + ob1[tc]);
+          tv[tc][3] = *reinterpret_cast<const float*>(im + ob1[tc] + 4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tv[tc][k] = gv[tc][k];
+        }
       }
       assign(tv);
       fuse_store(c, tv);
-      if (!WALDO_FWF_LDS_DB) lds_barrier();  // every thread has read channel c's taps
+      if (kAny && !WALDO_FWF_LDS_DB) lds_barrier();  // every thread has read channel c's taps
       park(WALDO_FWF_LDS_DB ? (set ^ 1) : 0);  // (waits for the boxes of channel c + 1, not for channel c's stores; the other
                                                // set was last read before the previous trip's barrier)
-      lds_barrier();
+      take();
+      if (kAny) lds_barrier();
     }
+  };
+  // (uniform dispatch; a context beyond Tc repeats context Tc - 1: same box, same bit)
+  if (FULL && TCP == 4 && WALDO_FWF_PER_CONTEXT) {
+    switch (stage_mask & 15u) {
+#define WALDO_FWF_CASE(M) case M: channel_loop(std::integral_constant<unsigned, M>{}); break;
+      WALDO_FWF_CASE(0) WALDO_FWF_CASE(1) WALDO_FWF_CASE(2) WALDO_FWF_CASE(3) WALDO_FWF_CASE(4) WALDO_FWF_CASE(5)
+      WALDO_FWF_CASE(6) WALDO_FWF_CASE(7) WALDO_FWF_CASE(8) WALDO_FWF_CASE(9) WALDO_FWF_CASE(10) WALDO_FWF_CASE(11)
+      WALDO_FWF_CASE(12) WALDO_FWF_CASE(13) WALDO_FWF_CASE(14) WALDO_FWF_CASE(15)
+#undef WALDO_FWF_CASE
+    }
+  } else if (stage_mask == (1u << TCP) - 1u) {
+    channel_loop(std::integral_constant<unsigned, (1u << TCP) - 1u>{});
   } else {
-    // some context's box is too large for its image (a folded or strongly sheared warp): the pair gathers of the
-    // kernel above for the whole tile, software-pipelined the same way
-#pragma unroll
-    for (int tc = 0; tc < TCP; ++tc) {
-      const int cy0 = cyx0[tc] >> 16, xb = cyx0[tc] & 0xffff;
-      ob0[tc] = (uint32_t)(__mul24(cy0, Wd) + xb) * 4u;
-      ob1[tc] = (uint32_t)(__mul24(cy1v[tc], Wd) + xb) * 4u;
-    }
-    float tv[TCP][4];
-    auto load_taps = [&](int c, float (&v)[TCP][4]) {
-#pragma unroll
-      for (int tc = 0; tc < TCP; ++tc) {
-        const float* plane = frame[tc] + (int64_t)c * HWd;
-        const f32x2_fw top = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob0[tc]);
-        const f32x2_fw bot = *reinterpret_cast<const f32x2_fw*>(reinterpret_cast<const char*>(plane) + ob1[tc]);
-        v[tc][0] = top[0];
-        v[tc][1] = top[1];
-        v[tc][2] = bot[0];
-        v[tc][3] = bot[1];
-      }
-    };
-    load_taps(0, tv);
-    for (int c = 0; c < C; ++c) {
-      float nv[TCP][4];
-      load_taps(min(c + 1, C - 1), nv);
-      assign(tv);
-      fuse_store(c, tv);
-#pragma unroll
-      for (int tc = 0; tc < TCP; ++tc)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tv[tc][k] = nv[tc][k];
-    }
+    channel_loop(std::integral_constant<unsigned, 0u>{});
   }
   float acc = 0.0f;  // the score channel
 #pragma unroll

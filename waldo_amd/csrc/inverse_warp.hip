@@ -20,7 +20,7 @@
 
 namespace waldo {
 
-constexpr int kNoWinner = 0x7f7f7f7f;  // hipMemsetAsync(0x7f)
+constexpr int kNoWinner = 0x7f7f7f7f;
 
 // ---- step 1+2: resized displacement, target cell, winner election
 __global__ __launch_bounds__(kBlock) void iw_splat_kernel(
@@ -813,7 +813,8 @@ int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const fl
   const int Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int HW = H * W, HWp = Hp * Wp;
   dim3 gs((HW + kBlock - 1) / kBlock, (unsigned)B), gp((HWp + kBlock - 1) / kBlock, (unsigned)B);
-  (void)hipMemsetAsync(winner, 0x7f, sizeof(int) * (size_t)B * HW, st);
+  // every cell starts without a winner (a fill KERNEL: see fill_words in waldo_common.hip.h)
+  fill_words(winner, (unsigned)kNoWinner, sizeof(int) * (size_t)B * HW, st);
   hipLaunchKernelGGL(iw_splat_kernel, gs, dim3(kBlock), 0, st, src_grid, src_id, dxy, cell, winner,
                      rank, Hs, Ws, H, W);
   if (order) {
@@ -857,7 +858,7 @@ int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const fl
   }
   // the final mask is left in mask_a for the backward
   if (mi != mask_a)
-    (void)hipMemcpyAsync(mask_a, mi, (size_t)n, hipMemcpyDeviceToDevice, st);
+    copy_bytes(mask_a, mi, (size_t)n, st);
   hipLaunchKernelGGL(iw_finalize_kernel, gs, dim3(kBlock), 0, st, fin, mask_a, tgt_id, out, H, W,
                      pad);
   return launch_status(fn);

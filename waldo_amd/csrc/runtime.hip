@@ -26,6 +26,39 @@ int launch_status(const char* what) {
   return WALDO_OK;
 }
 
+__global__ __launch_bounds__(kBlock) void fill_words_kernel(unsigned* __restrict__ dst, unsigned word, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (i + 3 < n && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    *reinterpret_cast<uint4*>(dst + i) = make_uint4(word, word, word, word);
+  } else {
+    for (size_t k = i; k < n && k < i + 4; ++k) dst[k] = word;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void copy_bytes_kernel(unsigned char* __restrict__ dst,
+                                                            const unsigned char* __restrict__ src, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  const bool wide = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  if (i + 15 < n && wide) {
+    *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+  } else {
+    for (size_t k = i; k < n && k < i + 16; ++k) dst[k] = src[k];
+  }
+}
+
+void fill_words(void* dst, unsigned word, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return;
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, st,
+                     reinterpret_cast<unsigned*>(dst), word, n);
+}
+
+void copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)((bytes + 16 * kBlock - 1) / (16 * kBlock))), dim3(kBlock), 0, st,
+                     reinterpret_cast<unsigned char*>(dst), reinterpret_cast<const unsigned char*>(src), bytes);
+}
+
 static std::atomic<int> g_debug[WALDO_DEBUG_COUNT];
 
 bool debug_option(int option) {

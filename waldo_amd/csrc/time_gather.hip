@@ -159,7 +159,7 @@ extern "C" int waldo_time_gather_bwd(const float* grad_out, const int64_t* ctx_t
       set_error("waldo_time_gather_bwd: null pointer");
       return WALDO_EINVAL;
     }
-    (void)hipMemsetAsync(grad_x, 0, (size_t)B * T * P * 2 * sizeof(float), (hipStream_t)stream);
+    fill_words(grad_x, 0u, (size_t)B * T * P * 2 * sizeof(float), (hipStream_t)stream);
     return launch_status("waldo_time_gather_bwd");
   }
   const int rc = check_time_gather("waldo_time_gather_bwd", grad_out, pred_ts, grad_x, B, T, Tc, Tp, P, HW, subtract,

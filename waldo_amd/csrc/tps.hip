@@ -295,8 +295,7 @@ extern "C" int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid,
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_mapping, 0, sizeof(float) * B * K3 * 2, st) != hipSuccess)
-    return launch_status("waldo_tps_grid_bwd(memset)");
+  fill_words(grad_mapping, 0u, sizeof(float) * B * K3 * 2, st);
   const int64_t per_chunk = (int64_t)kBlock * kGradPPT;
   const int64_t nchunks = (HW + per_chunk - 1) / per_chunk, groups_b = (B + kGradNB - 1) / kGradNB;
   // several chunks per workgroup (fewer atomics per output) while keeping >= ~512 workgroups

@@ -29,6 +29,13 @@ void set_error(const char* fmt, ...);
 int launch_status(const char* what);
 bool debug_option(int option);  // waldo_set_debug_option (tests only; all off by default)
 
+// Fills and copies inside the entry points are KERNELS, never hipMemsetAsync / hipMemcpyAsync: captured into a HIP graph
+// those become memset / memcpy NODES, and on this stack (ROCm 7.2, gfx950) the replay of a graph with a large memset node
+// that followed an eager kernel on the same stream ended in a memory access fault (round 5: the 107 MB "no winner" fill
+// of the grid inversion, tools_dev/repro_graph_parts.py); kernel nodes replay.  One workgroup per 4 KB.
+void fill_words(void* dst, unsigned word, size_t bytes, hipStream_t st);  // bytes % 4 == 0, dst 4-byte aligned
+void copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st);
+
 constexpr int kWave = 64;   // gfx950 wavefront
 constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
 

@@ -120,8 +120,8 @@ extern "C" int waldo_wif_fuse_bwd(const float* vid, const float* net, const floa
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (grad_vid) (void)hipMemsetAsync(grad_vid, 0, sizeof(float) * (size_t)(N * Tc * C * HW), st);
-  if (grad_net) (void)hipMemsetAsync(grad_net, 0, sizeof(float) * (size_t)(N * Tc * Co * HW), st);
+  if (grad_vid) fill_words(grad_vid, 0u, sizeof(float) * (size_t)(N * Tc * C * HW), st);
+  if (grad_net) fill_words(grad_net, 0u, sizeof(float) * (size_t)(N * Tc * Co * HW), st);
   const int tiles = (int)((HW + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(wif_fuse_bwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0, st, vid, net,
                      out, grad_out, grad_vid, grad_net, Tc, C, Co, HW, tiles, ab);
