@@ -132,17 +132,31 @@ int waldo_grid_sample2d_fwd(const float* input, const float* grid, float* output
  *   out_group / out_stride / out_offset: output map n is written to slot (n / out_group) * out_stride + out_offset +
  *     n % out_group of an output tensor of (slots, C, Ho, Wo) maps ((N, N, 0): the plain output).  With (1, L, 0) for
  *     the background and (No, L, 1) for the objects the two calls of Warper.layer_to_output (lvd.py:533-537) write
- *     straight into the (frames, L, C, Ho, Wo) tensor its torch.cat would build. */
+ *     straight into the (frames, L, C, Ho, Wo) tensor its torch.cat would build;
+ *   pre_scale / pre_bias: the image sampled is pre_scale * input + pre_bias -- Warper.grid_to_flow[_ctx] warps
+ *     `(obj_alpha + 1) / 2` and `(bg_alpha + 1) / 2` (lvd.py:602-606, 716-720): (0.5, 0.5) warps them without the
+ *     two images being written first.  (1, 0): the plain call. */
 int waldo_grid_sample2d_ex_fwd(const float* input, const float* grid, float* output, float* mask_out,
                                int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
                                int64_t outer_div, int64_t inner, int64_t grid_outer_div, int64_t grid_inner,
-                               int64_t out_group, int64_t out_stride, int64_t out_offset, waldo_stream_t stream);
+                               int64_t out_group, int64_t out_stride, int64_t out_offset, float pre_scale,
+                               float pre_bias, waldo_stream_t stream);
 /* grad_input (Nin,C,Hi,Wi) must be ZERO-FILLED by the caller (accumulated with atomics; may be
  * NULL to skip); grad_grid (N,Ho,Wo,2) is overwritten (may be NULL to skip). */
 int waldo_grid_sample2d_bwd(const float* input, const float* grid, const float* grad_output,
                             float* grad_input, float* grad_grid, int64_t N, int C, int Hi, int Wi,
                             int Ho, int Wo, float delta, int64_t outer_div, int64_t inner,
                             waldo_stream_t stream);
+/* The backward of a waldo_grid_sample2d_ex_fwd call (one grid per output map): grad_output is the gradient of the
+ * WHOLE (slots, C, Ho, Wo) tensor the forward wrote into, and map n reads slot (n / gout_group) * gout_stride +
+ * gout_offset + n % gout_group of it -- the backward of Warper.layer_to_output's torch.cat (lvd.py:533-537) without
+ * the two slices of the gradient being copied out first; pre_scale / pre_bias as in the forward (grad_input is the
+ * gradient of `input`, not of the scaled image). */
+int waldo_grid_sample2d_ex_bwd(const float* input, const float* grid, const float* grad_output,
+                               float* grad_input, float* grad_grid, int64_t N, int C, int Hi, int Wi,
+                               int Ho, int Wo, float delta, int64_t outer_div, int64_t inner,
+                               int64_t gout_group, int64_t gout_stride, int64_t gout_offset, float pre_scale,
+                               float pre_bias, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A6. Occlusion product / soft-alpha composite -- replaces the
@@ -280,8 +294,9 @@ int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const f
  * Backward of A9 / A10 (csrc/flow_ctx_bwd.hip): the reference's live backward path in LVD training
  * (models/synthesizer.py:841 through models/nets/lvd.py:602-853).  Shapes as the forward entry points.
  *
- * waldo_flow_ctx_alpha_bwd:  grad_a01 (B*Tw,L,Hd,Wd) = d loss / d a01 (a caller that also holds a
- *   gradient of alpha_out = 2 a01 - 1 adds twice that);  grad_alpha_lr (B*Tw,L,H,W) OVERWRITTEN;
+ * waldo_flow_ctx_alpha_bwd:  grad_a01, grad_alpha_out (B*Tw,L,Hd,Wd) = d loss / d a01 and d loss / d alpha_out, the
+ *   two outputs of the forward (alpha_out = 2 a01 - 1: the kernel reads grad_a01 + 2 grad_alpha_out; either may be
+ *   NULL = zero, not both);  grad_alpha_lr (B*Tw,L,H,W) OVERWRITTEN;
  *   grad_dist (B,L-1,Nl) and grad_occ (B,T,L,L) must be ZERO-FILLED (one float atomic per workgroup
  *   and entry; either may be NULL);  workspace: B*Tw*L*Hd*Wd floats when scale > 1 (the gradient at
  *   the HD raster, transposed-upsampled by a gather pass), unused at scale 1.
@@ -295,9 +310,9 @@ int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const f
  *   (`input`) are data: no gradient is produced for them.
  * ------------------------------------------------------------------------------------- */
 int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* input, const float* dist,
-                             const float* occ, const float* grad_a01, float* grad_alpha_lr,
-                             float* grad_dist, float* grad_occ, float* workspace, int B, int T, int Tw,
-                             int L, int Nl, int C, int chan_off, int H, int W, int scale,
+                             const float* occ, const float* grad_a01, const float* grad_alpha_out,
+                             float* grad_alpha_lr, float* grad_dist, float* grad_occ, float* workspace, int B,
+                             int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W, int scale,
                              waldo_stream_t stream);
 int waldo_flow_ctx_warp_bwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                             const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,

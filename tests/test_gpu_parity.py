@@ -185,6 +185,80 @@ def test_grid_sample_mask_by_product(dev, hwo):
     close(x.grad, x2.grad, 1e-5, rel=True, what="grad_input (float atomics: order of additions)")
 
 
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("hwo", [(12, 10), (16, 32)])
+def test_layers_to_output_is_the_concatenation(dev, hwo, shared):
+    """WF.layers_to_output = Warper.layer_to_output (lvd.py:533-559) as one differentiable op.  With pre = (1, 0)
+    its forward has the bits of `cat([grid_sample(bg), grid_sample(obj)])`, its grid gradients too (they are written,
+    not accumulated), its image gradients agree up to the order of the float atomics; with pre = (0.5, 0.5) it is
+    `cat(...)` of `(x + 1) / 2` (grid_to_flow's rough alphas, lvd.py:602-606) to rounding, values and gradients;
+    against the CPU restatement as well.  `shared`: the images shared over time (lvd.py:544,555)."""
+    from waldo_amd import _lib, functional as WF
+    b, t, no, c, ho, wo = 2, 3, 4, 2, 8, 8
+    h, w = hwo
+    frames = b * t
+    torch.manual_seed(5)
+    obj = torch.randn(b * no if shared else frames * no, c, ho, wo, device=dev)
+    bg = torch.randn(b if shared else frames, c, h, w, device=dev)
+    gobj = torch.rand(frames * no, h, w, 2, device=dev) * 2.6 - 1.3
+    gbg = torch.rand(frames, h, w, 2, device=dev) * 2.6 - 1.3
+    obc, bbc = ((t * no, no), (t, 1)) if shared else (None, None)
+    wgt = torch.randn(frames, no + 1, c, h, w, device=dev)
+
+    def spelled(pre, delta):
+        leaves = [x.clone().requires_grad_() for x in (obj, bg, gobj, gbg)]
+        o, g, go, gb = leaves
+        oo, gg = (o, g) if pre is None else ((o + 1) / 2, (g + 1) / 2)
+        out = torch.cat([WF.grid_sample(gg, gb, delta=delta, broadcast=bbc).view(frames, 1, c, h, w),
+                         WF.grid_sample(oo, go, delta=delta, broadcast=obc).view(frames, no, c, h, w)], dim=1)
+        (out * wgt).sum().backward()
+        return out.detach(), [x.grad for x in leaves]
+
+    def fused(pre, delta, mask=False):
+        leaves = [x.clone().requires_grad_() for x in (obj, bg, gobj, gbg)]
+        o, g, go, gb = leaves
+        out = WF.layers_to_output(o, g, go, gb, delta, delta, obc, bbc, pre if pre is not None else (1.0, 0.0), mask)
+        out, m = out if mask else (out, None)
+        (out * wgt).sum().backward()
+        return out.detach(), [x.grad for x in leaves], m
+
+    for delta in (0.0, 1.0):
+        want, wg = spelled(None, delta)
+        got, gg, mask = fused(None, delta, mask=True)
+        assert torch.equal(got, want)
+        assert torch.equal(gg[2], wg[2]) and torch.equal(gg[3], wg[3])
+        close(gg[0], wg[0], 1e-5, rel=True, what="grad_obj (float atomics: order of additions)")
+        close(gg[1], wg[1], 1e-5, rel=True, what="grad_bg")
+        assert not mask.requires_grad
+        assert torch.equal(mask, WF.grid_sample(torch.ones(frames * no, 1, ho, wo, device=dev), gobj))
+    want, wg = spelled((0.5, 0.5), 0.0)
+    got, gg, _ = fused((0.5, 0.5), 0.0)
+    close(got, want, 1e-6, what="out, (x + 1) / 2 folded into the taps")
+    for a, bb, name in zip(gg, wg, ("grad_obj", "grad_bg", "grad_grid_obj", "grad_grid_bg")):
+        close(a, bb, 1e-5, rel=True, what=name)
+    # the CPU restatement of the spelled-out form
+    leaves = [x.detach().cpu().requires_grad_() for x in (obj, bg, gobj, gbg)]
+    o, g, go, gb = leaves
+    if shared:
+        oe = o.view(b, 1, no, c, ho, wo).expand(-1, t, -1, -1, -1, -1).reshape(frames * no, c, ho, wo)
+        ge = g.view(b, 1, c, h, w).expand(-1, t, -1, -1, -1).reshape(frames, c, h, w)
+    else:
+        oe, ge = o, g
+    ref = torch.cat([O.grid_sample_delta((ge + 1) / 2, gb, 0.0).view(frames, 1, c, h, w),
+                     O.grid_sample_delta((oe + 1) / 2, go, 0.0).view(frames, no, c, h, w)], dim=1)
+    (ref * wgt.cpu()).sum().backward()
+    close(got, ref, what="out vs oracle")
+    for a, x, name in zip(gg, leaves, ("grad_obj", "grad_bg", "grad_grid_obj", "grad_grid_bg")):
+        close(a, x.grad, rel=True, what=name + " vs oracle")
+    with pytest.raises(_lib.WaldoHipError):
+        WF.layers_to_output(obj, bg, gobj[:-1], gbg)          # not a whole number of objects per frame
+    with pytest.raises(_lib.WaldoHipError):
+        WF.layers_to_output(obj, bg[:, :1], gobj, gbg)        # channel counts differ
+    empty = WF.layers_to_output(obj[:0], bg if shared else bg, gobj[:0], gbg, 0.0, 0.0, None, bbc)
+    assert empty.shape == (frames, 1, c, h, w)                 # no objects: the background alone
+    assert torch.equal(empty[:, 0], WF.grid_sample(bg, gbg, delta=0.0, broadcast=bbc))
+
+
 def test_grid_sample_empty(dev):
     from waldo_amd import functional as WF
     out = WF.grid_sample(torch.zeros(0, 3, 4, 4, device=dev), torch.zeros(0, 5, 5, 2, device=dev))

@@ -476,6 +476,45 @@ def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
         assert (a01 == 0).float().mean().item() > 0.5
 
 
+@pytest.mark.parametrize("nl,s,rows", [(5, 2, False), (12, 1, False), (17, 1, False), (17, 1, True)])
+def test_flow_ctx_alpha_backward_takes_both_output_gradients(dev, nl, s, rows):
+    """waldo_flow_ctx_alpha_bwd reads d loss / d a01 and d loss / d alpha_out (= 2 a01 - 1) and sums them itself:
+    a loss on both outputs gives the gradients of the same loss on `a01` alone with the two gradients added first
+    (g_a01 + 2 g_alpha_out, what the wrapper used to do in two passes) -- grad_alpha_lr bit for bit (it is written,
+    not accumulated), grad_dist / grad_occ up to the order of their float atomics; and each output alone."""
+    from waldo_amd import _lib, functional as WF
+    b, t, tw, ncls, h, w = 2, 3, 2, 20, 16, 32
+    hd, wd = h * s, w * s
+    g = torch.Generator(device=dev).manual_seed(35 + nl)
+    alpha_lr = torch.rand(b * tw, nl, h, w, generator=g, device=dev)
+    inp = torch.randn(b, t, 3 + ncls, hd, wd, generator=g, device=dev) * 2
+    dist = torch.rand(b, nl - 1, ncls, generator=g, device=dev).softmax(dim=2)
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    w1 = torch.randn(b * tw, nl, hd, wd, generator=g, device=dev)
+    w2 = torch.randn(b * tw, nl, hd, wd, generator=g, device=dev)
+
+    def grads(loss):
+        leaves = [x.clone().requires_grad_() for x in (alpha_lr, dist, occ)]
+        a01, alpha = WF.flow_ctx_alpha(leaves[0], inp, leaves[1], leaves[2], tw, 3, s)
+        loss(a01, alpha).backward()
+        return [x.grad for x in leaves]
+
+    if rows:
+        assert _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 1) == 0
+    try:
+        for name, two, one in (
+                ("both", lambda a01, alpha: (a01 * w1).sum() + (alpha * w2).sum(), lambda a01, alpha: (a01 * (w1 + 2.0 * w2)).sum()),
+                ("alpha_out alone", lambda a01, alpha: (alpha * w2).sum(), lambda a01, alpha: (a01 * (2.0 * w2)).sum()),
+                ("a01 alone", lambda a01, alpha: (a01 * w1).sum(), lambda a01, alpha: (a01 * w1).sum() + 0.0 * alpha.sum())):
+            got, want = grads(two), grads(one)
+            assert torch.equal(got[0], want[0]), f"{name}: grad_alpha_lr"
+            close(got[1], want[1], 1e-5, rel=True, what=f"{name}: grad_dist (float atomics)")
+            close(got[2], want[2], 1e-5, rel=True, what=f"{name}: grad_occ (float atomics)")
+    finally:
+        if rows:
+            _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 0)
+
+
 @pytest.mark.parametrize("over,ctx_only,include_self", [
     (dict(num_obj=3, dim=16, load_dim=0), False, True),                       # the LVD recipe's shape: x1, ctx "prev"
     (dict(num_obj=16, obj_shape=[2, 2], dim=8, load_dim=32), True, False),   # L = 17, x4, ghost mask

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1011
+ABI_VERSION = 1012
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -35,9 +35,11 @@ SIGNATURES = {
     "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
                                 _i64, _i64, _i64, _stream],
     "waldo_grid_sample2d_ex_fwd": [_c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
-                                   _i64, _i64, _i64, _i64, _i64, _i64, _stream],
+                                   _i64, _i64, _i64, _i64, _i64, _i64, _flt, _flt, _stream],
     "waldo_grid_sample2d_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int,
                                 _flt, _i64, _i64, _stream],
+    "waldo_grid_sample2d_ex_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int,
+                                   _flt, _i64, _i64, _i64, _i64, _i64, _flt, _flt, _stream],
     "waldo_occ_composite_fwd": [_c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
     "waldo_occ_composite_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _i64, _i64, _stream],
     "waldo_compute_occ_fwd": [_c_f, _c_f, _i64, _int, _flt, _stream],
@@ -52,7 +54,7 @@ SIGNATURES = {
     "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
     "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 11 + [_int] * 11 + [_stream],
     "waldo_frame_warp_fuse_raw_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
-    "waldo_flow_ctx_alpha_bwd": [_c_f] * 9 + [_int] * 10 + [_stream],
+    "waldo_flow_ctx_alpha_bwd": [_c_f] * 10 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_bwd": [_c_f] * 8 + [_int] * 9 + [_flt, _stream],
     "waldo_lyt_dist_fwd": [_c_f, _c_f, _i64, _i64, _c_f, _flt] + [_c_f] * 4 + [_i64] + [_int] * 7 + [_stream],

@@ -1159,16 +1159,24 @@ static int frame_warp_fuse_launch(const char* fn, const float* input, const floa
 #if WALDO_FWF_LDS && WALDO_FWF_TP_INNER && WALDO_FWF_TILE_COLS == 32
   // (16-byte loads of the boxes: rows that start on a multiple of four texels from a 16-byte aligned base)
   if (Wd % 4 == 0 && (reinterpret_cast<uintptr_t>(input) & 15) == 0 && Tc <= 4) {
-    if (Tc == 4 && !include_self)
-      hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<4, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                         alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
-    else
-      hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<4, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                         alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+    // (the context count is a template parameter: a padding context repeats the last real one -- its taps, its box, its
+    // loads -- so one context compiled for four did four contexts' work: the LVD recipe's "prev" mode, 114 us per call)
+#define WALDO_FWF_LAUNCH(TCPV, FULLV)                                                                                   \
+  hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<TCPV, FULLV>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow, \
+                     alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, \
+                     geom.nbands)
+    if (Tc == 4 && !include_self) WALDO_FWF_LAUNCH(4, true);
+    else if (Tc == 1) WALDO_FWF_LAUNCH(1, false);
+    else if (Tc == 2) WALDO_FWF_LAUNCH(2, false);
+    else WALDO_FWF_LAUNCH(4, false);
+#undef WALDO_FWF_LAUNCH
     return launch_status(fn);
   }
 #endif
-  if (Tc <= 4)
+  if (Tc == 1)
+    hipLaunchKernelGGL(frame_warp_fuse_kernel<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
+                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+  else if (Tc <= 4)
     hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
                        alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   else

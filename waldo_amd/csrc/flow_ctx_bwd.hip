@@ -93,13 +93,22 @@ __device__ __forceinline__ void composite_bwd(const float (&a)[LP], const float 
   }
 }
 
+// d loss / d a01 from the gradients of the two outputs of the forward, a01 and alpha_out = 2 a01 - 1: what the caller
+// summed as `g_a01 + 2 * g_alpha_out` in two passes over (B*Tw, L, Hd, Wd) before the call (the same bits: the
+// doubling is exact).  Either pointer may be null (uniform), not both.
+__device__ __forceinline__ float grad_of_a01(const float* g_a01, const float* g_aout, int64_t at) {
+  if (g_aout == nullptr) return g_a01[at];
+  if (g_a01 == nullptr) return 2.0f * g_aout[at];
+  return g_a01[at] + 2.0f * g_aout[at];
+}
+
 template <int LP>
 __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_bwd_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, const float* __restrict__ g_a01,
-    float* __restrict__ g_up, float* __restrict__ g_dist, float* __restrict__ g_occ, int T, int Tw,
-    int L, int Nl, int C, int chan_off, int H, int W, int scale, int tiles, int tiles_per_block,
-    int groups) {
+    const float* __restrict__ g_aout, float* __restrict__ g_up, float* __restrict__ g_dist,
+    float* __restrict__ g_occ, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W, int scale,
+    int tiles, int tiles_per_block, int groups) {
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
   const int n = blockIdx.x / groups;  // (b, t) with t < Tw
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
       f[l] = 1.0f;
-      gv[l] = (l < L && live) ? g_a01[((int64_t)n * L + min(l, L - 1)) * HWd + pc] : 0.0f;
+      gv[l] = (l < L && live) ? grad_of_a01(g_a01, g_aout, ((int64_t)n * L + min(l, L - 1)) * HWd + pc) : 0.0f;
     }
     float pr[kMaxCls];
     if (filt) {
@@ -516,10 +525,10 @@ static int check_bwd_shape(const char* fn, int64_t N, int L, int H, int W, int s
     break;
 
 extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* input, const float* dist,
-                                        const float* occ, const float* grad_a01, float* grad_alpha_lr,
-                                        float* grad_dist, float* grad_occ, float* workspace, int B, int T,
-                                        int Tw, int L, int Nl, int C, int chan_off, int H, int W, int scale,
-                                        waldo_stream_t stream) {
+                                        const float* occ, const float* grad_a01, const float* grad_alpha_out,
+                                        float* grad_alpha_lr, float* grad_dist, float* grad_occ, float* workspace,
+                                        int B, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W,
+                                        int scale, waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tw;
   if (int rc = check_bwd_shape("waldo_flow_ctx_alpha_bwd", N, L, H, W, scale)) return rc;
   if (B < 0 || T < 1 || Tw < 1 || Tw > T ||
@@ -528,8 +537,8 @@ extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* inpu
     return WALDO_EINVAL;
   }
   if (N == 0) return WALDO_OK;
-  if (!alpha_lr || !occ || !grad_a01 || !grad_alpha_lr || (dist != nullptr && !input) || (scale > 1 && !workspace)) {
-    set_error("waldo_flow_ctx_alpha_bwd: null pointer (scale > 1 needs the (B*Tw, L, Hd, Wd) workspace)");
+  if (!alpha_lr || !occ || (!grad_a01 && !grad_alpha_out) || !grad_alpha_lr || (dist != nullptr && !input) || (scale > 1 && !workspace)) {
+    set_error("waldo_flow_ctx_alpha_bwd: null pointer (one of grad_a01 / grad_alpha_out; scale > 1 needs the (B*Tw, L, Hd, Wd) workspace)");
     return WALDO_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -539,19 +548,19 @@ extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* inpu
   if (rows_kernels(L)) {
     if (dist == nullptr || Nl <= 20)
       hipLaunchKernelGGL(flow_ctx_alpha_bwd_rows_kernel<20>, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, alpha_lr,
-                         input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale,
-                         tiles, tpb, groups);
+                         input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W,
+                         scale, tiles, tpb, groups);
     else
       hipLaunchKernelGGL(flow_ctx_alpha_bwd_rows_kernel<32>, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, alpha_lr,
-                         input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale,
-                         tiles, tpb, groups);
+                         input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W,
+                         scale, tiles, tpb, groups);
   } else switch (flow_ctx_pad_l(L)) {
-    WALDO_FCB_CASE(4, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(8, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(12, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(17, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(24, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(32, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(4, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(8, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(12, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(17, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(24, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+    WALDO_FCB_CASE(32, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
   }
   if (scale > 1) {
     const int64_t P = N * L;
@@ -624,13 +633,15 @@ extern "C" int waldo_frame_warp_fuse_bwd(const float* input, const float* flow, 
     return WALDO_EINVAL;
   }
   const dim3 grid((unsigned)((int64_t)B * Tp * tiles));
-  if (Tc <= 4)
-    hipLaunchKernelGGL(frame_warp_fuse_bwd_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, grad_out, grad_raw, grad_flow, grad_alpha, T, Tc, Tp, C, L, Hd, Wd,
-                       include_self, eps, (int)tiles);
-  else
-    hipLaunchKernelGGL(frame_warp_fuse_bwd_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, ctx_ts, grad_out, grad_raw, grad_flow, grad_alpha, T, Tc, Tp, C, L, Hd, Wd,
-                       include_self, eps, (int)tiles);
+  // (a padding context repeats the last real one's taps and its L alpha loads: the count is compiled in for 1, 2, 4)
+#define WALDO_FWFB_LAUNCH(TCPV)                                                                                         \
+  hipLaunchKernelGGL(frame_warp_fuse_bwd_kernel<TCPV>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow, alpha, \
+                     ctx_ts, grad_out, grad_raw, grad_flow, grad_alpha, T, Tc, Tp, C, L, Hd, Wd, include_self, eps,      \
+                     (int)tiles)
+  if (Tc == 1) WALDO_FWFB_LAUNCH(1);
+  else if (Tc == 2) WALDO_FWFB_LAUNCH(2);
+  else if (Tc <= 4) WALDO_FWFB_LAUNCH(4);
+  else WALDO_FWFB_LAUNCH(8);
+#undef WALDO_FWFB_LAUNCH
   return launch_status("waldo_frame_warp_fuse_bwd");
 }

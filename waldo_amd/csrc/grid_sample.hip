@@ -21,6 +21,14 @@ struct OutSlots {
   __device__ __forceinline__ int64_t slot(int64_t n) const { return (n / group) * stride + offset + n % group; }
 };
 
+// The sampled image is `scale * input + bias` (Warper.grid_to_flow warps `(alpha + 1) / 2`, lvd.py:602-606 / 716-720,
+// without the image being written first).  Sampling is linear and the weights of the in-range taps sum to wsum:
+// sample(s x + b + delta) - delta = s sample(x) + (b + delta) wsum - delta.  (1, 0): the plain call, the same bits as
+// before there was a PreAffine -- fmaf(1, v, shift) = v + shift, delta + 0 = delta.
+struct PreAffine {
+  float scale, bias;
+};
+
 // The sample of an all-ones image at the same taps: tap_sample() on the constant 1 (the same operations on the
 // validity products: the bits grid_sample(ones, grid) gives).  Warper.grid_to_flow_ctx asks for it next to the layer
 // flows (`is_obj = obj_to_output(ones) > 0.9`, lvd.py:785-791): the same grids, so the mask is a by-product.
@@ -34,7 +42,7 @@ __device__ __forceinline__ float tap_sample_ones(const Taps& t) {
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
-    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os) {
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os, PreAffine pre) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   if (p >= HWo) return;
@@ -46,8 +54,8 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
   float* out = output + os.slot(n) * C * HWo + p;
   // sum of the weights of the in-range taps: sample(x + delta) = sample(x) + delta * wsum
   const float wsum = (t.w00 + t.w01) + (t.w10 + t.w11);
-  const float shift = fmaf(delta, wsum, -delta);
-  for (int c = 0; c < C; ++c) out[(int64_t)c * HWo] = tap_sample(in + (int64_t)c * HWi, t) + shift;
+  const float shift = fmaf(delta + pre.bias, wsum, -delta);
+  for (int c = 0; c < C; ++c) out[(int64_t)c * HWo] = fmaf(pre.scale, tap_sample(in + (int64_t)c * HWi, t), shift);
 }
 
 // Sum of v over the lanes from this one to the end of its RUN (consecutive lanes with the same scatter address;
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
     const float* __restrict__ input, const float* __restrict__ grid,
     const float* __restrict__ grad_output, float* __restrict__ grad_input,
     float* __restrict__ grad_grid, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles,
-    float delta, int64_t outer_div, int64_t inner) {
+    float delta, int64_t outer_div, int64_t inner, OutSlots gos, PreAffine pre) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p_ = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
   // (a thread past the last pixel works on the last one with zero weights: it takes part in the wavefront's sums)
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
   const int64_t HWi = (int64_t)Hi * Wi;
   const int64_t nin = in_index(n, outer_div, inner);
   const float* in = input + nin * C * HWi;
-  const float* go = grad_output + n * C * HWo + p;
+  const float* go = grad_output + gos.slot(n) * C * HWo + p;  // (the gradient of a tensor written through OutSlots)
+  const float db = delta + pre.bias;
   float gix = 0.0f, giy = 0.0f;
   const float m00 = t.vx0 * t.vy0, m01 = t.vx1 * t.vy0, m10 = t.vx0 * t.vy1, m11 = t.vx1 * t.vy1;
   // ---- the scatter.  A wavefront is 64 consecutive output pixels; where the output is finer than the input (object
@@ -110,10 +119,11 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
   }
   for (int c = 0; c < C; ++c) {
     const float gv = go[(int64_t)c * HWo];
+    const float gvs = gv * pre.scale;  // d out / d input texel = scale * weight
     if (grad_grid != nullptr) {
       const float* pl = in + (int64_t)c * HWi;
-      const float v00 = (ldb(pl, t.o00) + delta) * m00, v01 = (ldb(pl, t.o01) + delta) * m01;
-      const float v10 = (ldb(pl, t.o10) + delta) * m10, v11 = (ldb(pl, t.o11) + delta) * m11;
+      const float v00 = fmaf(pre.scale, ldb(pl, t.o00), db) * m00, v01 = fmaf(pre.scale, ldb(pl, t.o01), db) * m01;
+      const float v10 = fmaf(pre.scale, ldb(pl, t.o10), db) * m10, v11 = fmaf(pre.scale, ldb(pl, t.o11), db) * m11;
       const float ddx = fmaf(t.fy, (v11 - v10) - (v01 - v00), v01 - v00);
       const float top = fmaf(t.fx, v01 - v00, v00);
       const float bot = fmaf(t.fx, v11 - v10, v10);
@@ -126,10 +136,10 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (WALDO_GS_RUNS) {
-          const float sum = run_sum(gv * wq[q], stop[q]);
+          const float sum = run_sum(gvs * wq[q], stop[q]);
           if (head[q] && sum != 0.0f) atomicAdd(gp + (key[q] >> 2), sum);
         } else if (wq[q] != 0.0f) {
-          atomicAdd(gp + (key[q] >> 2), gv * wq[q]);
+          atomicAdd(gp + (key[q] >> 2), gvs * wq[q]);
         }
       }
     }
@@ -197,7 +207,7 @@ __device__ __forceinline__ float pair_sample(const f32x2_gs a, const f32x2_gs b,
 __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
     const float* __restrict__ input, const float* __restrict__ grid, float* __restrict__ output,
     float* __restrict__ mask_out, int64_t N, int C, int Hi, int Wi, int64_t HWo, int tiles, float delta,
-    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os) {
+    int64_t outer_div, int64_t inner, int64_t g_outer_div, int64_t g_inner, OutSlots os, PreAffine pre) {
   const int64_t n = blockIdx.x / tiles;
   const int64_t p = ((int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x) * 4;
   if (p >= HWo) return;
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float wsum = (t[q].w00 + t[q].w01) + (t[q].w10 + t[q].w11);
-    shift[q] = fmaf(delta, wsum, -delta);
+    shift[q] = fmaf(delta + pre.bias, wsum, -delta);
     touches |= (t[q].vx0 + t[q].vx1) * (t[q].vy0 + t[q].vy1) != 0.0f;
   }
   const bool pairs = WALDO_GS_PAIRS && Wi >= 2;  // (uniform)
@@ -240,14 +250,14 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd4_kernel(
       }
       f32x4_gs o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = pair_sample(a[q], b[q], t[q], po[q].shift) + shift[q];
+      for (int q = 0; q < 4; ++q) o[q] = fmaf(pre.scale, pair_sample(a[q], b[q], t[q], po[q].shift), shift[q]);
       *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
     }
   } else {
     for (int c = 0; c < C; ++c) {
       f32x4_gs o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = tap_sample(in + (int64_t)c * HWi, t[q]) + shift[q];
+      for (int q = 0; q < 4; ++q) o[q] = fmaf(pre.scale, tap_sample(in + (int64_t)c * HWi, t[q]), shift[q]);
       *reinterpret_cast<f32x4_gs*>(out + (int64_t)c * HWo) = o;
     }
   }
@@ -281,7 +291,7 @@ using namespace waldo;
 static int grid_sample2d_fwd_launch(const char* fn, const float* input, const float* grid, float* output, float* mask_out,
                                     int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta, int64_t outer_div,
                                     int64_t inner, int64_t grid_outer_div, int64_t grid_inner, OutSlots os,
-                                    waldo_stream_t stream) {
+                                    PreAffine pre, waldo_stream_t stream) {
   if (os.group < 1 || os.stride < os.group || os.offset < 0 || os.offset + os.group > os.stride) {
     set_error("%s: bad output slots (group %lld, stride %lld, offset %lld)", fn, (long long)os.group,
               (long long)os.stride, (long long)os.offset);
@@ -303,13 +313,13 @@ static int grid_sample2d_fwd_launch(const char* fn, const float* input, const fl
     const int tiles4 = (int)((HWo / 4 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(grid_sample2d_fwd4_kernel, dim3((unsigned)(N * tiles4)), dim3(kBlock), 0,
                        (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles4, delta, outer_div, inner,
-                       grid_outer_div, grid_inner, os);
+                       grid_outer_div, grid_inner, os, pre);
     return launch_status(fn);
   }
   const int tiles = (int)((HWo + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(grid_sample2d_fwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
                      (hipStream_t)stream, input, grid, output, mask_out, N, C, Hi, Wi, HWo, tiles, delta,
-                     outer_div, inner, grid_outer_div, grid_inner, os);
+                     outer_div, inner, grid_outer_div, grid_inner, os, pre);
   return launch_status(fn);
 }
 
@@ -319,29 +329,34 @@ extern "C" int waldo_grid_sample2d_fwd(const float* input, const float* grid, fl
                                        int64_t grid_outer_div, int64_t grid_inner, waldo_stream_t stream) {
   return grid_sample2d_fwd_launch("waldo_grid_sample2d_fwd", input, grid, output, nullptr, N, C, Hi, Wi, Ho, Wo, delta,
                                   outer_div, inner, grid_outer_div, grid_inner, OutSlots{N > 0 ? N : 1, N > 0 ? N : 1, 0},
-                                  stream);
+                                  PreAffine{1.0f, 0.0f}, stream);
 }
 
 extern "C" int waldo_grid_sample2d_ex_fwd(const float* input, const float* grid, float* output, float* mask_out,
                                           int64_t N, int C, int Hi, int Wi, int Ho, int Wo, float delta,
                                           int64_t outer_div, int64_t inner, int64_t grid_outer_div,
                                           int64_t grid_inner, int64_t out_group, int64_t out_stride,
-                                          int64_t out_offset, waldo_stream_t stream) {
+                                          int64_t out_offset, float pre_scale, float pre_bias,
+                                          waldo_stream_t stream) {
   return grid_sample2d_fwd_launch("waldo_grid_sample2d_ex_fwd", input, grid, output, mask_out, N, C, Hi, Wi, Ho, Wo,
                                   delta, outer_div, inner, grid_outer_div, grid_inner,
-                                  OutSlots{out_group, out_stride, out_offset}, stream);
+                                  OutSlots{out_group, out_stride, out_offset}, PreAffine{pre_scale, pre_bias}, stream);
 }
 
-extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,
-                                       const float* grad_output, float* grad_input,
-                                       float* grad_grid, int64_t N, int C, int Hi, int Wi, int Ho,
-                                       int Wo, float delta, int64_t outer_div, int64_t inner,
-                                       waldo_stream_t stream) {
-  int rc = check_gs("waldo_grid_sample2d_bwd", N, C, Hi, Wi, Ho, Wo, outer_div, inner);
+static int grid_sample2d_bwd_launch(const char* fn, const float* input, const float* grid, const float* grad_output,
+                                    float* grad_input, float* grad_grid, int64_t N, int C, int Hi, int Wi, int Ho,
+                                    int Wo, float delta, int64_t outer_div, int64_t inner, OutSlots gos, PreAffine pre,
+                                    waldo_stream_t stream) {
+  if (gos.group < 1 || gos.stride < gos.group || gos.offset < 0 || gos.offset + gos.group > gos.stride) {
+    set_error("%s: bad gradient slots (group %lld, stride %lld, offset %lld)", fn, (long long)gos.group,
+              (long long)gos.stride, (long long)gos.offset);
+    return WALDO_EINVAL;
+  }
+  int rc = check_gs(fn, N, C, Hi, Wi, Ho, Wo, outer_div, inner);
   if (rc) return rc;
   if (N == 0) return WALDO_OK;
   if (!input || !grid || !grad_output) {
-    set_error("waldo_grid_sample2d_bwd: null pointer");
+    set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
   }
   if (!grad_input && !grad_grid) return WALDO_OK;
@@ -349,6 +364,26 @@ extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,
   const int tiles = (int)((HWo + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(grid_sample2d_bwd_kernel, dim3((unsigned)(N * tiles)), dim3(kBlock), 0,
                      (hipStream_t)stream, input, grid, grad_output, grad_input, grad_grid, N, C,
-                     Hi, Wi, HWo, tiles, delta, outer_div, inner);
-  return launch_status("waldo_grid_sample2d_bwd");
+                     Hi, Wi, HWo, tiles, delta, outer_div, inner, gos, pre);
+  return launch_status(fn);
+}
+
+extern "C" int waldo_grid_sample2d_bwd(const float* input, const float* grid,
+                                       const float* grad_output, float* grad_input,
+                                       float* grad_grid, int64_t N, int C, int Hi, int Wi, int Ho,
+                                       int Wo, float delta, int64_t outer_div, int64_t inner,
+                                       waldo_stream_t stream) {
+  return grid_sample2d_bwd_launch("waldo_grid_sample2d_bwd", input, grid, grad_output, grad_input, grad_grid, N, C, Hi,
+                                  Wi, Ho, Wo, delta, outer_div, inner, OutSlots{N > 0 ? N : 1, N > 0 ? N : 1, 0},
+                                  PreAffine{1.0f, 0.0f}, stream);
+}
+
+extern "C" int waldo_grid_sample2d_ex_bwd(const float* input, const float* grid, const float* grad_output,
+                                          float* grad_input, float* grad_grid, int64_t N, int C, int Hi, int Wi,
+                                          int Ho, int Wo, float delta, int64_t outer_div, int64_t inner,
+                                          int64_t gout_group, int64_t gout_stride, int64_t gout_offset,
+                                          float pre_scale, float pre_bias, waldo_stream_t stream) {
+  return grid_sample2d_bwd_launch("waldo_grid_sample2d_ex_bwd", input, grid, grad_output, grad_input, grad_grid, N, C,
+                                  Hi, Wi, Ho, Wo, delta, outer_div, inner,
+                                  OutSlots{gout_group, gout_stride, gout_offset}, PreAffine{pre_scale, pre_bias}, stream);
 }

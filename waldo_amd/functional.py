@@ -16,6 +16,30 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _zeros_like_each(*tensors):
+    """Zero-filled tensors shaped like each argument (None -> None), carved out of ONE buffer and filled by ONE launch:
+    the gradients a backward kernel accumulates into with atomics -- at the LVD recipe a fill is a 4 us launch whatever
+    its size, and a backward call that zeroed two or three small tensors paid for each.  Every view starts on a
+    256-byte boundary."""
+    want = [t for t in tensors if t is not None]
+    if not want:
+        return [None] * len(tensors)
+    if len(want) == 1:
+        return [torch.zeros_like(t) if t is not None else None for t in tensors]
+    sizes = [(t.numel() + 63) // 64 * 64 for t in want]
+    flat = torch.zeros(sum(sizes), dtype=want[0].dtype, device=want[0].device)
+    out, at = [], 0
+    it = iter(sizes)
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        n = next(it)
+        out.append(flat[at:at + t.numel()].view(t.shape))
+        at += n
+    return out
+
+
 _INDEX_RANGE = {}  # id(index tensor) -> (weak reference to it, {version: (lowest, highest) index it holds})
 
 
@@ -259,7 +283,7 @@ class _GridSample(torch.autograd.Function):
             if want_mask:
                 _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
                           n, c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
-                          max(n, 1), max(n, 1), 0, _lib.current_stream(inp.device))
+                          max(n, 1), max(n, 1), 0, 1.0, 0.0, _lib.current_stream(inp.device))
             else:
                 _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), n,
                           c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
@@ -336,7 +360,7 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_m
         with torch.cuda.device(inp.device):
             if return_mask or out is not None:
                 _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(res), _lib.ptr(mask),
-                          n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, grp, stride, off,
+                          n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, grp, stride, off, 1.0, 0.0,
                           _lib.current_stream(inp.device))
             else:
                 _lib.call("waldo_grid_sample2d_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(res), n_out, c, hi, wi,
@@ -344,6 +368,96 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_m
         return (res, mask) if return_mask else res
     od, inn = broadcast if broadcast is not None else (None, None)
     return _GridSample.apply(inp, grid, delta, od, inn, bool(return_mask))
+
+
+class _LayersToOutput(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, bg, grid_obj, grid_bg, delta_obj, delta_bg, obj_bc, bg_bc, pre, want_mask):
+        nf, h, w, _ = grid_bg.shape
+        no = grid_obj.shape[0] // max(nf, 1)
+        nl = no + 1
+        c = obj.shape[1]
+        out = obj.new_empty(nf, nl, c, h, w)
+        mask = obj.new_empty(nf * no, 1, h, w) if want_mask else None
+        calls = ((obj, grid_obj, mask, nf * no, delta_obj, obj_bc, (no, nl, 1)),
+                 (bg, grid_bg, None, nf, delta_bg, bg_bc, (1, nl, 0)))
+        with torch.cuda.device(obj.device):
+            for inp, grid, msk, n, delta, bc, slots in calls:
+                if n == 0 or (slots[0] == 0):
+                    continue
+                od, inn = bc if bc is not None else (max(n, 1), max(n, 1))
+                _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(msk),
+                          n, c, inp.shape[2], inp.shape[3], h, w, float(delta), od, inn, max(n, 1), max(n, 1),
+                          *slots, float(pre[0]), float(pre[1]), _lib.current_stream(obj.device))
+        ctx.save_for_backward(obj, bg, grid_obj, grid_bg)
+        ctx.cfg = (float(delta_obj), float(delta_bg), obj_bc, bg_bc, (float(pre[0]), float(pre[1])), no)
+        if want_mask:
+            ctx.mark_non_differentiable(mask)
+            return out, mask
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_mask=None):
+        obj, bg, grid_obj, grid_bg = ctx.saved_tensors
+        delta_obj, delta_bg, obj_bc, bg_bc, pre, no = ctx.cfg
+        nf, h, w, _ = grid_bg.shape
+        nl = no + 1
+        c = obj.shape[1]
+        grad_out = _c(grad_out)
+        need = ctx.needs_input_grad
+        res = []
+        gis = _zeros_like_each(obj if need[0] else None, bg if need[1] else None)
+        calls = ((obj, grid_obj, nf * no, delta_obj, obj_bc, (no, nl, 1), gis[0], need[2]),
+                 (bg, grid_bg, nf, delta_bg, bg_bc, (1, nl, 0), gis[1], need[3]))
+        with torch.cuda.device(obj.device):
+            for inp, grid, n, delta, bc, slots, gi, want_g in calls:
+                want_i = gi is not None
+                gg = torch.empty_like(grid) if want_g else None
+                if n > 0 and slots[0] > 0 and (want_i or want_g):
+                    od, inn = bc if bc is not None else (max(n, 1), max(n, 1))
+                    _lib.call("waldo_grid_sample2d_ex_bwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(grad_out),
+                              _lib.ptr(gi), _lib.ptr(gg), n, c, inp.shape[2], inp.shape[3], h, w, delta, od, inn,
+                              *slots, pre[0], pre[1], _lib.current_stream(obj.device))
+                res.append((gi, gg))
+        return res[0][0], res[1][0], res[0][1], res[1][1], None, None, None, None, None, None
+
+
+def layers_to_output(obj, bg, grid_obj, grid_bg, delta_obj=0.0, delta_bg=0.0, obj_broadcast=None, bg_broadcast=None,
+                     pre=(1.0, 0.0), return_mask=False):
+    """``Warper.layer_to_output`` (models/nets/lvd.py:533-559) as ONE differentiable op: the objects' maps and the
+    background's warped straight into the tensor the reference concatenates,
+
+        torch.cat([grid_sample(bg', grid_bg, delta_bg)[:, None], grid_sample(obj', grid_obj, delta_obj).view(F, No, ...)], 1)
+
+    obj (Nin_o, C, Ho, Wo) with grid_obj (F * No, H, W, 2), bg (Nin_b, C, Hb, Wb) with grid_bg (F, H, W, 2) ->
+    (F, No + 1, C, H, W), the background at layer 0.  ``*_broadcast`` = (outer_div, inner) as in ``grid_sample`` (the
+    reference's ``.expand`` over time).  ``pre`` = (scale, bias): the images warped are ``scale * obj + bias`` and
+    ``scale * bg + bias`` -- ``grid_to_flow`` warps ``(alpha + 1) / 2`` (lvd.py:602-606, 716-720) -- without being written
+    first; the gradients returned are those of ``obj`` / ``bg``.  ``return_mask``: also the warped all-ones canvas of
+    the objects' grids (F * No, 1, H, W) (``grid_sample(..., return_mask=True)``; no gradient).
+
+    Forward: two launches that write disjoint slots of one tensor (no ``cat``); backward: two launches that read their
+    slots of the tensor's gradient (no copies of its two slices)."""
+    _lib.check_cuda(obj, bg, grid_obj, grid_bg)
+    obj, bg, grid_obj, grid_bg = _c(obj), _c(bg), _c(grid_obj), _c(grid_bg)
+    nf, h, w, two = grid_bg.shape
+    ngo = grid_obj.shape[0]
+    if two != 2 or grid_obj.dim() != 4 or tuple(grid_obj.shape[1:]) != (h, w, 2) or obj.dim() != 4 or bg.dim() != 4 or \
+            obj.shape[1] != bg.shape[1] or (nf == 0 and ngo != 0) or (nf > 0 and ngo % nf != 0) or obj.dtype != bg.dtype:
+        raise _lib.WaldoHipError(f"layers_to_output: obj {tuple(obj.shape)} / grid_obj {tuple(grid_obj.shape)} against "
+                                 f"bg {tuple(bg.shape)} / grid_bg {tuple(grid_bg.shape)}")
+    for name, inp, n, bc in (("obj", obj, ngo, obj_broadcast), ("bg", bg, nf, bg_broadcast)):
+        if bc is None:
+            if inp.shape[0] != n:
+                raise _lib.WaldoHipError(f"layers_to_output: {inp.shape[0]} {name} images for {n} grids")
+        else:
+            od, inn = int(bc[0]), int(bc[1])
+            if od < 1 or inn < 1 or (n > 0 and ((n - 1) // od) * inn + min(inn, n) > inp.shape[0]):
+                raise _lib.WaldoHipError(f"layers_to_output: {name} broadcast {bc} of {n} maps over {inp.shape[0]} images")
+    obj_bc = None if obj_broadcast is None else (int(obj_broadcast[0]), int(obj_broadcast[1]))
+    bg_bc = None if bg_broadcast is None else (int(bg_broadcast[0]), int(bg_broadcast[1]))
+    return _LayersToOutput.apply(obj, bg, grid_obj, grid_bg, float(delta_obj), float(delta_bg), obj_bc, bg_bc,
+                                 (float(pre[0]), float(pre[1])), bool(return_mask))
 
 
 # --------------------------------------------------------------------------------------
@@ -659,20 +773,16 @@ class _FlowCtxAlpha(torch.autograd.Function):
         # alpha_out = 2 a01 - 1
         if g_a01 is None and g_out is None:
             return None, None, None, None, None, None, None
-        if g_a01 is None:
-            g = 2.0 * g_out
-        elif g_out is None:
-            g = g_a01
-        else:
-            g = g_a01 + 2.0 * g_out
-        g = _c(g)
+        # (the kernel reads g_a01 + 2 g_out itself: no pass over (B*Tw, L, Hd, Wd) to add them first)
+        g_a01 = _c(g_a01) if g_a01 is not None else None
+        g_out = _c(g_out) if g_out is not None else None
         g_lr = torch.empty_like(alpha_lr)
-        g_dist = torch.zeros_like(dist) if (dist is not None and ctx.needs_input_grad[2]) else None
-        g_occ = torch.zeros_like(occ) if ctx.needs_input_grad[3] else None
+        g_dist, g_occ = _zeros_like_each(dist if (dist is not None and ctx.needs_input_grad[2]) else None,
+                                         occ if ctx.needs_input_grad[3] else None)
         ws = alpha_lr.new_empty(n, nl, hd, wd) if scale > 1 else None
         with torch.cuda.device(alpha_lr.device):
             _lib.call("waldo_flow_ctx_alpha_bwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
-                      _lib.ptr(occ), _lib.ptr(g), _lib.ptr(g_lr), _lib.ptr(g_dist), _lib.ptr(g_occ),
+                      _lib.ptr(occ), _lib.ptr(g_a01), _lib.ptr(g_out), _lib.ptr(g_lr), _lib.ptr(g_dist), _lib.ptr(g_occ),
                       _lib.ptr(ws), b, t, tw, nl, ncls, c, chan_off, h, w, scale,
                       _lib.current_stream(alpha_lr.device))
         return g_lr, None, g_dist, g_occ, None, None, None
@@ -733,8 +843,7 @@ class _FlowCtxWarp(torch.autograd.Function):
         g_actx = _c(g_actx) if g_actx is not None else None
         g_dis = _c(g_dis) if g_dis is not None else None
         g_lr = torch.empty_like(flow_lr)
-        g_a01 = torch.zeros_like(a01) if ctx.needs_input_grad[2] else None
-        g_occ = torch.zeros_like(occ) if ctx.needs_input_grad[5] else None
+        g_a01, g_occ = _zeros_like_each(a01 if ctx.needs_input_grad[2] else None, occ if ctx.needs_input_grad[5] else None)
         ws = flow_lr.new_empty(m, nl, 2, hd, wd) if scale > 1 else None
         with torch.cuda.device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_bwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
@@ -1038,8 +1147,7 @@ class _WarpComposite(torch.autograd.Function):
         grad_rgb = _c(grad_rgb)
         if grad_alpha is not None:
             grad_alpha = _c(grad_alpha)
-        gm = torch.zeros_like(mapping) if ctx.needs_input_grad[1] else None
-        go = torch.zeros_like(occ) if ctx.needs_input_grad[2] else None
+        gm, go = _zeros_like_each(mapping if ctx.needs_input_grad[1] else None, occ if ctx.needs_input_grad[2] else None)
         # 0: the shape is served by the generic kernel (or a test asked for it: WALDO_DEBUG_BWD_GENERIC)
         ws_bytes = _lib.load().waldo_warp_composite_bwd_workspace_bytes(f, nl, h, w, k3)
         ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=layers.device) if ws_bytes else None

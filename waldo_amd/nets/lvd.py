@@ -160,9 +160,33 @@ class Warper(nn.Module):
         return WF.grid_sample(src.reshape(b * t, c, h, w), tgt_grid_bg.reshape(b * t, h, w, 2)).view(b, t, c, h, w)
 
     # ------------------------------------------------------------------ layer -> image space
-    def layer_to_output(self, obj, bg, grid, delta_bg=1, delta_obj=1):
-        output = self.obj_to_output(obj, grid, delta_obj)
-        return torch.cat([self.bg_to_output(bg, grid, delta_bg), output], dim=2)
+    def layer_to_output(self, obj, bg, grid, delta_bg=1, delta_obj=1, pre=None, return_mask=False):
+        """Reference lvd.py:533-537: ``cat([bg_to_output(bg), obj_to_output(obj)], dim=2)`` -- here one op whose two
+        launches write the concatenated tensor directly and whose backward reads the two parts of its gradient in
+        place (``WF.layers_to_output``).  ``pre`` = (scale, bias): the layers warped are ``scale * obj + bias`` and
+        ``scale * bg + bias`` (grid_to_flow's ``(alpha + 1) / 2``, lvd.py:602-606) without being written first.
+        ``return_mask``: also the warped all-ones canvas of the objects' grids (B, T, No, 1, H, W)."""
+        src_grid_obj, src_grid_bg = grid[1], grid[3]
+        if isinstance(src_grid_obj, TimeRepeat) or isinstance(src_grid_bg, TimeRepeat):
+            # grids shared by several outputs (inference): the index-mapped launches of obj_ / bg_to_output
+            if pre is not None:
+                obj, bg = obj * pre[0] + pre[1], bg * pre[0] + pre[1]
+            output = self.obj_to_output(obj, grid, delta_obj, return_mask=return_mask)
+            cat = torch.cat([self.bg_to_output(bg, grid, delta_bg), output[0] if return_mask else output], dim=2)
+            return (cat, output[1]) if return_mask else cat
+        b, t, no = src_grid_obj.shape[:3]
+        c1 = obj.size(-3)
+        ho, wo = self.tgt_shape
+        h, w = self.src_shape
+        # (B, No, C+1, Ho, Wo) / (B, C+1, H, W): shared over time (lvd.py:544,555), broadcast without copies
+        obc = (t * no, no) if obj.ndim == 5 else None
+        bbc = (t, 1) if bg.ndim == 4 else None
+        out = WF.layers_to_output(obj.reshape(-1, c1, ho, wo), bg.reshape(-1, c1, h, w),
+                                  src_grid_obj.reshape(b * t * no, h, w, 2), src_grid_bg.reshape(b * t, h, w, 2),
+                                  delta_obj, delta_bg, obc, bbc, pre if pre is not None else (1.0, 0.0), return_mask)
+        if return_mask:
+            return out[0].view(b, t, no + 1, c1, h, w), out[1].view(b, t, no, 1, h, w)
+        return out.view(b, t, no + 1, c1, h, w)
 
     def obj_to_output(self, obj, grid, delta_obj=1, return_mask=False, into=None):
         """Reference lvd.py:533-549.  ``return_mask``: also the warped all-ones canvas of the same grids,
@@ -357,7 +381,7 @@ class Warper(nn.Module):
         ho, wo = self.tgt_shape
         s = int(self.scale_hd)
         tw = tc if ctx_only else t
-        alpha = self.layer_to_output((obj_alpha + 1) / 2, (bg_alpha + 1) / 2, grid, delta_bg=0, delta_obj=0)
+        alpha = self.layer_to_output(obj_alpha, bg_alpha, grid, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # of (x + 1) / 2
         if tw < alpha.size(1):  # (a full-range slice still costs autograd a zero-filled buffer and a copy backward)
             alpha = alpha[:, :tw]                                               # B Tw L 1 H W
         dist = None
@@ -384,8 +408,7 @@ class Warper(nn.Module):
                 is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True, into=flow_lr)
                 self.bg_to_output(bg_flow, gridp, 0, into=flow_lr)
             else:
-                obj_part, is_obj = self.obj_to_output(obj_flow, gridp, delta_obj=0, return_mask=True)
-                flow_lr = torch.cat([self.bg_to_output(bg_flow, gridp, 0), obj_part], dim=2)
+                flow_lr, is_obj = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0, return_mask=True)
             is_obj = is_obj.reshape(b * tc * tp, no, h, w)
         else:
             flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
@@ -427,7 +450,7 @@ class Warper(nn.Module):
         win = slice(0, tc) if ctx_only else slice(0, t)
 
         # rough alpha of every layer in image space (objects / background shared over time)
-        alpha = self.layer_to_output((obj_alpha + 1) / 2, (bg_alpha + 1) / 2, grid, delta_bg=0, delta_obj=0)
+        alpha = self.layer_to_output(obj_alpha, bg_alpha, grid, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # of (x + 1) / 2
         alpha = alpha[:, win]                                                   # B Tw L 1 H W
         filt = ctx_only or not self.no_filter
         if filt:
