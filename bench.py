@@ -273,7 +273,8 @@ def main():
                          "contiguous blocks (context frames replicated, one all-gather of the predicted frames), so that "
                          "a single clip uses every GPU (waldo_amd/tools/demo.py:predict_sharded)")
     ap.add_argument("--graph", action="store_true",
-                    help="--pipeline: replay the rank's whole step from ONE HIP graph (the collective stays outside it)")
+                    help="--pipeline / --config LVD: replay the rank's whole step from ONE HIP graph (the collective stays "
+                         "outside it); the LVD step is ~90 short launches and its eager time follows the box's host")
     ap.add_argument("--shard", default=None, metavar="R/W",
                     help="--pipeline --scaling strong on ONE GPU: time rank R's share of a W-rank job without any "
                          "collective (what a rank of the 8-GPU node would compute; tools_dev/strong_projection.py)")
@@ -548,15 +549,39 @@ def run_lvd(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):
         step()
-    settle_interpreter()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def timed(run):
+        settle_interpreter()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        fence()
+        return time.perf_counter() - t0
+
+    elapsed_eager = timed(step)
+    # forward, loss and backward captured ONCE and replayed (the library launches on the current stream and never
+    # synchronises; its host-side index checks are skipped during capture).  The step is ~90 short launches behind
+    # ~2.4 ms of interpreter and autograd-engine time per step: eager, it runs at the speed of the box's host
+    # (1.9 - 3.1 ms over this pool's boxes); the replay is the GPU's time.  The leaves' gradients are the graph's
+    # buffers: every replay overwrites them.
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
         step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    for _ in range(max(args.warmup, 3)):
+        graph.replay()
+    elapsed_graph = timed(graph.replay)
+    elapsed = elapsed_graph if args.graph else elapsed_eager
+    grads_ok = step.grads_finite()
     # the per-entry-point table from a SECOND, untimed pass: a step is ~250 short launches queued ahead of the GPU,
     # and two event records around each of its ~70 library calls make the host the bottleneck (3.7 ms against 2.1)
     n_table = max(3, min(args.steps, 10))
@@ -565,9 +590,10 @@ def run_lvd(args, clips, world, rank, device, dist):
             step()
         fence()
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed, elapsed_eager, elapsed_graph], device=device if args.dist_backend == "nccl" else "cpu",
+                          dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        elapsed, elapsed_eager, elapsed_graph = tt.tolist()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         table = {}
@@ -599,7 +625,10 @@ def run_lvd(args, clips, world, rank, device, dist):
                                  "ms_outside = autograd's own kernels (gradient accumulation, fills, the loss) and "
                                  "launch gaps",
                          "entry_points": table},
-            "grads_finite": step.grads_finite(),
+            "grads_finite": grads_ok,
+            "launch": "the whole step (forward, loss, backward) replayed from one HIP graph" if args.graph else "eager",
+            "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 4),
+            "ms_per_step_graph_replay": round(elapsed_graph / args.steps * 1e3, 4),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

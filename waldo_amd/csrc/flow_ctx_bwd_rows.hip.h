@@ -217,6 +217,7 @@ __global__ __launch_bounds__(kBlock, 4) void flow_ctx_alpha_bwd_rows_kernel(
     const float* __restrict__ g_aout, float* __restrict__ g_up, float* __restrict__ g_dist,
     float* __restrict__ g_occ, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W, int scale,
     int tiles, int tiles_per_block, int groups) {
+  const GradOfA01 grad_of_a01(g_a01, g_aout);
   constexpr int LP = kRowsLP;
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kBlock, 4) void flow_ctx_alpha_bwd_rows_kernel(
         const bool real = l < L;
         const int lc = min(l, L - 1);
         A[l][lane] = real ? up_sample(alpha_lr + ((int64_t)n * L + lc) * HW, ut) : 0.0f;
-        G[l][lane] = (real && live) ? grad_of_a01(g_a01, g_aout, ((int64_t)n * L + lc) * HWd + pc) : 0.0f;
+        G[l][lane] = (real && live) ? grad_of_a01(((int64_t)n * L + lc) * HWd + pc) : 0.0f;
       }
     }
     wave_lds_sync();

@@ -59,9 +59,36 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_fwd_kernel(
 }
 
 // Sum of v over the lanes from this one to the end of its RUN (consecutive lanes with the same scatter address;
-// `stop`: the run ends at this lane -- lane 63 always).  After the step of distance d a lane that has not met its
-// run's end has summed d more lanes, all of its run, so lane + d exists: no range check.
+// `stop`: the run ends at this lane).  After the step of distance d a lane that has not met its run's end has summed d
+// more lanes, all of its run, so lane + d exists: no range check.
+// Runs end at the 16-lane ROW boundaries (WALDO_GS_RUN_ROWS): the four steps are DPP row shifts -- two VALU operations
+// each, no LDS crossbar -- where six steps of two ds_bpermute round trips each made the hot wavefronts (the few whose
+// pixels land inside the object's canvas) crawl; a run cut by a row boundary costs one more atomic.  The runs are
+// 2 - 4 lanes long where a 64 x 64 canvas covers ~100 frame pixels.
+#ifndef WALDO_GS_RUN_ROWS
+#define WALDO_GS_RUN_ROWS 1
+#endif
+constexpr int kRunSpan = WALDO_GS_RUN_ROWS ? 16 : kWave;
+template <int D>
+__device__ __forceinline__ int row_from_above(int v) {  // lane i <- lane i + D of its row (row_shl:D; past the row: 0)
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 + D, 0xf, 0xf, true);
+}
 __device__ __forceinline__ float run_sum(float v, bool stop) {
+#if WALDO_GS_RUN_ROWS
+  int st = stop ? 1 : 0;
+#define WALDO_GS_STEP(D)                                                         \
+  {                                                                              \
+    const float vo = __int_as_float(row_from_above<D>(__float_as_int(v)));       \
+    const int so = row_from_above<D>(st);                                        \
+    if (!st) {                                                                   \
+      v += vo;                                                                   \
+      st = so;                                                                   \
+    }                                                                            \
+  }
+  WALDO_GS_STEP(1) WALDO_GS_STEP(2) WALDO_GS_STEP(4) WALDO_GS_STEP(8)
+#undef WALDO_GS_STEP
+  return v;
+#else
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
     const float vo = __shfl_down(v, d, kWave);
@@ -72,6 +99,7 @@ __device__ __forceinline__ float run_sum(float v, bool stop) {
     }
   }
   return v;
+#endif
 }
 
 #ifndef WALDO_GS_RUNS
@@ -112,9 +140,14 @@ __global__ __launch_bounds__(kBlock) void grid_sample2d_bwd_kernel(
   if (WALDO_GS_RUNS && scatter) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+#if WALDO_GS_RUN_ROWS  // (the neighbours inside the row; the row's first / last lane starts / ends a run whatever they hold)
+      const uint32_t nxt = (uint32_t)row_from_above<1>((int)key[q]);
+      const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[q], 0x111, 0xf, 0xf, true);  // row_shr:1
+#else
       const uint32_t nxt = (uint32_t)__shfl_down((int)key[q], 1, kWave), prv = (uint32_t)__shfl_up((int)key[q], 1, kWave);
-      stop[q] = lane == kWave - 1 || nxt != key[q];
-      head[q] = lane == 0 || prv != key[q];
+#endif
+      stop[q] = (lane & (kRunSpan - 1)) == kRunSpan - 1 || nxt != key[q];
+      head[q] = (lane & (kRunSpan - 1)) == 0 || prv != key[q];
     }
   }
   for (int c = 0; c < C; ++c) {

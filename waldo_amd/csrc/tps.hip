@@ -147,14 +147,18 @@ constexpr int kGradMaxK = 136;  // K3 values whose partial sums fit the workgrou
 __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __restrict__ basis_t,
                                                               const float* __restrict__ ggrid,
                                                               float* __restrict__ gmap, int64_t B,
-                                                              int64_t HW, int K3, int chunks) {
+                                                              int64_t HW, int K3, int chunks, int kper) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  // blockIdx.z: a range of kper basis functions (a multiple of kGradKB).  The background grids of the LVD recipe are 10
+  // maps of 32768 pixels against K3 = 131: 96 workgroups, each a chain of 33 dependent load -> fma -> reduce rounds
+  // (59 us); with the basis functions dealt over five workgroups the chains are 7 rounds long
+  const int kbeg = (int)blockIdx.z * kper, kend = min(K3, kbeg + kper);
   const int64_t b0 = (int64_t)blockIdx.y * kGradNB;
   const int nb = (int)min((int64_t)kGradNB, B - b0);
   __shared__ float acc[4][kGradMaxK * kGradNB * 2];
   const bool table = K3 <= kGradMaxK;
   if (table)
-    for (int e = lane; e < K3 * kGradNB * 2; e += kWave) acc[wave][e] = 0.0f;  // wave-private row
+    for (int e = kbeg * kGradNB * 2 + lane; e < kend * kGradNB * 2; e += kWave) acc[wave][e] = 0.0f;  // wave-private row
   for (int c = 0; c < chunks; ++c) {
     const int64_t pbase = (((int64_t)blockIdx.x * chunks + c) * kBlock + threadIdx.x) * kGradPPT;
     if ((((int64_t)blockIdx.x * chunks + c) * kBlock) * kGradPPT >= HW) break;  // block-uniform
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
     // 8 (half the shuffles, a quarter of the dependent reduction chains: at K3 = 131 those chains, one per k,
     // were what the kernel's 68 us were made of); their sixteen basis loads are in flight together
     // (unconditional: past the raster the gradient is 0).  Each partial sum is the same fma chain as before.
-    for (int k0 = 0; k0 < K3; k0 += kGradKB) {
+    for (int k0 = kbeg; k0 < kend; k0 += kGradKB) {
       float part[kGradKB * kGradNB * 2];
 #pragma unroll
       for (int i = 0; i < kGradKB * kGradNB * 2; ++i) part[i] = 0.0f;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
       const float red = wave_transpose_reduce<kGradKB * kGradNB * 2>(part, lane);
       const int e = bitrev6(lane);
       const int k = k0 + e / (kGradNB * 2), idx = e % (kGradNB * 2);
-      if (e < kGradKB * kGradNB * 2 && k < K3 && idx < nb * 2) {
+      if (e < kGradKB * kGradNB * 2 && k < kend && idx < nb * 2) {
         if (table)
           acc[wave][k * kGradNB * 2 + idx] += red;  // one lane per entry: plain read-modify-write
         else
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void tps_grid_bwd_kernel(const float* __res
   }
   if (table) {
     __syncthreads();
-    for (int e = threadIdx.x; e < K3 * kGradNB * 2; e += kBlock) {
+    for (int e = kbeg * kGradNB * 2 + threadIdx.x; e < kend * kGradNB * 2; e += kBlock) {
       const int k = e / (kGradNB * 2), idx = e % (kGradNB * 2);
       if (idx < nb * 2)
         atomicAdd(gmap + ((b0 + (idx >> 1)) * K3 + k) * 2 + (idx & 1),
@@ -300,8 +304,13 @@ extern "C" int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid,
   const int64_t nchunks = (HW + per_chunk - 1) / per_chunk, groups_b = (B + kGradNB - 1) / kGradNB;
   // several chunks per workgroup (fewer atomics per output) while keeping >= ~512 workgroups
   const int chunks = (int)min((int64_t)16, max((int64_t)1, nchunks * groups_b / 512));
-  dim3 g((unsigned)((nchunks + chunks - 1) / chunks), (unsigned)groups_b);
+  // few workgroups (few, large maps): the basis functions are dealt over blockIdx.z, in multiples of kGradKB
+  const int64_t wgs = ((nchunks + chunks - 1) / chunks) * groups_b;
+  const int rounds = (K3 + kGradKB - 1) / kGradKB;
+  const int ksplit = (int)min((int64_t)rounds, max((int64_t)1, 512 / wgs));
+  const int kper = ((rounds + ksplit - 1) / ksplit) * kGradKB;
+  dim3 g((unsigned)((nchunks + chunks - 1) / chunks), (unsigned)groups_b, (unsigned)((K3 + kper - 1) / kper));
   hipLaunchKernelGGL(tps_grid_bwd_kernel, g, dim3(kBlock), 0, st, basis_t, grad_grid,
-                     grad_mapping, B, HW, K3, chunks);
+                     grad_mapping, B, HW, K3, chunks, kper);
   return launch_status("waldo_tps_grid_bwd");
 }
