@@ -9,6 +9,6 @@ for i in 1 2; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); e=d['pipeline']['entry_points']
 g=lambda k: e.get(k,{}).get('ms_per_step')
-print('LVD [$lib] eager', d['ms_per_step_eager'], 'graph', d['ms_per_step_graph_replay'], 'warp_bwd', g('waldo_flow_ctx_warp_bwd'), 'alpha_bwd', g('waldo_flow_ctx_alpha_bwd'), 'gs_bwd', g('waldo_grid_sample2d_bwd'), 'gs_ex_bwd', g('waldo_grid_sample2d_ex_bwd'), 'iw_fwd', g('waldo_inverse_warp_fwd'), 'iw_bwd', g('waldo_inverse_warp_bwd'))" | tee -a gpurun_out/ab_lvd/ab_libs.txt
+print('LVD [$lib] eager', d['ms_per_step_eager'], 'graph', d['ms_per_step_graph_replay'], 'warp_bwd', g('waldo_flow_ctx_warp_bwd'), 'alpha_bwd', g('waldo_flow_ctx_alpha_bwd'), 'gs_bwd', g('waldo_grid_sample2d_bwd'), 'gs_ex_bwd', g('waldo_grid_sample2d_ex_bwd'), 'iw_fwd', g('waldo_inverse_warp_fwd'),  'iw_bwd', g('waldo_inverse_warp_bwd'), 'fwf_bwd', g('waldo_frame_warp_fuse_bwd'), 'fwf', g('waldo_frame_warp_fuse_fwd'))" | tee -a gpurun_out/ab_lvd/ab_libs.txt
   done
 done

@@ -144,10 +144,10 @@ def load():
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL), as the integer ctypes converts to ``void*`` itself."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def check_cuda(*tensors):
@@ -161,8 +161,34 @@ def check_cuda(*tensors):
             raise WaldoHipError(f"waldo_amd ops are fp32-only, got {t.dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The ``hipStream_t`` PyTorch launches on for ``device`` right now (inside ``torch.cuda.stream(...)``: that one).
+    The raw query when the build has it: a library call is ~20 us of interpreter time around a ~5 us launch, and the
+    LVD training step makes ~45 of them -- building a ``torch.cuda.Stream`` object per call was a quarter of that."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """``with on_device(dev):`` = ``with torch.cuda.device(dev):`` (the kernels launch on the CURRENT device) that
+    costs nothing when ``dev`` already is the current device -- the one-GPU-per-process case."""
+    __slots__ = ("guard",)
+
+    def __init__(self, device):
+        self.guard = None if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            return self.guard.__exit__(*exc)
+        return False
 
 
 class KernelTimer:

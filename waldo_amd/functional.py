@@ -118,7 +118,7 @@ class _TpsMapping(torch.autograd.Function):
         inverse_kernel = _c(inverse_kernel)
         b, n, _ = src_pts.shape
         mapping = src_pts.new_empty(b, n + 3, 2)
-        with torch.cuda.device(src_pts.device):
+        with _lib.on_device(src_pts.device):
             _lib.call("waldo_tps_mapping_fwd", _lib.ptr(inverse_kernel), _lib.ptr(src_pts),
                       _lib.ptr(mapping), b, n, _lib.current_stream(src_pts.device))
         ctx.save_for_backward(inverse_kernel)
@@ -131,7 +131,7 @@ class _TpsMapping(torch.autograd.Function):
         grad_mapping = _c(grad_mapping)
         b = grad_mapping.shape[0]
         grad_pts = grad_mapping.new_empty(b, ctx.n, 2)
-        with torch.cuda.device(grad_mapping.device):
+        with _lib.on_device(grad_mapping.device):
             _lib.call("waldo_tps_mapping_bwd", _lib.ptr(inverse_kernel), _lib.ptr(grad_mapping),
                       _lib.ptr(grad_pts), b, ctx.n, _lib.current_stream(grad_mapping.device))
         return None, grad_pts
@@ -146,7 +146,7 @@ class _TpsGrid(torch.autograd.Function):
         b, k3, _ = mapping.shape
         hw = basis_t.shape[1]
         grid = mapping.new_empty(b, hw, 2)
-        with torch.cuda.device(mapping.device):
+        with _lib.on_device(mapping.device):
             _lib.call("waldo_tps_grid_fwd", _lib.ptr(basis_t), _lib.ptr(mapping), _lib.ptr(grid),
                       b, hw, k3, _lib.current_stream(mapping.device))
         ctx.save_for_backward(basis_t)
@@ -159,7 +159,7 @@ class _TpsGrid(torch.autograd.Function):
         grad_grid = _c(grad_grid)
         b, hw, _ = grad_grid.shape
         grad_mapping = grad_grid.new_empty(b, ctx.k3, 2)  # zero-filled by the launcher
-        with torch.cuda.device(grad_grid.device):
+        with _lib.on_device(grad_grid.device):
             _lib.call("waldo_tps_grid_bwd", _lib.ptr(basis_t), _lib.ptr(grad_grid),
                       _lib.ptr(grad_mapping), b, hw, ctx.k3,
                       _lib.current_stream(grad_grid.device))
@@ -203,7 +203,7 @@ class _InverseWarp(torch.autograd.Function):
         work = (_lib.ptr(out), _lib.ptr(dxy), _lib.ptr(cell), _lib.ptr(winner), _lib.ptr(field_a),
                 _lib.ptr(field_b), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask_a),
                 _lib.ptr(mask_b), b, hs, ws, h, w, niter, int(bool(erode)))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if order is None:
                 _lib.call("waldo_inverse_warp_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
                           _lib.ptr(tgt_id), _lib.ptr(gauss), *work, _lib.current_stream(dev))
@@ -228,7 +228,7 @@ class _InverseWarp(torch.autograd.Function):
         grad_out = _c(grad_out)
         gfield = grad_out.new_empty(b, 2, fill_iter.shape[1])
         gsrc = grad_out.new_empty(b, hs, ws, 2)
-        with torch.cuda.device(grad_out.device):
+        with _lib.on_device(grad_out.device):
             _lib.call("waldo_inverse_warp_bwd", _lib.ptr(grad_out), _lib.ptr(gauss), _lib.ptr(cell),
                       _lib.ptr(winner), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask),
                       _lib.ptr(gfield), _lib.ptr(gsrc), b, hs, ws, h, w, niter,
@@ -279,7 +279,7 @@ class _GridSample(torch.autograd.Function):
             outer_div = inner = max(n, 1)
         out = inp.new_empty(n, c, ho, wo)
         mask = inp.new_empty(n, 1, ho, wo) if want_mask else None
-        with torch.cuda.device(inp.device):
+        with _lib.on_device(inp.device):
             if want_mask:
                 _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(mask),
                           n, c, hi, wi, ho, wo, float(delta), outer_div, inner, max(n, 1), max(n, 1),
@@ -304,7 +304,7 @@ class _GridSample(torch.autograd.Function):
         n, ho, wo, _ = grid.shape
         gi = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None
         gg = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(inp.device):
+        with _lib.on_device(inp.device):
             _lib.call("waldo_grid_sample2d_bwd", _lib.ptr(inp), _lib.ptr(grid),
                       _lib.ptr(grad_out), _lib.ptr(gi), _lib.ptr(gg), n, c, hi, wi, ho, wo,
                       delta, outer_div, inner, _lib.current_stream(inp.device))
@@ -357,7 +357,7 @@ def grid_sample(inp, grid, delta=0.0, broadcast=None, grid_repeat=None, return_m
             grp, stride, off = max(n_out, 1), max(n_out, 1), 0
             res = inp.new_empty(n_out, c, ho, wo)
         mask = inp.new_empty(n_out, 1, ho, wo) if return_mask else None
-        with torch.cuda.device(inp.device):
+        with _lib.on_device(inp.device):
             if return_mask or out is not None:
                 _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(res), _lib.ptr(mask),
                           n_out, c, hi, wi, ho, wo, float(delta), od, inn, god, gin, grp, stride, off, 1.0, 0.0,
@@ -381,7 +381,7 @@ class _LayersToOutput(torch.autograd.Function):
         mask = obj.new_empty(nf * no, 1, h, w) if want_mask else None
         calls = ((obj, grid_obj, mask, nf * no, delta_obj, obj_bc, (no, nl, 1)),
                  (bg, grid_bg, None, nf, delta_bg, bg_bc, (1, nl, 0)))
-        with torch.cuda.device(obj.device):
+        with _lib.on_device(obj.device):
             for inp, grid, msk, n, delta, bc, slots in calls:
                 if n == 0 or (slots[0] == 0):
                     continue
@@ -409,7 +409,7 @@ class _LayersToOutput(torch.autograd.Function):
         gis = _zeros_like_each(obj if need[0] else None, bg if need[1] else None)
         calls = ((obj, grid_obj, nf * no, delta_obj, obj_bc, (no, nl, 1), gis[0], need[2]),
                  (bg, grid_bg, nf, delta_bg, bg_bc, (1, nl, 0), gis[1], need[3]))
-        with torch.cuda.device(obj.device):
+        with _lib.on_device(obj.device):
             for inp, grid, n, delta, bc, slots, gi, want_g in calls:
                 want_i = gi is not None
                 gg = torch.empty_like(grid) if want_g else None
@@ -471,7 +471,7 @@ class _OccComposite(torch.autograd.Function):
         occ = _c(occ)
         m, nl, hw = alpha.shape
         out = torch.empty_like(alpha)
-        with torch.cuda.device(alpha.device):
+        with _lib.on_device(alpha.device):
             _lib.call("waldo_occ_composite_fwd", _lib.ptr(alpha), _lib.ptr(occ), _lib.ptr(out), m,
                       nl, hw, occ_div, _lib.current_stream(alpha.device))
         ctx.save_for_backward(alpha, occ)
@@ -485,7 +485,7 @@ class _OccComposite(torch.autograd.Function):
         m, nl, hw = alpha.shape
         ga = torch.empty_like(alpha)
         go = torch.zeros_like(occ) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(alpha.device):
+        with _lib.on_device(alpha.device):
             _lib.call("waldo_occ_composite_bwd", _lib.ptr(alpha), _lib.ptr(occ),
                       _lib.ptr(grad_out), _lib.ptr(ga), _lib.ptr(go), m, nl, hw, ctx.occ_div,
                       _lib.current_stream(alpha.device))
@@ -511,7 +511,7 @@ class _ComputeOcc(torch.autograd.Function):
         score = _c(score)
         m, no = score.shape
         occ = score.new_empty(m, no + 1, no + 1)
-        with torch.cuda.device(score.device):
+        with _lib.on_device(score.device):
             _lib.call("waldo_compute_occ_fwd", _lib.ptr(score), _lib.ptr(occ), m, no, float(eps),
                       _lib.current_stream(score.device))
         ctx.save_for_backward(score)
@@ -524,7 +524,7 @@ class _ComputeOcc(torch.autograd.Function):
         grad_occ = _c(grad_occ)
         m, no = score.shape
         gs = torch.empty_like(score)
-        with torch.cuda.device(score.device):
+        with _lib.on_device(score.device):
             _lib.call("waldo_compute_occ_bwd", _lib.ptr(score), _lib.ptr(grad_occ), _lib.ptr(gs), m, no,
                       ctx.eps, _lib.current_stream(score.device))
         return gs, None
@@ -552,7 +552,7 @@ class _AlphaHead(torch.autograd.Function):
             raise _lib.WaldoHipError(f"alpha_head: mask has {mask.numel()} elements, expected "
                                      f"{h * scale}x{w * scale}")
         out = x.new_empty(n, c, h * scale, w * scale)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("waldo_alpha_head_fwd", _lib.ptr(x), _lib.ptr(prior), _lib.ptr(mask), _lib.ptr(out), n, c,
                       h, w, scale, float(bias), int(has_alpha), mode, _lib.current_stream(x.device))
         ctx.save_for_backward(x, prior, mask)
@@ -566,7 +566,7 @@ class _AlphaHead(torch.autograd.Function):
         grad_out = _c(grad_out)
         n, c, h, w = x.shape
         gx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("waldo_alpha_head_bwd", _lib.ptr(x), _lib.ptr(prior), _lib.ptr(mask), _lib.ptr(grad_out),
                       _lib.ptr(gx), n, c, h, w, scale, bias, has_alpha, mode, _lib.current_stream(x.device))
         return gx, None, None, None, None, None, None
@@ -582,7 +582,7 @@ def disocc_test(layer_max):
     layer_max = _c(layer_max.detach())
     b, tc, tp, h, w = layer_max.shape
     out = layer_max.new_empty(b, tp, h, w)
-    with torch.cuda.device(layer_max.device):
+    with _lib.on_device(layer_max.device):
         _lib.call("waldo_disocc_test_fwd", _lib.ptr(layer_max), _lib.ptr(out), b, tc, tp, h * w,
                   _lib.current_stream(layer_max.device))
     return out
@@ -608,7 +608,7 @@ class _PoseAffine(torch.autograd.Function):
             raise _lib.WaldoHipError(f"pose_affine: inconsistent shapes pose={tuple(pose.shape)} "
                                      f"base={tuple(base.shape)}")
         out = pose.new_empty(r, p, 2)
-        with torch.cuda.device(pose.device):
+        with _lib.on_device(pose.device):
             _lib.call("waldo_pose_affine_fwd", _lib.ptr(pose), _lib.ptr(mul6), _lib.ptr(bias6), _lib.ptr(base),
                       _lib.ptr(out), r, p, float(mul_delta), float(pts_mul), _lib.current_stream(pose.device))
         ctx.save_for_backward(pose, mul6, bias6, base)
@@ -621,7 +621,7 @@ class _PoseAffine(torch.autograd.Function):
         grad_out = _c(grad_out)
         r, d = pose.shape
         gp = torch.empty_like(pose)
-        with torch.cuda.device(pose.device):
+        with _lib.on_device(pose.device):
             _lib.call("waldo_pose_affine_bwd", _lib.ptr(pose), _lib.ptr(mul6), _lib.ptr(bias6), _lib.ptr(base),
                       _lib.ptr(grad_out), _lib.ptr(gp), r, (d - 6) // 2, ctx.cfg[0], ctx.cfg[1],
                       _lib.current_stream(pose.device))
@@ -651,7 +651,7 @@ class _WifFuse(torch.autograd.Function):
         if tuple(net.shape) != (b, t, tc, co, h, w):
             raise _lib.WaldoHipError(f"wif_fuse: shapes {tuple(vid.shape)} vs {tuple(net.shape)}")
         out = vid.new_empty(b, t, 3, h, w)
-        with torch.cuda.device(vid.device):
+        with _lib.on_device(vid.device):
             _lib.call("waldo_wif_fuse_fwd", _lib.ptr(vid), _lib.ptr(net), _lib.ptr(out), b * t, tc,
                       c, co, h * w, int(bool(ab)), _lib.current_stream(vid.device))
         ctx.save_for_backward(vid, net, out)
@@ -666,7 +666,7 @@ class _WifFuse(torch.autograd.Function):
         grad_out = _c(grad_out)
         gv = torch.empty_like(vid) if ctx.needs_input_grad[0] else None
         gn = torch.empty_like(net) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(vid.device):
+        with _lib.on_device(vid.device):
             _lib.call("waldo_wif_fuse_bwd", _lib.ptr(vid), _lib.ptr(net), _lib.ptr(out),
                       _lib.ptr(grad_out), _lib.ptr(gv), _lib.ptr(gn), b * t, tc, c, co, h * w,
                       ctx.ab, _lib.current_stream(vid.device))
@@ -694,7 +694,7 @@ class _LytDist(torch.autograd.Function):
         total = alpha.new_empty(b, no)
         wsb = _lib.load().waldo_lyt_dist_workspace_bytes(b, tw, no, nl, h, w)
         ws = alpha.new_empty(max(wsb, 4) // 4)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("waldo_lyt_dist_fwd", _lib.ptr(alpha), _lib.ptr(lyt), lyt.stride(0), lyt.stride(1),
                       _lib.ptr(cls), float(min_cls), _lib.ptr(dist), _lib.ptr(mean), _lib.ptr(total),
                       _lib.ptr(ws), b, tw, la, first_obj, no, nl, h, w, _lib.current_stream(dev))
@@ -716,7 +716,7 @@ class _LytDist(torch.autograd.Function):
         g_cls = torch.empty_like(cls) if cls is not None else None
         wsb = _lib.load().waldo_lyt_dist_workspace_bytes(b, tw, no, nl, h, w)
         ws = alpha.new_empty(max(wsb, 4) // 4)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("waldo_lyt_dist_bwd", _lib.ptr(g_dist), _lib.ptr(alpha), _lib.ptr(lyt), lyt.stride(0),
                       lyt.stride(1), _lib.ptr(cls), min_cls, _lib.ptr(dist), _lib.ptr(mean),
                       _lib.ptr(total), _lib.ptr(g_alpha), _lib.ptr(g_cls), _lib.ptr(ws), b, tw, la,
@@ -754,7 +754,7 @@ class _FlowCtxAlpha(torch.autograd.Function):
         ncls = dist.shape[2] if dist is not None else 0
         a01 = alpha_lr.new_empty(n, nl, hd, wd)
         out = alpha_lr.new_empty(n, nl, hd, wd)
-        with torch.cuda.device(alpha_lr.device):
+        with _lib.on_device(alpha_lr.device):
             _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
                       _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), b, t, tw, nl, ncls, c, chan_off, h, w,
                       scale, _lib.current_stream(alpha_lr.device))
@@ -780,7 +780,7 @@ class _FlowCtxAlpha(torch.autograd.Function):
         g_dist, g_occ = _zeros_like_each(dist if (dist is not None and ctx.needs_input_grad[2]) else None,
                                          occ if ctx.needs_input_grad[3] else None)
         ws = alpha_lr.new_empty(n, nl, hd, wd) if scale > 1 else None
-        with torch.cuda.device(alpha_lr.device):
+        with _lib.on_device(alpha_lr.device):
             _lib.call("waldo_flow_ctx_alpha_bwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
                       _lib.ptr(occ), _lib.ptr(g_a01), _lib.ptr(g_out), _lib.ptr(g_lr), _lib.ptr(g_dist), _lib.ptr(g_occ),
                       _lib.ptr(ws), b, t, tw, nl, ncls, c, chan_off, h, w, scale,
@@ -820,7 +820,7 @@ class _FlowCtxWarp(torch.autograd.Function):
         alpha_ctx = flow_lr.new_empty(m, nl, hd, wd)
         disocc = flow_lr.new_empty(m, hd, wd)
         amax = flow_lr.new_empty(m, hd, wd) if layer_max else flow_lr.new_empty(0)
-        with torch.cuda.device(flow_lr.device):
+        with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
                       _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, b, t, tw, tc, tp, nl, h, w, scale,
@@ -845,7 +845,7 @@ class _FlowCtxWarp(torch.autograd.Function):
         g_lr = torch.empty_like(flow_lr)
         g_a01, g_occ = _zeros_like_each(a01 if ctx.needs_input_grad[2] else None, occ if ctx.needs_input_grad[5] else None)
         ws = flow_lr.new_empty(m, nl, 2, hd, wd) if scale > 1 else None
-        with torch.cuda.device(flow_lr.device):
+        with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_bwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(g_flow), _lib.ptr(g_actx),
                       _lib.ptr(g_dis), _lib.ptr(g_lr), _lib.ptr(g_a01), _lib.ptr(g_occ), _lib.ptr(ws), b, t, tw,
@@ -942,7 +942,7 @@ def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sca
         score = flow_lr.new_empty(b, tc, tp, hd, wd)
         disocc = flow_lr.new_empty(m, hd, wd)
         amax = flow_lr.new_empty(m, hd, wd) if layer_max else None
-        with torch.cuda.device(flow_lr.device):
+        with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_raw_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(raw),
                       _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax), b, t, tw, tc, tp, nl, h, w, scale,
@@ -966,7 +966,7 @@ class _FrameWarpFuse(torch.autograd.Function):
         # permute(0, 2, 1, ...).contiguous() (wif.py:39) then is a no-op instead of a copy of the
         # pipeline's largest tensor (C4 recipe: 11.8 GB read + written per predict)
         raw = input.new_empty(b, tp, tcx, c + nl, hd, wd)
-        with torch.cuda.device(input.device):
+        with _lib.on_device(input.device):
             _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
                       _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
                       1 if include_self else 0, float(eps), _lib.current_stream(input.device))
@@ -987,7 +987,7 @@ class _FrameWarpFuse(torch.autograd.Function):
         g_raw = _c(g_raw) if g_raw is not None else None
         g_flow = torch.empty_like(flow)
         g_alpha = torch.empty_like(alpha)
-        with torch.cuda.device(input.device):
+        with _lib.on_device(input.device):
             _lib.call("waldo_frame_warp_fuse_bwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
                       _lib.ptr(ctx_ts), _lib.ptr(g_out), _lib.ptr(g_raw), _lib.ptr(g_flow), _lib.ptr(g_alpha), b, t,
                       tc, tp, c, nl, hd, wd, 1 if include_self else 0, eps, _lib.current_stream(input.device))
@@ -1035,7 +1035,7 @@ class _TimeGather(torch.autograd.Function):
         p = math.prod(x.shape[2:]) // 2
         tp = pred_ts.numel()
         out = x.new_empty(b, tc, tp, *((p // hw, 2, hw) if hw else (p, 2)))
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("waldo_time_gather_fwd", _lib.ptr(x), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(out),
                       b, t, tc, tp, p, hw, int(subtract), _lib.current_stream(x.device))
         ctx.save_for_backward(ctx_ts, pred_ts)
@@ -1049,7 +1049,7 @@ class _TimeGather(torch.autograd.Function):
         grad_out = _c(grad_out)
         gx = grad_out.new_empty(shape)
         b, t = shape[:2]
-        with torch.cuda.device(grad_out.device):
+        with _lib.on_device(grad_out.device):
             _lib.call("waldo_time_gather_bwd", _lib.ptr(grad_out), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(gx),
                       b, t, tc, pred_ts.numel(), math.prod(shape[2:]) // 2, hw, int(subtract),
                       _lib.current_stream(grad_out.device))
@@ -1105,7 +1105,7 @@ def downscale_frames(input, num_frames, first_channel, factor):
         raise _lib.WaldoHipError(f"downscale_frames: factor {factor} on {hd} x {wd} frames (a power of two that divides both)")
     x = _c(input.detach().float())
     out = x.new_empty(b, int(num_frames), c - int(first_channel), hd // s, wd // s)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.call("waldo_downscale_frames_fwd", _lib.ptr(x), _lib.ptr(out), b, t, int(num_frames), c,
                   int(first_channel), hd // s, wd // s, s, _lib.current_stream(x.device))
     return out
@@ -1130,7 +1130,7 @@ class _WarpComposite(torch.autograd.Function):
                 f"mapping={tuple(mapping.shape)} occ={tuple(occ.shape)} basis_t={tuple(basis_t.shape)}")
         rgb = layers.new_empty(f, 3, h, w)
         alpha = layers.new_empty(f, nl, h, w) if want_alpha else None
-        with torch.cuda.device(layers.device):
+        with _lib.on_device(layers.device):
             _lib.call("waldo_warp_composite_fwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(rgb), _lib.ptr(alpha), f, nl, h,
                       w, k3, float(delta), _lib.current_stream(layers.device))
@@ -1154,7 +1154,7 @@ class _WarpComposite(torch.autograd.Function):
         # with a workspace the two-kernel path writes every texel of grad_layers exactly once;
         # the generic kernel accumulates with atomics into a zero-filled buffer
         gl = torch.empty_like(layers) if ws_bytes else torch.zeros_like(layers)
-        with torch.cuda.device(layers.device):
+        with _lib.on_device(layers.device):
             _lib.call("waldo_warp_composite_bwd", _lib.ptr(layers), _lib.ptr(basis_t),
                       _lib.ptr(mapping), _lib.ptr(occ), _lib.ptr(grad_rgb), _lib.ptr(grad_alpha),
                       _lib.ptr(gl), _lib.ptr(gm), _lib.ptr(go), _lib.ptr(ws), ws_bytes, f, nl, h,
@@ -1215,7 +1215,7 @@ def _warp_composite_pts(layers, src_pts, occ, inverse_kernel, basis_t, want_alph
     rgb = layers.new_empty(f, 3, h, w)
     alpha = layers.new_empty(f, nl, h, w) if want_alpha else None
     per = max(1, MAX_FL_PER_LAUNCH // nl)
-    with torch.cuda.device(layers.device):
+    with _lib.on_device(layers.device):
         for i in range(0, f, per):
             j = min(f, i + per)
             _lib.call("waldo_warp_composite_pts_fwd", _lib.ptr(layers[i:j]), _lib.ptr(basis_t),
