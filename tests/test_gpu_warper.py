@@ -854,6 +854,39 @@ def test_time_gather_against_the_spelled_out_expressions(dev, shape):
     assert tuple(empty.shape) == (0, tc, tp, h, w, 2)
 
 
+def test_time_gather_of_every_frame_in_order_is_the_clip_itself(dev):
+    """`x[:, pred_ts]` for one context with pred_ts = 0 .. T-1 (the LVD recipe's ctx_mode "prev": every frame is
+    predicted): `time_gather` hands out a VIEW of the clip -- the same values and gradients as the kernel's copy, no
+    launch either way -- once the index is KNOWN to be the identity (one read per (tensor, version)); after an in-place
+    change of the index, for a permutation, a shorter index or two contexts it is the kernel again."""
+    from waldo_amd import functional as WF
+    b, t, no, h, w = 2, 5, 3, 6, 7
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.randn(b, t, no, h, w, 2, generator=g, device=dev, requires_grad=True)
+    wgt = torch.randn(b, 1, t, no, h, w, 2, generator=g, device=dev)
+    pred = torch.arange(t, device=dev)
+    out = WF.time_gather(x, None, pred, num_ctx=1)
+    assert out.shape == (b, 1, t, no, h, w, 2) and out.data_ptr() == x.data_ptr()
+    (out * wgt).sum().backward()
+    g_view = x.grad.clone()
+    x.grad = None
+    perm = torch.tensor([1, 0, 2, 3, 4], device=dev)
+    for idx, nctx in ((perm, 1), (pred[:3], 1), (pred, 2)):
+        o = WF.time_gather(x, None, idx, num_ctx=nctx)
+        assert o.data_ptr() != x.data_ptr()
+        assert torch.equal(o, x[:, idx].unsqueeze(1).expand(-1, nctx, *([-1] * 5)))
+    pred2 = pred.clone()
+    copy = WF.time_gather(x, None, pred2.flip(0).flip(0).contiguous() + 0, num_ctx=1)  # equal values, another tensor: read once
+    assert torch.equal(copy, out)
+    pred.mul_(0)                                                   # the same tensor object, a new version: frame 0 five times
+    rep = WF.time_gather(x, None, pred, num_ctx=1)
+    assert rep.data_ptr() != x.data_ptr() and torch.equal(rep, x[:, :1].expand(-1, t, -1, -1, -1, -1).unsqueeze(1))
+    # the kernel's gradient for the identity index (forced through the kernel by a second context) is the view's
+    both = WF.time_gather(x, None, torch.arange(t, device=dev), num_ctx=2)
+    (both[:, :1] * wgt).sum().backward()
+    assert torch.equal(x.grad, g_view)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 7, 16, 32, 2, 2, 3), (1, 2, 23, 32, 64, 4, 2, 3), (1, 1, 4, 8, 8, 8, 1, 0)])
 def test_downscale_frames_matches_interpolate(dev, shape):
     """waldo_downscale_frames_fwd == scale(input[:, :Tw, c0:], 1 / S) (lvd.py:611 through lvd.py:175-179), bit for bit."""

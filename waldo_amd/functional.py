@@ -60,20 +60,41 @@ def _index_version(ts):
     return ts._version
 
 
-def _index_range(ts, private=False):
-    """(lowest, highest) index in ``ts``: ONE device -> host read per distinct (tensor, version), whatever
+def _index_info(ts, private=False):
+    """(lowest, highest, is_arange) of ``ts``: ONE device -> host read per distinct (tensor, version), whatever
     limits it is checked against afterwards.  A tensor without a version counter (inference mode) is read on
     every call -- its owner could have written to it in place unseen -- unless it is ``private``: a copy
-    ``normalise_time_index`` made and nobody else holds."""
+    ``normalise_time_index`` made and nobody else holds.  ``is_arange``: a 1-D index equal to 0, 1, ..., n - 1
+    (``x[:, ts]`` is then ``x[:, :n]``: ``time_gather`` hands out the clip itself instead of a copy of it)."""
     seen = _index_entry(ts)
     ver = _index_version(ts)
     key = ver if ver is not None else ("private" if (private or "private" in seen) else None)
     if key is not None and key in seen:
         return seen[key]
-    rng = tuple(int(v) for v in torch.aminmax(ts))
+    if ts.ndim == 1:
+        same = (ts == torch.arange(ts.numel(), device=ts.device, dtype=ts.dtype)).all().to(ts.dtype)
+        lo, hi, same = torch.stack([ts.min(), ts.max(), same]).tolist()
+        info = (int(lo), int(hi), bool(same))
+    else:
+        info = tuple(int(v) for v in torch.aminmax(ts)) + (False,)
     if key is not None:
-        seen[key] = rng
-    return rng
+        seen[key] = info
+    return info
+
+
+def _index_range(ts, private=False):
+    return _index_info(ts, private)[:2]
+
+
+def _known_arange(ts):
+    """True when ``ts`` is KNOWN to be 0, 1, ..., n - 1 from an earlier read of this very (tensor, version) -- never
+    reads the device, so it also answers while a HIP graph is being captured (the warm-up steps before the capture
+    made the read)."""
+    seen = _index_entry(ts)
+    ver = _index_version(ts)
+    key = ver if ver is not None else ("private" if "private" in seen else None)
+    info = seen.get(key) if key is not None else None
+    return bool(info is not None and info[2])
 
 
 def normalise_time_index(ts):
@@ -1085,9 +1106,13 @@ def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=
             raise _lib.WaldoHipError("time_gather: without ctx_ts give num_ctx (and no difference)")
         tc = int(num_ctx)
     _check_time_index("time_gather", "pred_ts", pred_ts, t)
+    tp = pred_ts.numel()
+    if ctx_ts is None and tc == 1 and tp == t and not channel_first and _known_arange(pred_ts):
+        # x[:, [0, 1, ..., T - 1]] for one context: the clip itself (a view: no copy, and the backward is autograd's sum
+        # instead of a scatter kernel) -- the LVD recipe's `ctx_mode "prev"`, where every frame is predicted
+        return x.view(b, 1, t, *x.shape[2:])
     hw = x.shape[3] * x.shape[4] if channel_first else 0
     out = _TimeGather.apply(x, ctx_ts, pred_ts, tc, hw, bool(subtract))
-    tp = pred_ts.numel()
     if channel_first:
         return out.view(b, tc, tp, x.shape[2], 2, x.shape[3], x.shape[4])
     return out.view(b, tc, tp, *x.shape[2:])
