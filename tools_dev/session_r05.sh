@@ -7,7 +7,10 @@ python bench.py --config C5 --pipeline --steps 8 --warmup 2 > gpurun_out/r05_ben
 python bench.py --config C5 --pipeline --steps 8 --warmup 2 --motion wild > gpurun_out/r05_bench_C5_pipeline_wild.json 2> gpurun_out/err_p5w.txt
 python bench.py --config C4 --pipeline --steps 8 --warmup 2 > gpurun_out/r05_bench_C4_pipeline.json 2> gpurun_out/err_p4.txt
 python bench.py --config C4 --pipeline --steps 8 --warmup 2 --motion wild > gpurun_out/r05_bench_C4_pipeline_wild.json 2> gpurun_out/err_p4w.txt
-python bench.py --config LVD --steps 40 > gpurun_out/r05_bench_LVD.json 2> gpurun_out/err_lvd.txt
+python bench.py --config LVD --steps 200 --warmup 20 > gpurun_out/r05_bench_LVD.json 2> gpurun_out/err_lvd.txt
+python bench.py --config LVD --steps 200 --warmup 20 --graph > gpurun_out/r05_bench_LVD_graph.json 2> gpurun_out/err_lvdg.txt
+python tools_dev/glue_ops.py LVD > gpurun_out/r05_lvd_step_framework_ops.txt 2> gpurun_out/err_glue.txt
+python tools_dev/lvd_host_profile.py > gpurun_out/r05_lvd_step_host_profile.txt 2>&1
 # one job split over ranks (bench.py --scaling strong): every rank's share timed on this one GPU, eager and from one HIP graph
 python tools_dev/strong_projection.py C5 > gpurun_out/r05_strong_projection_C5.json 2> gpurun_out/err_sp5.txt
 python tools_dev/strong_projection.py C4 > gpurun_out/r05_strong_projection_C4.json 2> gpurun_out/err_sp4.txt
