@@ -1002,6 +1002,17 @@ def test_decode_output_glue(dev, restrict, use_disocc, include_self):
                             ctx_ts.to(dev), pred_ts.to(dev), restrict, use_disocc)
     for x, y, z, name in zip(got, ref, ref64, ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")):
         close(x, y, what=name, exact=z)
+    # a caller that drops `alpha` / `alpha_unflt` (Synthesizer.predict does) can have the flow pass not write them:
+    # None in their place, every other output bit for bit
+    wp.return_alpha = False
+    with torch.no_grad():
+        lean = decode_output(wp, inp.to(dev), [x.to(dev) for x in grid_o], occ_h, oa_h, ba_h, cls.to(dev),
+                             ctx_ts.to(dev), pred_ts.to(dev), restrict, use_disocc)
+    for x, y, name in zip(lean, got, ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")):
+        if name in ("alpha_unflt", "alpha") and wp.fuse_hd and x is None:
+            continue
+        assert (x is None and y is None) or torch.equal(x, y), name
+    assert lean[3] is None or not wp._fused_ok([inp.to(dev)], nl, inp.size(2) - 3)
 
 
 def test_warper_state_dict_names(dev):

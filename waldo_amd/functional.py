@@ -809,12 +809,14 @@ class _FlowCtxAlpha(torch.autograd.Function):
         return g_lr, None, g_dist, g_occ, None, None, None
 
 
-def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale):
+def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale, want_alpha=True):
     """Upsampling + layout filter + first occlusion product (models/nets/lvd.py:731-766).
     alpha_lr (B*Tw, L, H, W) in [0, 1]; input (B, T, C, Hd, Wd) with the layout logits in channels
     [chan_off, chan_off + Nl); dist (B, L-1, Nl) or None (no filter); occ (B, T, L, L).
     Returns (a01, alpha) of shape (B*Tw, L, Hd, Wd): the composited alpha in [0, 1] and 2a - 1.
-    Differentiable w.r.t. alpha_lr, dist and occ (the frames / layouts in ``input`` are data)."""
+    Differentiable w.r.t. alpha_lr, dist and occ (the frames / layouts in ``input`` are data).
+    ``want_alpha=False`` (no autograd): ``alpha`` is not written and comes back as None -- ``Synthesizer.predict``
+    drops it (synthesizer.py:445, 472), and it is as large as ``a01``."""
     _lib.check_cuda(alpha_lr, input, occ)
     alpha_lr, input, occ = _c(alpha_lr), _c(input.detach()), _c(occ)
     n, nl, h, w = alpha_lr.shape
@@ -827,6 +829,14 @@ def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale):
         dist = _c(dist)
         if tuple(dist.shape[:2]) != (b, nl - 1):
             raise _lib.WaldoHipError(f"flow_ctx_alpha: dist {tuple(dist.shape)} is not (B, L-1, Nl)")
+    if not want_alpha and not (torch.is_grad_enabled() and (alpha_lr.requires_grad or occ.requires_grad or
+                                                               (dist is not None and dist.requires_grad))):
+        a01 = alpha_lr.new_empty(n, nl, hd, wd)
+        with _lib.on_device(alpha_lr.device):
+            _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist), _lib.ptr(occ),
+                      _lib.ptr(a01), None, b, t, tw, nl, dist.shape[2] if dist is not None else 0, c, chan_off, h, w,
+                      scale, _lib.current_stream(alpha_lr.device))
+        return a01, None
     return _FlowCtxAlpha.apply(alpha_lr, input, dist, occ, tw, chan_off, scale)
 
 

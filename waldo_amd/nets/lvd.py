@@ -130,6 +130,10 @@ class Warper(nn.Module):
         self.allow_ghost = opt.allow_ghost
         # ask the fused flow pass for max_l alpha_ctx as a by-product (read it from .alpha_ctx_max after the call)
         self.keep_alpha_ctx_max = False
+        # False: the fused flow pass does not write `alpha` / `alpha_unflt` (2 a' - 1 on the Tw frames: as large as
+        # what it keeps) and decode_output returns None for them -- for callers that drop them, as Synthesizer.predict
+        # does (synthesizer.py:445, 472: `rec_output, _, _, _, _, raw_output, alpha_ctx = ...`).  Inference only.
+        self.return_alpha = True
         self.alpha_ctx_max = None
         self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused
 
@@ -381,9 +385,10 @@ class Warper(nn.Module):
         ho, wo = self.tgt_shape
         s = int(self.scale_hd)
         tw = tc if ctx_only else t
-        alpha = self.layer_to_output(obj_alpha, bg_alpha, grid, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # of (x + 1) / 2
-        if tw < alpha.size(1):  # (a full-range slice still costs autograd a zero-filled buffer and a copy backward)
-            alpha = alpha[:, :tw]                                               # B Tw L 1 H W
+        # the rough alphas of the Tw frames that are used (lvd.py:716-722 warps all T and slices: with four contexts of
+        # fourteen frames ten of them for nothing); (x + 1) / 2 folded into the taps
+        ga = grid if tw >= src_grid_obj.size(1) else [None, src_grid_obj[:, :tw], None, src_grid_bg[:, :tw]]
+        alpha = self.layer_to_output(obj_alpha, bg_alpha, ga, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # B Tw L 1 H W
         dist = None
         if ctx_only or not self.no_filter:
             if s >= 2 and s & (s - 1) == 0 and input.is_cuda and hd % s == 0 and wd % s == 0:
@@ -394,7 +399,8 @@ class Warper(nn.Module):
         occ = occ.reshape(b, t, nl, nl)
         # (an input of the context frames alone -- _clip_length -- goes with the occlusion matrices of those frames)
         occ_in = occ if input.size(1) == t else occ[:, :input.size(1)]
-        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s)
+        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s,
+                                           want_alpha=self.return_alpha)
 
         obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
@@ -422,7 +428,7 @@ class Warper(nn.Module):
         flow, alpha_ctx, disocc = res[:3]
         # by-product for Synthesizer.predict's disocclusion test (synthesizer.py:447: alpha_ctx.max(dim=3)[0])
         self.alpha_ctx_max = res[3].view(b, tc, tp, hd, wd) if self.keep_alpha_ctx_max else None
-        alpha_out = alpha_out.view(b, tw, nl, hd, wd)
+        alpha_out = alpha_out.view(b, tw, nl, hd, wd) if alpha_out is not None else None
         return (flow.view(b, tc, tp, 2, hd, wd), (alpha_out if self.fast else None), alpha_out,
                 (alpha_ctx if into_raw else alpha_ctx.view(b, tc, tp, nl, hd, wd)), disocc.view(b, tc, tp, 1, hd, wd))
 

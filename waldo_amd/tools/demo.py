@@ -152,6 +152,12 @@ def _obj_alpha_mask(opt, device):
     return m.view(1, 1, 1, ho, wo)
 
 
+def _cached_by(key, make):
+    if key not in _CONSTANTS:
+        _CONSTANTS[key] = make()
+    return _CONSTANTS[key]
+
+
 def _cached_index(values, device):
     """A small index tensor on the device, made once (a fresh host-to-device copy per call would stall the
     launch queue: see _cached)."""
@@ -203,21 +209,30 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames):
     occ, obj_alpha, bga, grid = estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(nb, nt, no, lo, 2),
                                                         bg_pose.view(nb, nt, 1, lb, 2), net["occ_score"],
                                                         obj_alpha_mask=mask)
-    ctx_ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
-    if opt.last_n_ctx > 0:
-        ctx_ts = ctx_ts[:, -opt.last_n_ctx:].contiguous()
     first = sel.index(frames[0])
-    pred_ts = torch.arange(first, first + n, device=dev, dtype=torch.int64)
+
+    def make_ctx_ts():  # synthesizer.py:438-442
+        ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
+        return WF.normalise_time_index(ts[:, -opt.last_n_ctx:] if opt.last_n_ctx > 0 else ts)
+
+    # the frame indices of a decode, made ONCE per shape and kept (int64, contiguous: as the kernels take them): the
+    # wrappers validate an index tensor against the time axis with one device -> host read per (tensor, version) --
+    # built afresh per call (synthesizer.py:438-444 does, its gather() checks on the device) every decode stopped
+    # the launch queue four times
+    ctx_ts = _cached_by(("ctx_ts", str(dev), ctx_len, nb, n, opt.last_n_ctx), make_ctx_ts)
+    pred_ts = _cached_by(("pred_ts", str(dev), first, n),
+                         lambda: torch.arange(first, first + n, device=dev, dtype=torch.int64))
     # decode_output + max_l alpha_ctx, which the fused flow pass produces as a by-product (the warper's switch and its
     # result are restored / cleared afterwards: no state is left on the module)
-    prev = warper.keep_alpha_ctx_max
+    prev, prev_alpha = warper.keep_alpha_ctx_max, warper.return_alpha
     warper.keep_alpha_ctx_max = True
+    warper.return_alpha = False  # (`alpha` / `alpha_unflt` are dropped two lines below, as in synthesizer.py:445)
     try:
         output, flow, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
                                                                      net["cls"], ctx_ts, pred_ts)
         mx = warper.alpha_ctx_max
     finally:
-        warper.keep_alpha_ctx_max = prev
+        warper.keep_alpha_ctx_max, warper.return_alpha = prev, prev_alpha
         warper.alpha_ctx_max = None
     # synthesizer.py:447-450: max / min over the contexts of max_l alpha_ctx, dmax[dmax - dmin > 1] = 0 -- one pass
     # over the flow pass's by-product (torch: aminmax, subtract, compare, masked_fill)
@@ -235,8 +250,13 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     b, t = real_vid.shape[:2]
     every = list(range(t))
     out = {}
-    # reconstruct video (synthesizer.py:436-445)
-    real_input = torch.cat([real_vid, real_lyt], dim=2)
+    # reconstruct video (synthesizer.py:436-445).  The reference concatenates all T frames and their layouts
+    # (synthesizer.py:445: 2.7 GB per step at the Cityscapes recipe, 1 ms); `decode_output` with `restrict_to_ctx` and no
+    # `include_self` reads the CONTEXT frames of it only (lvd.py:716-745, 837; Warper._clip_length): those alone are
+    # concatenated -- 29 % of the bytes, the same results bit for bit (tests/test_demo.py compares with the restatement
+    # that is handed all T frames)
+    n_in = t if getattr(opt, "include_self", False) else ctx_len
+    real_input = torch.cat([real_vid[:, :n_in], real_lyt[:, :n_in]], dim=2)
     rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every)
     out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
     if not opt.no_future:
