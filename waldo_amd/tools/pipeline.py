@@ -113,7 +113,8 @@ class Pipeline:
             lr = m * (nl * 2 + ghost) * hw                      # per-layer flows and object masks, low resolution
             fcw_out = m * (2 + nl + 1 + 1) * hwd                # flow, alpha_ctx, disocc, layer maximum
             add = {
-                "waldo_flow_ctx_alpha_fwd": 4 * (b * tc * nl * hw + b * tc * ncls * hwd + 2 * b * tc * nl * hwd),
+                # (a01 alone is written: predict drops `alpha` = 2 a01 - 1 and asks the pass not to write it)
+                "waldo_flow_ctx_alpha_fwd": 4 * (b * tc * nl * hw + b * tc * ncls * hwd + b * tc * nl * hwd),
                 "waldo_flow_ctx_warp_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out),
                 "waldo_flow_ctx_warp_raw_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out + m * hwd),  # + score
                 "waldo_frame_warp_fuse_fwd": 4 * (b * tc * c * hwd + m * (2 + nl) * hwd + b * tp * (c + 1) * hwd
