@@ -404,7 +404,7 @@ class _LayersToOutput(torch.autograd.Function):
                  (bg, grid_bg, None, nf, delta_bg, bg_bc, (1, nl, 0)))
         with _lib.on_device(obj.device):
             for inp, grid, msk, n, delta, bc, slots in calls:
-                if n == 0 or (slots[0] == 0):
+                if n == 0:  # (no frames, or no objects: the background alone)
                     continue
                 od, inn = bc if bc is not None else (max(n, 1), max(n, 1))
                 _lib.call("waldo_grid_sample2d_ex_fwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(out), _lib.ptr(msk),
@@ -434,7 +434,7 @@ class _LayersToOutput(torch.autograd.Function):
             for inp, grid, n, delta, bc, slots, gi, want_g in calls:
                 want_i = gi is not None
                 gg = torch.empty_like(grid) if want_g else None
-                if n > 0 and slots[0] > 0 and (want_i or want_g):
+                if n > 0 and (want_i or want_g):
                     od, inn = bc if bc is not None else (max(n, 1), max(n, 1))
                     _lib.call("waldo_grid_sample2d_ex_bwd", _lib.ptr(inp), _lib.ptr(grid), _lib.ptr(grad_out),
                               _lib.ptr(gi), _lib.ptr(gg), n, c, inp.shape[2], inp.shape[3], h, w, delta, od, inn,
