@@ -663,9 +663,10 @@ def run_pipeline(args, clips, world, rank, device, dist):
     tp = t - pipe.ctx_len
     pending = [None]  # the previous step's all-gather: over xGMI while this step's kernels run
 
-    graph = pipe.graphed() if args.graph else None
+    graph_box = [pipe.graphed() if args.graph else None]
 
     def step():
+        graph = graph_box[0]
         if graph is not None:
             out = graph(*graph.inputs)
             if dist is not None:
@@ -699,6 +700,23 @@ def run_pipeline(args, clips, world, rank, device, dist):
             step()
         fence()
         elapsed = time.perf_counter() - t0
+    # one GPU, eager line: the same step replayed from ONE HIP graph beside it (the GPU's time without the launch
+    # gaps; what `--graph` makes the line's ms_per_step)
+    graph_ms = None
+    if dist is None and graph_box[0] is None and emulated is None:
+        try:
+            graph_box[0] = pipe.graphed()
+            for _ in range(max(args.warmup, 1)):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()  # (the same step, its hand-over of the frames included)
+            fence()
+            graph_ms = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+        except Exception as exc:  # (the eager line stands on its own)
+            graph_ms = f"capture failed: {exc}"
+        graph_box[0] = None
     if dist is not None:
         tt = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -767,6 +785,8 @@ def run_pipeline(args, clips, world, rank, device, dist):
                                  "kernels and launch gaps between the calls (indexing, permutes, the stand-ins)",
                          "entry_points": table},
         }
+        if graph_ms is not None:
+            out["ms_per_step_graph_replay"] = graph_ms
         if emulated:
             out["emulated_shard"] = {"rank": emulated[0], "world": emulated[1],
                                      "note": "value = the WHOLE job's frames / this one rank's step time: what the "
