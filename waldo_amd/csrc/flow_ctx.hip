@@ -39,7 +39,7 @@ namespace waldo {
 #define WALDO_FCW_CONST_OUT 0   // 1: outputs of layers outside the active set as constants, behind a wave-uniform branch
                                 // -- measured SLOWER (8.1 against 7.6 ms: twelve more branches cut the store stream up)
 #endif
-template <int LP>
+template <int LP, int NCP>
 __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, float* __restrict__ a01,
@@ -84,21 +84,21 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
   if (dist != nullptr) {
     // softmax over the Nl layout logits of this pixel (held in registers)
     const float* lg = input + (((int64_t)b * T + t) * C + chan_off) * HWd + p;
-    float pr[kMaxCls];
+    float pr[NCP];
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) {
+    for (int c = 0; c < NCP; ++c) {
       pr[c] = (c < Nl) ? lg[(int64_t)min(c, Nl - 1) * HWd] : -INFINITY;
       m = fmaxf(m, pr[c]);
     }
     float den = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) {
+    for (int c = 0; c < NCP; ++c) {
       pr[c] = (c < Nl) ? expf(pr[c] - m) : 0.0f;
       den += pr[c];
     }
 #pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
+    for (int c = 0; c < NCP; ++c) pr[c] = pr[c] / den;
     // (non-finite logits make every filter weight NaN, and 0 * NaN is NaN: no short cuts then)
     if (__ballot(!(den >= 1.0f && den <= 3.0e38f)) != 0ull) active = LP >= 32 ? 0xffffffffu : (1u << LP) - 1u;
 #pragma unroll
@@ -1012,14 +1012,27 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   }
   hipStream_t st = (hipStream_t)stream;
   const HdGeom geom = hd_geom(N, H * scale, W * scale);
+  // (the class probabilities of a pixel live in registers: compiled for up to kFewCls classes and for kMaxCls)
+#define WALDO_FCA_CASE(LPV)                                                                                              \
+  case LPV:                                                                                                              \
+    if (dist == nullptr || Nl <= kFewCls)                                                                                \
+      hipLaunchKernelGGL((flow_ctx_alpha_kernel<LPV, kFewCls>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,   \
+                         alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, (int)N,     \
+                         geom.tiles, geom.nbands);                                                                       \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((flow_ctx_alpha_kernel<LPV, kMaxCls>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,   \
+                         alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, (int)N,     \
+                         geom.tiles, geom.nbands);                                                                       \
+    break;
   switch (flow_ctx_pad_l(L)) {
-    WALDO_FC_CASE(4, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
-    WALDO_FC_CASE(8, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
-    WALDO_FC_CASE(12, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
-    WALDO_FC_CASE(17, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
-    WALDO_FC_CASE(24, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
-    WALDO_FC_CASE(32, flow_ctx_alpha_kernel, alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale)
+    WALDO_FCA_CASE(4)
+    WALDO_FCA_CASE(8)
+    WALDO_FCA_CASE(12)
+    WALDO_FCA_CASE(17)
+    WALDO_FCA_CASE(24)
+    WALDO_FCA_CASE(32)
   }
+#undef WALDO_FCA_CASE
   return launch_status("waldo_flow_ctx_alpha_fwd");
 }
 

@@ -111,7 +111,7 @@ struct GradOfA01 {
   }
 };
 
-template <int LP>
+template <int LP, int NCP>
 __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_bwd_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, const float* __restrict__ g_a01,
@@ -156,23 +156,23 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
       f[l] = 1.0f;
       gv[l] = (l < L && live) ? grad_of_a01(((int64_t)n * L + min(l, L - 1)) * HWd + pc) : 0.0f;
     }
-    float pr[kMaxCls];
+    float pr[NCP];
     if (filt) {
       const float* lg = input + (((int64_t)b * T + t) * C + chan_off) * HWd + pc;
       float m = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < kMaxCls; ++c) {
+      for (int c = 0; c < NCP; ++c) {
         pr[c] = (c < Nl) ? lg[(int64_t)min(c, Nl - 1) * HWd] : -INFINITY;
         m = fmaxf(m, pr[c]);
       }
       float den = 0.0f;
 #pragma unroll
-      for (int c = 0; c < kMaxCls; ++c) {
+      for (int c = 0; c < NCP; ++c) {
         pr[c] = (c < Nl) ? expf(pr[c] - m) : 0.0f;
         den += pr[c];
       }
 #pragma unroll
-      for (int c = 0; c < kMaxCls; ++c) pr[c] = pr[c] / den;
+      for (int c = 0; c < NCP; ++c) pr[c] = pr[c] / den;
 #pragma unroll
       for (int l = 1; l < LP; ++l) f[l] = 1.0f - dist_l1(sdist_t + (l - 1) * kMaxCls, pr, Nl) / 2.0f;
     }
@@ -192,15 +192,15 @@ __global__ __launch_bounds__(kBlock, WALDO_FCB_ALPHA_WAVES) void flow_ctx_alpha_
         if (l < L) {  // wave-uniform
           const float aup = up_sample(alpha_lr + ((int64_t)n * L + l) * HW, ut);
           const float gf = live ? -0.5f * ga[l] * aup : 0.0f;
-          float vals[kMaxCls];
+          float vals[NCP];
 #pragma unroll
-          for (int c = 0; c < kMaxCls; ++c) {
+          for (int c = 0; c < NCP; ++c) {
             // gf sign(d): gf with d's sign bit (v_bfi), or 0 where d == 0 -- four operations, not seven
             // (classes from Nl on: dist and pr are both 0 there)
             const float d = sdist_t[(l - 1) * kMaxCls + c] - pr[c];
             vals[c] = d == 0.0f ? 0.0f : gf * __builtin_copysignf(1.0f, d);
           }
-          const float red = wave_transpose_reduce<kMaxCls>(vals, lane);
+          const float red = wave_transpose_reduce<NCP>(vals, lane);
           const int c = bitrev6(lane);
           if (c < Nl) acc_d[wave][(l - 1) * kMaxCls + c] += red;
         }
@@ -564,13 +564,28 @@ extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* inpu
       hipLaunchKernelGGL(flow_ctx_alpha_bwd_rows_kernel<32>, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, alpha_lr,
                          input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W,
                          scale, tiles, tpb, groups);
-  } else switch (flow_ctx_pad_l(L)) {
-    WALDO_FCB_CASE(4, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(8, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(12, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(17, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(24, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
-    WALDO_FCB_CASE(32, flow_ctx_alpha_bwd_kernel, alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W, scale, tiles, tpb, groups)
+  } else {
+    // (the class probabilities of a pixel live in registers: compiled for up to kFewCls classes and for kMaxCls)
+#define WALDO_FCAB_CASE(LPV)                                                                                             \
+  case LPV:                                                                                                              \
+    if (dist == nullptr || Nl <= kFewCls)                                                                                \
+      hipLaunchKernelGGL((flow_ctx_alpha_bwd_kernel<LPV, kFewCls>), dim3((unsigned)(N * groups)), dim3(kBlock), 0, st,   \
+                         alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, \
+                         chan_off, H, W, scale, tiles, tpb, groups);                                                     \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((flow_ctx_alpha_bwd_kernel<LPV, kMaxCls>), dim3((unsigned)(N * groups)), dim3(kBlock), 0, st,   \
+                         alpha_lr, input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, \
+                         chan_off, H, W, scale, tiles, tpb, groups);                                                     \
+    break;
+    switch (flow_ctx_pad_l(L)) {
+      WALDO_FCAB_CASE(4)
+      WALDO_FCAB_CASE(8)
+      WALDO_FCAB_CASE(12)
+      WALDO_FCAB_CASE(17)
+      WALDO_FCAB_CASE(24)
+      WALDO_FCAB_CASE(32)
+    }
+#undef WALDO_FCAB_CASE
   }
   if (scale > 1) {
     const int64_t P = N * L;

@@ -62,6 +62,10 @@ __device__ __forceinline__ float up_sample(const float* __restrict__ plane, cons
 }
 
 constexpr int kMaxCls = 32;
+// The kernels that hold a pixel's class probabilities in registers are compiled for 20 classes (Cityscapes' 20, KITTI's
+// 19) and for kMaxCls: with the count only known at run time every pixel paid 32 exponentials, 32 divisions and -- in
+// the backward -- a 32-value transpose-reduce per object, for 20 classes.
+constexpr int kFewCls = 20;
 
 // ---------------------------------------------------------------------------------------
 // The order (occlusion matrix) of one frame in LDS, padded to LP x LP: by rows ([i][j], row stride kRow)
@@ -117,10 +121,12 @@ __device__ __forceinline__ bool dist_stage(float* sdist, const float* __restrict
 
 // sum_c |dist[row][c] - pr[c]| over the Nl classes in ascending order (pr[c] == 0 from class Nl on: the
 // padding of a group of four adds exact zeros)
-__device__ __forceinline__ float dist_l1(const float* sdist_row, const float (&pr)[kMaxCls], int Nl) {
+template <int NCP>
+__device__ __forceinline__ float dist_l1(const float* sdist_row, const float (&pr)[NCP], int Nl) {
+  static_assert(NCP % 4 == 0 && NCP <= kMaxCls, "classes in groups of four");
   float d = 0.0f;
 #pragma unroll
-  for (int c = 0; c < kMaxCls; c += 4)
+  for (int c = 0; c < NCP; c += 4)
     if (c < Nl) {  // uniform
       const f32x4_o q = *reinterpret_cast<const f32x4_o*>(sdist_row + c);
 #pragma unroll
