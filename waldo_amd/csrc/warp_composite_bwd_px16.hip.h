@@ -305,6 +305,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
       }
     }
 
+    WALDO_PRIO_ON(WALDO_K1_PRIO_MASK, 2);
     const float g0 = grad_rgb[(int64_t)f * 3 * HW + p] * livef;
     const float g1 = grad_rgb[(int64_t)f * 3 * HW + HW + p] * livef;
     const float g2 = grad_rgb[(int64_t)f * 3 * HW + 2 * HW + p] * livef;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     };
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
+    WALDO_PRIO_OFF(WALDO_K1_PRIO_MASK, 2);
     WALDO_STAMP(2);
     {
 #pragma unroll
@@ -355,12 +357,14 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
           }
           continue;
         }
+        WALDO_PRIO_ON(WALDO_K1_PRIO_MASK, 1);
         if (fits[l]) {
           const int n = bh[l] * (bw[l] >> 1);
           if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
             stage_store(img + (l & 1) * kImgBufFloats, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
+        WALDO_PRIO_OFF(WALDO_K1_PRIO_MASK, 1);
         // the incoming alpha gradient of this layer travels with the staging loads (loaded where it
         // is used, the wave would wait for it with vmcnt(0) -- and with it for every box load in
         // flight)
@@ -511,6 +515,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     // ---- (G) a_m = (s_m3 + 1)/2 for m >= 1; a_0 is the constant 1.  Records, contribution bounds
     // and the grid gradient of every layer.  The records go out FIRST: the stores get the rest of
     // this phase to drain.
+    WALDO_PRIO_ON(WALDO_K1_PRIO_MASK, 4);
 #ifndef WALDO_ABL_NO_REC_STORE  // timing-only ablation: K1 without its record stores (wrong gradients)
     if (live) {
 #else
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
                                                  (uint32_t)p * 16u, HW * 16,
                                                  (f32x4){gxs[l], gys[l], ap[l], l >= 1 ? 0.5f * ga[l] : 0.0f});
     }
+    WALDO_PRIO_OFF(WALDO_K1_PRIO_MASK, 4);
     if constexpr (!kPark) lds_barrier();  // every wave is done sampling: gg overlays the staged image
     {
       float ggx[LP], ggy[LP];
@@ -600,6 +606,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
     // contracts the pixels it produced; the 4 wave results are summed through LDS in a fixed order
     // and stored as this tile's partial (no atomics, deterministic).
     if (gmap_partial != nullptr) {
+      WALDO_PRIO_ON(WALDO_K1_PRIO_MASK, 8);
       // (H1) the A operand wants basis[k][pixel] with k along lane & 15: the wave writes the 64 x 20
       // values it holds in the grid phase's operand order into its LDS slice [pixel][k]
       float* Bw = (C::kBtInPark && wave == 3) ? park + C::kGgFloats : img + C::kBtBase + wave * C::kBtFloats;
@@ -646,6 +653,7 @@ __global__ __launch_bounds__(kBlock, (GOCC ? 2 : Px16Cfg<LP>::kWavesPerSimd)) vo
             macc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bv, macc[mt][nt], 0, 0, 0);
         }
       }
+      WALDO_PRIO_OFF(WALDO_K1_PRIO_MASK, 8);
       WALDO_STAMP(14);
       __syncthreads();  // every wave is done reading gg: reuse its bytes for the accumulators
 #pragma unroll

@@ -45,6 +45,25 @@ namespace waldo {
 #ifndef WALDO_FWD8_WAVES
 #define WALDO_FWD8_WAVES 3   // register cap of the L <= 8 forward (it needs 109: four waves per SIMD)
 #endif
+// Wave priority (s_setprio) around the phases that ISSUE memory operations, so that a wavefront about to put loads or
+// stores in flight does not queue behind the other workgroups' tap arithmetic.  Level 0: off.  The masks pick the
+// phases: bit 0 a layer's staging stores + the next box loads, bit 1 a frame's first box loads (and K1's output-gradient
+// loads), bit 2 the output stores (K1: the records), bit 3 K1's MFMA contraction.
+// Measured (round 5, tools_dev/ab_bench.py, three boxes, same bits): K1 with bits 0 + 1: backward 2.050 -> 2.005 ms on
+// one box, 2.045 -> 2.035 and 2.060 -> 2.047 on two others (levels 1 / 2 / 3 alike); with the record stores or the MFMA
+// phase as well: nothing more; the forward: no change with any of its bits (+1 % with bit 2); K2 around its candidate
+// loads: +2.5 % (worse).  So: K1 alone, its loads alone.
+#ifndef WALDO_STAGE_PRIO
+#define WALDO_STAGE_PRIO 1
+#endif
+#ifndef WALDO_FWD_PRIO_MASK
+#define WALDO_FWD_PRIO_MASK 0
+#endif
+#ifndef WALDO_K1_PRIO_MASK
+#define WALDO_K1_PRIO_MASK 3
+#endif
+#define WALDO_PRIO_ON(mask, bit) do { if (WALDO_STAGE_PRIO && ((mask) & (bit))) __builtin_amdgcn_s_setprio(WALDO_STAGE_PRIO); } while (0)
+#define WALDO_PRIO_OFF(mask, bit) do { if (WALDO_STAGE_PRIO && ((mask) & (bit))) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef WALDO_STAGE_AHEAD
 #define WALDO_STAGE_AHEAD 2  // layers whose box loads are in flight at a time (measured 2 / 3 / 4 / 6 / 8:
                              // fwd 0.726 / 0.728 / 0.736 / 0.836 / 0.990 ms, bwd 2.222 / 2.225 / 2.242 / 2.58 / 2.59)
@@ -461,8 +480,10 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
       stg[l].c2 = ld8(src + 2 * HW, off);
       stg[l].c3 = ld8(src + 3 * HW, off);
     };
+    WALDO_PRIO_ON(WALDO_FWD_PRIO_MASK, 2);
 #pragma unroll
     for (int l = 0; l < kAhead; ++l) issue(l);
+    WALDO_PRIO_OFF(WALDO_FWD_PRIO_MASK, 2);
     if (f == f0) WALDO_FSTAMP(3);  // boxes, first loads issued
     if (f == f0 + 1) WALDO_FSTAMP(10);
     {
@@ -474,12 +495,14 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
           continue;
         }
         const bool fits = bh[l] * bw[l] <= kCap;  // block-uniform
+        WALDO_PRIO_ON(WALDO_FWD_PRIO_MASK, 1);
         if (fits) {
           const int n = bh[l] * (bw[l] >> 1);
           if (item_l < n)  // row-major with pitch bw: item = r * bw2 + xh, texel 2 * item
             stage_store(img + (l & 1) * kBuf, item_l, stg[l]);
         }
         if (l + kAhead < LP) issue(l + kAhead);
+        WALDO_PRIO_OFF(WALDO_FWD_PRIO_MASK, 1);
         __syncthreads();  // buffer l&1 complete; buffer (l+1)&1 no longer read by anyone
         if (fits) {
           const TapCore tc = tap_core_px(gx[l], gy[l], H, W);
@@ -553,12 +576,14 @@ __global__ __launch_bounds__(NW * kWave, (NW == 8 ? 1 : 1) * (LP <= 8 ? WALDO_FW
       if (alpha_out != nullptr && pm.live && (EXL || j < L))
         alpha_out[((int64_t)f * L + j) * HW + p] = 2.0f * ap - 1.0f;
     }
+    WALDO_PRIO_ON(WALDO_FWD_PRIO_MASK, 4);
     if (pm.live) {
       float* o = rgb + (int64_t)f * 3 * HW + p;
       o[0] = 2.0f * r - 1.0f;
       o[HW] = 2.0f * g - 1.0f;
       o[2 * HW] = 2.0f * b - 1.0f;
     }
+    WALDO_PRIO_OFF(WALDO_FWD_PRIO_MASK, 4);
     __syncthreads();  // boxred and the image buffers are re-used by the next frame
     if (f == f0) WALDO_FSTAMP(6);  // composite, stores issued, closing barrier
     if (f == f0 + 1) WALDO_FSTAMP(12);
