@@ -24,7 +24,18 @@ metric string:
   C5  4 clips x 14 frames of 512x1024, L=12, forward + all-gather
   LVD 2 clips x 5 frames of 128x256, L=17: the warp-path part of an LVD training step (the reference's live
       backward path, models/synthesizer.py:815-841), fwd+bwd, per-entry-point table
+  WIF 2 clips x 5 frames (4 context + 1 predicted) of 512x1024 over 128x256 layers, L=17: BASELINE config 3 as the
+      reference RUNS it (Synthesizer.inpaint, models/synthesizer.py:517-576, 631-633): the unrestricted grid_to_flow +
+      input_to_output under no_grad, then WIF.forward + backward; per-entry-point table
   (--pipeline with C4 / C5: Synthesizer.predict's hot-path calls on whole clips instead of the synthetic forward)
+
+Timing protocol of every workload: a time-based settle (>= 0.3 s of the step, `settle_ms`) before the --warmup steps,
+then FIVE blocks of exactly --steps steps, each bracketed by barrier + synchronize; `ms_per_step` is the MEDIAN block
+(`ms_per_step_blocks` lists all five, max over ranks each); the per-kernel event pairs are taken in a separate pass
+afterwards, so the timed blocks carry no events.
+
+With --gpus N > 1 and the default workload the line carries a `north_star` object (the RCCL all-gather of composited
+frames, the C5 pipeline as ONE job split over the N ranks, a cross-rank bit-equality check): see north_star_block.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel, algorithmic bytes per launch / mean launch duration measured live
@@ -143,15 +154,33 @@ def cpu_baseline_child(argv):
     print(json.dumps({"seconds": [once() for _ in range(reps)]}), flush=True)
 
 
+def cpu_throttle_counters():
+    """cgroup CPU statistics of this container (cpu.stat: nr_periods, nr_throttled, throttled_usec / throttled_time),
+    or {}: what tells a quota-throttled measurement from one disturbed by other tenants of the host."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            with open(path) as fh:
+                out = {}
+                for ln in fh:
+                    k, _, v = ln.partition(" ")
+                    if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "usage_usec"):
+                        out[k] = int(v)
+                return out
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
 def cpu_baseline(nl, h, w, frames, reps):
     """Oracle (kind "port") on the host cores: fwd+bwd frames/s on `frames` frames.
 
     Every measurement runs in a CHILD process that is pinned before torch starts (OMP_NUM_THREADS, OMP_PROC_BIND=close,
     OMP_PLACES=cores, an affinity mask of as many CPUs as threads), with thread counts that fit the CPU time the box
     really grants (`cpu_budget`: affinity cut to the cgroup quota).  The thread count is the best median of three
-    on the same sample among a FIXED list; the figure is the median of `reps` runs at that count with best /
-    worst beside it, and `unstable: true` when worst / best exceeds 1.5 or when the probe's median at that thread count
-    and the measurement's disagree by more than 1.5x (the same configuration on the same sample, minutes apart)."""
+    on the same sample among a FIXED list; the figure is the median of the LAST `reps` runs at that count, and batches of
+    `reps` runs are repeated (at most three) until worst / best of a batch is <= 1.3.  The cgroup's throttling counters
+    are read before and after and printed: `unstable: true` (worst / best still > 1.3, or the probe and the measurement
+    at that thread count disagree by more than 1.5x) comes with the counter that explains it, or says that none moved."""
     import subprocess
     budget = cpu_budget()
 
@@ -168,25 +197,47 @@ def cpu_baseline(nl, h, w, frames, reps):
         xs = sorted(xs)
         return xs[len(xs) // 2]
 
+    before = cpu_throttle_counters()
     cands = [c for c in (4, 8, 16, 32) if c <= budget] or [budget]
     probe = {c: median(child(frames, 3, c)) for c in cands}  # the SAME sample as the measurement
     cores = min(probe, key=probe.get)
-    times = sorted(child(frames, max(reps, 3), cores))
+    batches = []
+    for _ in range(3):
+        batches.append(sorted(child(frames, max(reps, 3), cores)))
+        if batches[-1][-1] / batches[-1][0] <= 1.3:
+            break
+    times = batches[-1]
     med = median(times)
     f1 = max(1, min(4, frames))
     t1 = median(child(f1, 3, 1))
+    after = cpu_throttle_counters()
+    delta = {k: after[k] - before[k] for k in after if k in before}
+    spread = times[-1] / times[0]
     disagree = max(med, probe[cores]) / min(med, probe[cores])  # two runs of one configuration, minutes apart
+    unstable = bool(spread > 1.3 or disagree > 1.5)
+    if delta.get("nr_throttled", 0) > 0:
+        why = (f"cgroup CPU quota: throttled in {delta['nr_throttled']} of {delta.get('nr_periods', '?')} periods during the "
+               f"baseline ({delta.get('throttled_usec', delta.get('throttled_time', 0))} "
+               f"{'us' if 'throttled_usec' in delta else 'ns'} throttled)")
+    elif delta:
+        why = ("no cgroup throttling during the baseline (nr_throttled unchanged): the spread comes from outside this "
+               "container -- other tenants of the shared host (steal time is not visible from inside)")
+    else:
+        why = "cpu.stat not readable in this container: cause of the spread unknown"
     out = {"value": round(frames / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
            "value_best": round(frames / times[0], 3), "value_worst": round(frames / times[-1], 3),
-           "unstable": bool(times[-1] / times[0] > 1.5 or disagree > 1.5),
+           "worst_over_best": round(spread, 3), "batches_run": len(batches),
+           "unstable": unstable, "spread_explained_by": why if unstable else None,
+           "cpu_stat_delta": delta or None,
            "probe_over_measurement": round(probe[cores] / med, 3),
            "value_1_thread": round(f1 / t1, 3), "cpu_budget": budget,
            "thread_probe_frames_per_s": {str(c): round(frames / t, 3) for c, t in probe.items()},
            "sample": f"{frames} frames of the same workload ({nl}x4x{h}x{w}, fwd+bwd), "
-                     f"median of {len(times)} after warm-up (best / worst beside it), torch {torch.__version__} "
+                     f"median of the last batch of {len(times)} runs after warm-up (best / worst beside it; batches are "
+                     f"repeated, at most 3, until worst / best <= 1.3), torch {torch.__version__} "
                      f"CPU in a pinned child process (OMP_PROC_BIND=close, affinity = {cores} CPUs), {cores} threads = "
                      f"best median of 3 on the same {frames} frames among {cands} (CPU budget {budget} of "
-                     f"{os.cpu_count()} logical CPUs); unstable = worst / best > 1.5 or the probe and the measurement at "
+                     f"{os.cpu_count()} logical CPUs); unstable = worst / best > 1.3 or the probe and the measurement at "
                      f"{cores} threads disagree by more than 1.5x; value_1_thread: {f1} frames, median of 3"}
     return out
 
@@ -214,7 +265,13 @@ CONFIGS = {
     "C5": (4, 14, 12, 512, 1024, "infer"),
     # the reference's live backward path: the warp-path part of an LVD training step (waldo_amd/tools/lvd_step.py)
     "LVD": (2, 5, 17, 128, 256, "lvd"),
+    # BASELINE config 3 as the reference runs it: Synthesizer.inpaint's call order at the train_wif.sh recipe
+    # (waldo_amd/tools/wif_step.py): the warp path under no_grad, then WIF.forward + backward
+    "WIF": (2, 5, 17, 512, 1024, "wif"),
 }
+
+TIMED_BLOCKS = 5       # blocks of --steps steps; the median block is the line's ms_per_step
+SETTLE_SECONDS = 0.3   # of the step itself, before the --warmup steps (a cold box: clocks, caches, allocator)
 
 
 def settle_interpreter():
@@ -224,6 +281,49 @@ def settle_interpreter():
     tools_dev/lvd_dbg.py: 20 steps' worth -- has next to nothing to traverse.  The collector stays enabled."""
     gc.collect()
     gc.freeze()
+
+
+def settle_gpu(step, fence, seconds=SETTLE_SECONDS):
+    """Run the step for at least `seconds` (disclosed as `settle_ms`): the driver's `--warmup 5` is 16 ms of GPU work
+    on a box that was idle a moment ago -- clocks, caches and the allocator have not seen the workload yet."""
+    fence()
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            break
+    fence()
+    return round((time.perf_counter() - t0) * 1e3, 1)
+
+
+def timed_blocks(step, fence, steps, dist=None, device=None, backend="nccl", nblocks=TIMED_BLOCKS):
+    """`nblocks` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize (`fence`); returns the
+    blocks' seconds, the MAX over ranks of each.  No events are recorded inside them."""
+    blocks = []
+    for _ in range(nblocks):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        blocks.append(time.perf_counter() - t0)
+    if dist is not None:
+        t = torch.tensor(blocks, device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks = t.tolist()
+    return blocks
+
+
+def median_block(blocks):
+    return sorted(blocks)[len(blocks) // 2]
+
+
+def block_fields(blocks, steps, settle_ms):
+    return {"ms_per_step_blocks": [round(b / steps * 1e3, 4) for b in blocks], "settle_ms": settle_ms,
+            "timing": f"median of {len(blocks)} blocks of {steps} steps (each bracketed by barrier + synchronize, max over "
+                      f"ranks), after {settle_ms} ms of settling and the warm-up steps; per-kernel events in a separate pass"}
 
 
 def spawn_ranks(n):
@@ -286,6 +386,12 @@ def main():
                     help="set a test-only kernel-variant switch of the C ABI (include/waldo_hip.h: WALDO_DEBUG_*) for A/B "
                          "timing")
     ap.add_argument("--lib", default=None, help="A/B timing: another build of the library (tools_dev/build_variant.py)")
+    ap.add_argument("--north-star", choices=["auto", "on", "off"], default="auto",
+                    help="append the `north_star` object (all-gather of composited frames over the ranks, the C5 pipeline "
+                         "as ONE job split over them, cross-rank bit-equality) to the default workload's line; auto: when "
+                         "--gpus > 1")
+    ap.add_argument("--north-star-config", choices=["C4", "C5"], default="C5",
+                    help="recipe of the north_star block's pipeline job (C5 = Cityscapes 512x1024, the north star's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -336,6 +442,9 @@ def main():
 
     if args.config == "LVD":
         run_lvd(args, clips, world, rank, device, dist)
+        return
+    if args.config == "WIF":
+        run_wif(args, clips, world, rank, device, dist)
         return
     if args.pipeline:
         if args.config not in ("C4", "C5"):
@@ -395,15 +504,12 @@ def main():
         fence()
         return time.perf_counter() - t0
 
+    settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
     settle_interpreter()
-    with _lib.KernelTimer() as kt:
-        elapsed = timed(args.steps)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
+    elapsed = median_block(blocks)
     # the same step with the loss gradient 2 * rgb / N written as ONE elementwise kernel (_SquareMean) instead of
     # autograd's four-pass chain: reported next to the headline, never as it
     loss_variants = None
@@ -411,11 +517,17 @@ def main():
         n = max(5, min(args.steps, 20))
         for _ in range(2):
             step(loss=_SquareMean.apply)
+        one_pass = sorted(timed(n, loss=_SquareMean.apply) / n for _ in range(3))[1]
         loss_variants = {"autograd_loss_ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                         "one_pass_loss_gradient_ms_per_step": round(timed(n, loss=_SquareMean.apply) / n * 1e3, 4),
+                         "one_pass_loss_gradient_ms_per_step": round(one_pass * 1e3, 4),
                          "note": "value / ms_per_step use out.square().mean().backward() as it is written in SURVEY "
                                  "8(d); the second line is the same step with the loss gradient 2*rgb/N in one "
-                                 "elementwise pass (bench.py:_SquareMean, same numbers)"}
+                                 "elementwise pass (bench.py:_SquareMean, same numbers; median of 3 short blocks)"}
+    # per-entry-point device times from a SEPARATE pass (event pairs on the launch stream around every C-ABI call):
+    # the timed blocks above carry no events
+    n_events = max(5, min(args.steps, 20))
+    with _lib.KernelTimer() as kt:
+        timed(n_events)
 
     # launch-bound shapes: what part of a replay is kernel, what part the floor of launching a graph
     launch_split = None
@@ -452,6 +564,7 @@ def main():
                                 "forwards - empty-graph replay) / 16: the forward kernel with its in-graph dependency "
                                 "boundary, without the per-replay launch floor"}
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_frames = frames * world
@@ -466,7 +579,7 @@ def main():
             # time plus the graph's launch floor
             ks = {"waldo_warp_composite_fwd": (args.steps, ms_per_step)}
         else:
-            ks = kt.summary()
+            ks = kt.summary()  # (from the separate events pass)
             # without autograd the forward is the one-launch entry point from the control points
             # (same kernel, mapping folded in): reported under the forward's name
             if "waldo_warp_composite_pts_fwd" in ks and "waldo_warp_composite_fwd" not in ks:
@@ -519,12 +632,24 @@ def main():
                                          else "no data-path collective")},
             "roofline": roof,
         }
+        out.update(block_fields(blocks, args.steps, settle_ms))
         if loss_variants is not None:
             out["loss_variants"] = loss_variants
             out["value_one_pass_loss_gradient"] = round(
                 total_frames / (loss_variants["one_pass_loss_gradient_ms_per_step"] * 1e-3), 2)
         if launch_split is not None:
             out["launch_split"] = launch_split
+    # the north star's multi-GPU evidence rides on the default command's line (the driver's scaling run passes no flags)
+    want_ns = args.north_star == "on" or (args.north_star == "auto" and world > 1 and args.config == "C3" and not custom)
+    if want_ns and dist is not None:
+        del layers, pts, occ
+        torch.cuda.empty_cache()
+        if rank == 0:  # (a copy on stderr first: should the block take the process down, the headline was said)
+            print("bench.py: headline before the north_star block: " + json.dumps(out), file=sys.stderr, flush=True)
+        ns = north_star_block(args, world, rank, device, dist)
+        if rank == 0:
+            out["north_star"] = ns
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nl, h, w, min(args.cpu_frames, max(1, 28 * 131072 // hw)),
                                                args.cpu_reps)
@@ -532,6 +657,165 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def north_star_block(args, world, rank, device, dist):
+    """What BASELINE.json's north star asks of N GPUs, measured by the ONE multi-GPU command the driver runs
+    (`bench.py --gpus N`), after its headline loop -- every rank calls this; rank 0 gets the object for the line:
+
+      all_gather     the C4 and C5 synthetic forwards with the all-gather of the composited frames (SURVEY 8e;
+                     tools/engine.py:86-92 is the reference's all_gather): frames and bytes per rank, the collective
+                     alone (ms, GB/s received per rank), the step with the gather waited for at once (overlap off) and
+                     overlapped with the next step's kernels (overlap on), and what of it stays exposed in either form
+      strong_split   the C5 pipeline (Synthesizer.predict's hot-path calls) as ONE job of 4 clips whose (b, t) output
+                     units are dealt over the N ranks (tools/demo.py:predict_sharded), one all-gather of the predicted
+                     frames per step: ms_per_step (max over ranks), every rank's own compute time, the whole job on rank 0
+                     alone and the speed-up over it
+      gather_bit_equal   a 1-clip job split over the ranks and all-gathered equals the single-rank predict() bit for bit
+                     on EVERY rank (all-reduced)
+      rccl_ranks     the world size the communicator reports, `backend` its name ("nccl" is RCCL on ROCm)
+
+    A part that raises is recorded as a string; the headline and the exit code survive it."""
+    import waldo_amd
+    from waldo_amd import functional as WF
+    from waldo_amd.dist import all_gather_frames, all_gather_frames_async
+    from waldo_amd.tools.pipeline import Pipeline
+    from waldo_amd.tools.utils import get_grid
+    n = max(3, min(args.steps, 10))
+    cpu_coll = args.dist_backend != "nccl"
+    res = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "steps_per_measurement": n}
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_max(fn, wait=None):
+        """ms per call of fn over n calls between fences, max over ranks."""
+        fn()
+        if wait is not None:
+            wait()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        if wait is not None:
+            wait()
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / n * 1e3], device="cpu" if cpu_coll else device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def gather_part(name):
+        c_clips, c_fpc, c_nl, c_h, c_w, _ = CONFIGS[name]
+        frames = c_clips * c_fpc
+        tps = waldo_amd.TPSWarp(c_h, c_w, get_grid(4, 4).view(-1, 2)).to(device)
+        layers, pts, occ = synth(frames, c_nl, c_h, c_w, device, seed=rank)
+        pending = [None]
+
+        def fwd():
+            with torch.no_grad():
+                return WF.warp_composite(layers, pts, occ, tps.inverse_kernel, tps.basis_t)
+
+        rgb = fwd()
+
+        def sync_step():
+            all_gather_frames(fwd(), frames * world)
+
+        def overlapped_step():
+            prev, pending[0] = pending[0], all_gather_frames_async(fwd(), frames * world)
+            if prev is not None:
+                prev.wait()
+
+        def drain():
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+
+        kernel_ms = timed_max(fwd)
+        gather_ms = timed_max(lambda: all_gather_frames(rgb, frames * world))
+        off_ms = timed_max(sync_step)
+        on_ms = timed_max(overlapped_step, wait=drain)
+        nbytes = rgb.numel() * 4
+        return {"workload": f"{name}: {frames} frames of {c_h}x{c_w}, {c_nl} layers per rank, forward + all-gather",
+                "frames_per_rank": frames, "bytes_sent_per_rank": nbytes, "bytes_received_per_rank": nbytes * (world - 1),
+                "forward_ms": round(kernel_ms, 4), "all_gather_alone_ms": round(gather_ms, 4),
+                "all_gather_GBps_received_per_rank": round(nbytes * (world - 1) / (gather_ms * 1e-3) / 1e9, 2),
+                "step_ms_overlap_off": round(off_ms, 4), "step_ms_overlap_on": round(on_ms, 4),
+                "exposed_ms_overlap_off": round(off_ms - kernel_ms, 4), "exposed_ms_overlap_on": round(on_ms - kernel_ms, 4)}
+
+    def strong_part():
+        name = args.north_star_config
+        clips = CONFIGS[name][0]
+        pipe = Pipeline(name, clips, device, seed=0, motion=args.motion, shard=(rank, world))
+        tp = pipe.frames - pipe.ctx_len
+        pending = [None]
+
+        def own():
+            return pipe()["inp_pred_vid"]
+
+        def step():
+            prev, pending[0] = pending[0], all_gather_frames_async(own(), clips * tp)
+            if prev is not None:
+                prev.wait()
+
+        def drain():
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+
+        for _ in range(2):
+            own()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            own()
+        torch.cuda.synchronize()
+        mine = torch.tensor([(time.perf_counter() - t0) / n * 1e3], device="cpu" if cpu_coll else device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        job_ms = timed_max(step, wait=drain)
+        whole_ms = None
+        if rank == 0:  # the whole job on one GPU, the others idle: T(1) of the speed-up
+            whole = Pipeline(name, clips, device, seed=0, motion=args.motion)
+            for _ in range(2):
+                whole()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                whole()
+            torch.cuda.synchronize()
+            whole_ms = (time.perf_counter() - t0) / n * 1e3
+            del whole
+        fence()
+        per_rank = [round(x.item(), 4) for x in every]
+        out = {"workload": f"{name} pipeline, ONE job of {clips} clips x {pipe.frames} frames split over {world} ranks by (b, t) "
+                           f"output units, one all-gather of the inpainted predicted frames per step (overlapped)",
+               "ms_per_step": round(job_ms, 4), "per_rank_compute_ms": per_rank,
+               "rank_imbalance_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 3)}
+        if rank == 0:
+            out["whole_job_on_rank0_ms"] = round(whole_ms, 4)
+            out["speedup_over_one_gpu"] = round(whole_ms / job_ms, 3)
+            out["frames_per_s"] = round(clips * pipe.frames / (job_ms * 1e-3), 2)
+        return out
+
+    def equal_part():
+        name = args.north_star_config
+        one = Pipeline(name, 1, device, seed=0, motion=args.motion, shard=(rank, world))
+        got = one.gather(one(phases=("pred",)), keys=["inp_pred_vid"])["inp_pred_vid"]
+        ref = Pipeline(name, 1, device, seed=0, motion=args.motion)()["inp_pred_vid"]
+        ok = torch.tensor([1 if torch.equal(got, ref) else 0], device="cpu" if cpu_coll else device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item())
+
+    parts = (("all_gather_C4", lambda: gather_part("C4")), ("all_gather_C5", lambda: gather_part("C5")),
+             ("strong_split", strong_part), ("gather_bit_equal", equal_part))
+    for key, fn in parts:
+        try:
+            res[key] = fn()
+        except Exception as exc:  # (recorded, not raised: the headline line and the exit code survive)
+            res[key] = f"failed: {type(exc).__name__}: {exc}"
+        torch.cuda.empty_cache()
+    return res
 
 
 def run_lvd(args, clips, world, rank, device, dist):
@@ -549,38 +833,39 @@ def run_lvd(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):
+    settle_ms = settle_gpu(step, fence)
+    for _ in range(args.warmup):
         step()
-
-    def timed(run):
-        settle_interpreter()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        fence()
-        return time.perf_counter() - t0
-
-    elapsed_eager = timed(step)
+    settle_interpreter()
+    blocks_eager = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
     # forward, loss and backward captured ONCE and replayed (the library launches on the current stream and never
-    # synchronises; its host-side index checks are skipped during capture).  The step is ~90 short launches behind
-    # ~2.4 ms of interpreter and autograd-engine time per step: eager, it runs at the speed of the box's host
-    # (1.9 - 3.1 ms over this pool's boxes); the replay is the GPU's time.  The leaves' gradients are the graph's
-    # buffers: every replay overwrites them.
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
+    # synchronises; the frame indices are validated by the kernels, in a replay as in an eager call).  The step is ~90
+    # short launches behind ~1.6 ms of interpreter and autograd-engine time per step: eager, it runs at the speed of the
+    # box's host; the replay is the GPU's time.  The leaves' gradients are the graph's buffers: every replay overwrites
+    # them.  A capture that fails leaves the eager line standing (`--graph` then reports the failure as its ms_per_step
+    # note); a hard GPU fault is not catchable in-process: the eager blocks above have been timed by then.
+    blocks_graph, graph_note = None, None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
             step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
-    for _ in range(max(args.warmup, 3)):
-        graph.replay()
-    elapsed_graph = timed(graph.replay)
-    elapsed = elapsed_graph if args.graph else elapsed_eager
+        settle_gpu(graph.replay, fence)
+        blocks_graph = timed_blocks(graph.replay, fence, args.steps, dist, device, args.dist_backend)
+        _lib.IndexStatus.check_all(sync=True)
+    except Exception as exc:
+        graph_note = f"capture failed: {type(exc).__name__}: {exc}"
+    use_graph = args.graph and blocks_graph is not None
+    blocks = blocks_graph if use_graph else blocks_eager
+    elapsed = median_block(blocks)
+    elapsed_eager = median_block(blocks_eager)
+    elapsed_graph = median_block(blocks_graph) if blocks_graph is not None else None
     grads_ok = step.grads_finite()
     # the per-entry-point table from a SECOND, untimed pass: a step is ~250 short launches queued ahead of the GPU,
     # and two event records around each of its ~70 library calls make the host the bottleneck (3.7 ms against 2.1)
@@ -589,11 +874,6 @@ def run_lvd(args, clips, world, rank, device, dist):
         for _ in range(n_table):
             step()
         fence()
-    if dist is not None:
-        tt = torch.tensor([elapsed, elapsed_eager, elapsed_graph], device=device if args.dist_backend == "nccl" else "cpu",
-                          dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_eager, elapsed_graph = tt.tolist()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         table = {}
@@ -626,10 +906,96 @@ def run_lvd(args, clips, world, rank, device, dist):
                                  "launch gaps",
                          "entry_points": table},
             "grads_finite": grads_ok,
-            "launch": "the whole step (forward, loss, backward) replayed from one HIP graph" if args.graph else "eager",
+            "launch": "the whole step (forward, loss, backward) replayed from one HIP graph" if use_graph else "eager",
             "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 4),
-            "ms_per_step_graph_replay": round(elapsed_graph / args.steps * 1e3, 4),
+            "ms_per_step_graph_replay": round(elapsed_graph / args.steps * 1e3, 4) if elapsed_graph is not None else graph_note,
         }
+        out.update(block_fields(blocks, args.steps, settle_ms))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_wif(args, clips, world, rank, device, dist):
+    """`--config WIF`: BASELINE config 3 as the reference RUNS it -- the call order of Synthesizer.inpaint
+    (models/synthesizer.py:517-576, 631-633) at the scripts/cityscapes/train_wif.sh recipe: under no_grad the
+    producers, estimate_alpha_grid_occ and decode_output through the UNRESTRICTED Warper.grid_to_flow
+    (models/nets/lvd.py:602-705: train_wif.sh does not pass --s_restrict_to_ctx) and input_to_output, then WIF.forward
+    (models/nets/wif.py:37-57) with autograd, the L1 loss and its backward through waldo_wif_fuse_bwd
+    (waldo_amd/tools/wif_step.py; the UNet's place is taken by a 1 x 1 convolution that carries gradients).  Clips are
+    independent: ranks keep their own (DDP's split, tools/engine.py:63-64); the gradient all-reduce DDP would do is the
+    stand-in network's, outside the path: no data-path collective."""
+    from waldo_amd import _lib
+    from waldo_amd.tools.wif_step import WifStep
+    step = WifStep(clips, device, seed=rank, motion=args.motion)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    settle_ms = settle_gpu(step, fence)
+    for _ in range(args.warmup):
+        step()
+    settle_interpreter()
+    blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
+    elapsed = median_block(blocks)
+    # the no-grad half alone (what `inpaint` computes before net_ii): its share of the step
+    decode_blocks = timed_blocks(step.decode, fence, max(3, args.steps // 2), dist, device, args.dist_backend, nblocks=3)
+    decode_ms = median_block(decode_blocks) / max(3, args.steps // 2) * 1e3
+    grads_ok = step.grads_finite()
+    step.warper.check_time_indices()
+    n_table = max(3, min(args.steps, 10))
+    with _lib.KernelTimer() as kt:
+        for _ in range(n_table):
+            step()
+        fence()
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        alg = step.hd_algorithmic_bytes()
+        table = {}
+        for name, (n, ms) in sorted(kt.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            per_step = n * ms / n_table
+            row = {"launches_per_step": round(n / n_table, 2), "ms_per_step": round(per_step, 4)}
+            if name in alg:
+                row["alg_bytes_per_step"] = alg[name]
+                row["GBps"] = round(alg[name] / (per_step * 1e-3) / 1e9, 1)
+                row["frac"] = round(row["GBps"] / HBM_PEAK_GBS, 4)
+            table[name] = row
+        in_lib = sum(r["ms_per_step"] for r in table.values())
+        o, t = step.opt, step.frames
+        hd, wd = step.vid.shape[-2:]
+        dom = max((k for k in alg if k in table), key=lambda k: table[k]["ms_per_step"])
+        out = {
+            "metric": f"WIF training-step frames/sec at {hd}x{wd}, {o.num_obj + 1} layers, {t}-frame clips ({step.ctx_len} "
+                      f"context + {t - step.ctx_len} predicted); warp path forward under no_grad + WIF.forward/backward, as "
+                      f"Synthesizer.inpaint runs it (not the headline metric)",
+            "value": round(clips * t * world / (elapsed / args.steps), 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"WIF recipe step (scripts/cityscapes/train_wif.sh: 8 clips over 4 GPUs): {clips} clips x {t} "
+                                   f"frames per GPU, {o.num_obj} objects + background, {o.num_lyt} layout classes, layers at "
+                                   f"{o.dim}x{int(o.dim * o.aspect_ratio)}, frames at {hd}x{wd}; no_grad: decoder tail -> pose "
+                                   f"affine -> estimate_alpha_grid_occ -> cat(vid, lyt) -> decode_output (UNRESTRICTED "
+                                   f"grid_to_flow + input_to_output); autograd: WIF.forward -> L1 loss -> backward; networks "
+                                   f"outside the path replaced by seeded stand-ins (UNet: a 1x1 convolution 40 -> 5), "
+                                   f"background motion '{args.motion}'",
+                       "frames_per_gpu": clips * t, "layers": o.num_obj + 1, "height": hd, "width": wd,
+                       "parallelism": f"clips sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": table[dom]["frac"], "traffic": None,
+                         "alg_bytes_per_launch": alg[dom], "ms_per_launch": table[dom]["ms_per_step"]},
+            "pipeline": {"ms_in_library_calls": round(in_lib, 4), "ms_outside": round(ms_per_step - in_lib, 4),
+                         "ms_no_grad_decode": round(decode_ms, 4),
+                         "note": "per C-ABI entry point, event pairs on the launch stream, from a second untimed pass; "
+                                 "ms_outside = framework kernels (the cat of frames and layouts, the stand-in "
+                                 "convolution forward + weight gradient, the loss) and launch gaps; ms_no_grad_decode = "
+                                 "the step's first half alone (everything before net_ii)",
+                         "entry_points": table},
+            "grads_finite": grads_ok,
+        }
+        out.update(block_fields(blocks, args.steps, settle_ms))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -690,16 +1056,12 @@ def run_pipeline(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
     settle_interpreter()
-    with _lib.KernelTimer() as kt:
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
+    blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
+    elapsed = median_block(blocks)
     # one GPU, eager line: the same step replayed from ONE HIP graph beside it (the GPU's time without the launch
     # gaps; what `--graph` makes the line's ms_per_step)
     graph_ms = None
@@ -708,26 +1070,24 @@ def run_pipeline(args, clips, world, rank, device, dist):
             graph_box[0] = pipe.graphed()
             for _ in range(max(args.warmup, 1)):
                 step()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()  # (the same step, its hand-over of the frames included)
-            fence()
-            graph_ms = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+            gb = timed_blocks(step, fence, args.steps, nblocks=3)  # (the same step, its hand-over of the frames included)
+            graph_ms = round(median_block(gb) / args.steps * 1e3, 4)
         except Exception as exc:  # (the eager line stands on its own)
             graph_ms = f"capture failed: {exc}"
         graph_box[0] = None
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    # the per-entry-point table from a SEPARATE pass (event pairs around every C-ABI call; none inside a HIP graph)
+    n_table = max(3, min(args.steps, 10))
+    with _lib.KernelTimer() as kt:
+        for _ in range(n_table):
+            step()
+        fence()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         table = {}
         alg = {} if strong else pipe.hd_algorithmic_bytes()  # (a rank's share of a split job: no per-kernel roofline)
         for name, (n, ms) in sorted(kt.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-            per_step = n * ms / args.steps
-            row = {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(per_step, 4)}
+            per_step = n * ms / n_table
+            row = {"launches_per_step": round(n / n_table, 2), "ms_per_step": round(per_step, 4)}
             if name in alg:
                 row["alg_bytes_per_step"] = alg[name]
                 row["GBps"] = round(alg[name] / (per_step * 1e-3) / 1e9, 1)
@@ -781,10 +1141,12 @@ def run_pipeline(args, clips, world, rank, device, dist):
             "roofline": roof,
             "pipeline": {"ms_in_library_calls": round(in_lib, 4),
                          "ms_outside": round(ms_per_step - in_lib, 4),
-                         "note": "per C-ABI entry point, event pairs on the launch stream; ms_outside = framework "
-                                 "kernels and launch gaps between the calls (indexing, permutes, the stand-ins)",
+                         "note": "per C-ABI entry point, event pairs on the launch stream, from a separate untimed pass; "
+                                 "ms_outside = framework kernels and launch gaps between the calls (indexing, permutes, "
+                                 "the stand-ins)",
                          "entry_points": table},
         }
+        out.update(block_fields(blocks, args.steps, settle_ms))
         if graph_ms is not None:
             out["ms_per_step_graph_replay"] = graph_ms
         if emulated:

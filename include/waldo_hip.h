@@ -11,8 +11,10 @@
  *   - kernels are launched on `stream` (a hipStream_t passed as void*) of the CURRENT device;
  *   - returns 0 on success, a negative WALDO_E* code otherwise; no C++ exception crosses the ABI;
  *     waldo_last_error_string() gives the message of the last failure on the calling thread;
- *   - re-entrant: no global mutable state except the thread-local error string and the
- *     process-wide debug options below (tests only; all off unless a test switches one on).
+ *   - re-entrant: no global mutable state except the thread-local error string and ONE piece of
+ *     process-global state, the debug options of waldo_set_debug_option below (three test-only
+ *     switches between kernel variants that compute the same thing; all off unless a test
+ *     switches one on; a caller that never calls it has a stateless library).
  *
  * Build: hipcc --offload-arch=gfx950 -shared -fPIC (see waldo_amd/build.py).
  */
@@ -38,18 +40,32 @@ const char* waldo_last_error_string(void);
 int waldo_max_layers(void);
 
 /* Test-only switches between kernel variants that compute the same thing (A/B parity tests of the
- * fast paths against the plain ones).  Process-wide, off by default; nothing reads the environment. */
+ * fast paths against the plain ones).  THE ONE PIECE OF PROCESS-GLOBAL STATE of the library: process-wide,
+ * off by default, relaxed atomics; nothing reads the environment.  Kernel variants that were measured and
+ * rejected are NOT in the library (tools_dev/dropped/, buildable with tools_dev/build_variant.py). */
 #define WALDO_DEBUG_FWD_PLAIN 0   /* fused forward: gather kernel instead of the LDS-staged one */
 #define WALDO_DEBUG_IW_PASSES 1   /* grid inversion: one kernel per fill / erosion pass */
 #define WALDO_DEBUG_BWD_GENERIC 2 /* fused backward: the generic per-tap-atomics kernel for every shape
                                      (waldo_warp_composite_bwd_workspace_bytes answers 0) */
-#define WALDO_DEBUG_FWD_PIPELINED 3 /* fused forward, staged, L in {4, 8} layers: the frame loop software-pipelined
-                                       (round 5's experiment, bit-identical and 2.5 % slower: DESIGN.md) */
-#define WALDO_DEBUG_FCB_ROWS 4      /* backward of the full-resolution flow passes, 9 .. 17 layers: the lane-layer kernels
-                                       (csrc/flow_ctx_bwd_rows.hip.h: round 5's experiment, same gradients, no faster)
-                                       instead of the one-pixel-per-lane ones */
-#define WALDO_DEBUG_COUNT 5
+#define WALDO_DEBUG_COUNT 3
 int waldo_set_debug_option(int option, int value);
+
+/* Frame-index status.  The reference's gather_time (models/nets/lvd.py:462-467: `tensor.gather(1, ts)`) RAISES for
+ * a frame index outside the time axis.  The forward entry points that index frames with ctx_ts / pred_ts from
+ * device memory (waldo_time_gather_fwd, waldo_flow_ctx_warp_fwd / _raw_fwd, waldo_frame_warp_fuse_fwd / _raw_fwd)
+ * take `status`: WALDO_INDEX_STATUS_WORDS int32 words owned by the caller (zero them once), device-accessible --
+ * device memory, or pinned host memory through waldo_host_device_pointer, which the caller can read WITHOUT
+ * synchronising the device.  A kernel that meets an index outside its range clamps it (memory safety) and reports:
+ *   status[0] = the limit a ctx_ts entry violated (valid: 0 .. limit-1; never 0), status[1] = an offending value,
+ *   status[2], status[3] likewise for pred_ts.
+ * The words are STICKY (kernels only ever write non-zero limits); the caller checks and clears them when it
+ * chooses -- after a synchronisation for the reference's raise-at-once behaviour, or lazily (a captured HIP graph:
+ * after a replay).  status == NULL: out-of-range indices are clamped silently.  The backward entry points read the
+ * indices the forward saw and clamp only. */
+#define WALDO_INDEX_STATUS_WORDS 4
+/* Device pointer of a pinned (page-locked, mapped) host allocation, hipHostGetDevicePointer: WALDO_EINVAL when
+ * `host` is not such memory -- so that a status word in host memory fails at set-up, not as a fault in a kernel. */
+int waldo_host_device_pointer(void* host, void** device);
 
 /* ---------------------------------------------------------------------------------------
  * A2. Thin-plate-spline grid synthesis -- replaces TPSWarp.forward
@@ -245,10 +261,11 @@ int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const fl
 /* alpha_max (M,Hd,Wd), optional (NULL to skip): max over the layers of alpha_ctx -- what
  * Synthesizer.predict's disocclusion test takes from it (models/synthesizer.py:447, `alpha_ctx.max(dim=3)[0]`:
  * a pass over the largest tensor but one of the pipeline, here a by-product of writing it). */
+/* ctx_ts must lie in [0, Tw), pred_ts in [0, T): violations are reported in `status` ("Frame-index status" above). */
 int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                             const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                            float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B, int T,
-                            int Tw, int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
+                            float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int* status, int B,
+                            int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
 /* The same pass for a caller that runs waldo_frame_warp_fuse_raw_fwd next (LVD.forward(mode="decode_output"),
  * lvd.py:141-153, without autograd): the composited context alphas are written straight into the slots they
  * occupy in A10's `raw` tensor, raw[b, tp, tc, C + l] (lvd.py:846: `raw_output = cat(output, alpha)`), instead of
@@ -259,8 +276,8 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
  * of contexts 0 .. Tc-1 are written.  The reference's alpha_ctx (B,Tc,Tp,L,Hd,Wd) is a strided view of raw. */
 int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                 const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
-                                float* raw, float* score, float* disocc, float* alpha_max, int B, int T, int Tw,
-                                int Tc, int Tp, int L, int H, int W, int scale, int C, int Tcx,
+                                float* raw, float* score, float* disocc, float* alpha_max, int* status, int B,
+                                int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, int C, int Tcx,
                                 waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -274,11 +291,12 @@ int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, con
  *                             (B,Tc',Tp,...) tensor is the view raw.permute(0,2,1,3,4,5) (strides, no
  *                             copy), and WIF.forward's own permute + contiguous (wif.py:39) -- a copy of
  *                             the largest tensor of the pipeline -- finds it already in place
+ * ctx_ts must lie in [0, T): violations are reported in `status` ("Frame-index status" above).
  * Any Wd >= 2 and any alignment give the same bits; with Wd % 4 == 0, a 16-byte aligned `input` and Tc <= 4 the
  * contexts' footprints are staged in LDS (16-byte loads) instead of gathered tap by tap.
  * ------------------------------------------------------------------------------------- */
 int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
-                              const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
+                              const int64_t* ctx_ts, float* out, float* raw, int* status, int B, int T, int Tc,
                               int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
                               waldo_stream_t stream);
 /* A10 behind waldo_flow_ctx_warp_raw_fwd: the alpha slots of `raw` are filled already and `score` (B,Tc,Tp,Hd,Wd)
@@ -286,8 +304,8 @@ int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float
  * warped channels of every context (and, with include_self, the whole self slot) and `out`.  Same values, bit
  * for bit, as waldo_frame_warp_fuse_fwd on the contiguous alpha tensor. */
 int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const float* score,
-                                  const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc, int Tp,
-                                  int C, int L, int Hd, int Wd, int include_self, float eps,
+                                  const int64_t* ctx_ts, float* out, float* raw, int* status, int B, int T, int Tc,
+                                  int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
                                   waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -441,12 +459,13 @@ int waldo_wif_fuse_bwd(const float* vid, const float* net, const float* out, con
  *                   x[b, pred_ts[tp]] repeated over the Tc contexts (the `[:, pred_ts].unsqueeze(1).expand`)
  *   HW > 0 (a divisor of P): out is written channel-first, (B,Tc,Tp,P/HW,2,HW) -- the
  *   permute(..., 6, 4, 5) + reshape of lvd.py:662-664; HW == 0: (B,Tc,Tp,P,2).
- * ctx_ts (B,Tc,Tp) / pred_ts (Tp) int64 on the device, clamped to [0,T).
+ * ctx_ts (B,Tc,Tp) / pred_ts (Tp) int64 on the device, valid in [0,T): clamped, and the forward reports a violation
+ * in `status` ("Frame-index status" above).
  * Backward: grad_x (B,T,P,2) is OVERWRITTEN with the sum over the output frames that read each input
  * frame (a gather: deterministic, no atomics, no zero fill needed).
  * ------------------------------------------------------------------------------------- */
 int waldo_time_gather_fwd(const float* x, const int64_t* ctx_ts, const int64_t* pred_ts, float* out,
-                          int B, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
+                          int* status, int B, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
                           waldo_stream_t stream);
 int waldo_time_gather_bwd(const float* grad_out, const int64_t* ctx_ts, const int64_t* pred_ts,
                           float* grad_x, int B, int T, int Tc, int Tp, int64_t P, int64_t HW,

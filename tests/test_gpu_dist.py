@@ -196,3 +196,62 @@ def test_bench_strong_scaling_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert abs(out["value"] - 14 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]  # the job's 14 frames, once
+
+
+def test_default_multi_gpu_line_carries_the_north_star_block():
+    """`bench.py --gpus 2` with NO other workload flag -- the one multi-GPU command the driver's scaling run issues (here
+    with `--dist-backend gloo`: the two ranks share this box's GPU) -- prints ONE line: the C3 headline loop (no data-path
+    collective) and, behind it, the `north_star` object: the all-gather of composited frames at C4 and C5 (bytes, the
+    collective alone, exposed time with the overlap off and on), the C5 pipeline as one job split over the ranks
+    (ms_per_step, per-rank compute, speed-up over rank 0 running the whole job) and the cross-rank bit-equality check.
+    Reference: tools/engine.py:31-35,63-64,86-92; SURVEY.md section 8(e)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3",
+           "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["metric"] == "warped+composited frames/sec at 256x512, 8 layers; fwd+bwd" and out["n_gpus"] == 2
+    assert out["steps"] == 3 and out["warmup"] == 1 and len(out["ms_per_step_blocks"]) == 5 and out["settle_ms"] >= 300
+    ns = out["north_star"]
+    assert ns["rccl_ranks"] == 2 and ns["backend"] == "gloo"
+    for key in ("all_gather_C4", "all_gather_C5"):
+        g = ns[key]
+        assert isinstance(g, dict), g
+        assert g["bytes_received_per_rank"] == g["bytes_sent_per_rank"] > 0
+        assert g["all_gather_alone_ms"] > 0 and g["step_ms_overlap_off"] > 0 and g["step_ms_overlap_on"] > 0
+    st = ns["strong_split"]
+    assert isinstance(st, dict), st
+    assert len(st["per_rank_compute_ms"]) == 2 and st["ms_per_step"] > 0 and st["whole_job_on_rank0_ms"] > 0
+    assert st["speedup_over_one_gpu"] > 0
+    assert ns["gather_bit_equal"] is True, ns["gather_bit_equal"]
+    assert "headline before the north_star block" in r.stderr
+
+
+def test_bench_wif_line():
+    """`bench.py --config WIF`: the reference's WIF training step (Synthesizer.inpaint's call order at the
+    train_wif.sh recipe) as one JSON line with the per-entry-point table -- the unrestricted flow passes, the frame
+    warp and BOTH directions of the fusion kernel in it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "WIF", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["grads_finite"] is True and out["value"] > 0 and out["config"]["layers"] == 17
+    table = out["pipeline"]["entry_points"]
+    for name in ("waldo_flow_ctx_alpha_fwd", "waldo_flow_ctx_warp_raw_fwd", "waldo_frame_warp_fuse_raw_fwd",
+                 "waldo_wif_fuse_fwd", "waldo_wif_fuse_bwd", "waldo_inverse_warp_fwd"):
+        assert name in table, sorted(table)
+    assert table["waldo_wif_fuse_bwd"]["frac"] > 0 and out["roofline"]["frac"] > 0

@@ -595,38 +595,6 @@ def test_staged_forward_equals_plain_forward(dev, nl):
     assert torch.equal(staged[0], plain[0]) and torch.equal(staged[1], plain[1])
 
 
-@pytest.mark.parametrize("nl,f,h,w,sigma", [(8, 19, 64, 128, 0.05), (4, 9, 48, 72, 0.05), (8, 3, 256, 512, 0.05),
-                                           (8, 5, 40, 64, 0.6)])
-def test_pipelined_forward_same_bits(dev, nl, f, h, w, sigma):
-    """Round 5's experiment, kept behind WALDO_DEBUG_FWD_PIPELINED (it measured 2.5 % slower): the staged forward with
-    its frame loop software-pipelined (warp_composite_fwd_pipe.hip.h: the next frame's grid, boxes and first loads
-    ahead of this frame's composite) against the product's frame-by-frame kernel, bit for bit: with the mapping from memory (the training forward) and folded into the
-    kernel (the one-launch inference forward), odd frame counts (chunks of different lengths), a raster that is not a
-    multiple of the tile, and control points far enough out (sigma 0.6) that boxes overflow the LDS image and the
-    border path runs."""
-    from waldo_amd import _lib, functional as WF
-    import waldo_amd
-    layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, seed=nl + f, sigma=sigma)
-    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
-    lib = _lib.load()
-    res = {}
-    for serial in (0, 1):
-        assert lib.waldo_set_debug_option(_lib.DEBUG_FWD_PIPELINED, 1 - serial) == 0
-        try:
-            with torch.no_grad():  # one launch from the control points
-                folded = WF.warp_composite(layers.to(dev), pts.to(dev), occ.to(dev), tps.inverse_kernel, tps.basis_t,
-                                           return_alpha=True)
-            pd = pts.to(dev).requires_grad_()  # mapping kernel + forward
-            plain = WF.warp_composite(layers.to(dev), pd, occ.to(dev), tps.inverse_kernel, tps.basis_t,
-                                      return_alpha=True)
-            res[serial] = (folded[0], folded[1], plain[0].detach(), plain[1].detach())
-        finally:
-            lib.waldo_set_debug_option(_lib.DEBUG_FWD_PIPELINED, 0)
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
-    assert torch.equal(res[0][0], res[0][2])  # (folded mapping == mapping kernel, as before)
-
-
 @pytest.mark.parametrize("where", ["grad_rgb", "layers"])
 def test_non_finite_gradients_stay_visible(dev, where):
     """A NaN in the incoming gradient or in a layer must reach grad_layers on BOTH backward paths

@@ -476,14 +476,15 @@ def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
         assert (a01 == 0).float().mean().item() > 0.5
 
 
-@pytest.mark.parametrize("nl,s,rows", [(5, 2, False), (12, 1, False), (17, 1, False), (17, 1, True)])
-def test_flow_ctx_alpha_backward_takes_both_output_gradients(dev, nl, s, rows):
+@pytest.mark.parametrize("nl,s,ncls", [(5, 2, 20), (12, 1, 20), (17, 1, 20), (17, 1, 21), (8, 2, 32)])
+def test_flow_ctx_alpha_backward_takes_both_output_gradients(dev, nl, s, ncls):
     """waldo_flow_ctx_alpha_bwd reads d loss / d a01 and d loss / d alpha_out (= 2 a01 - 1) and sums them itself:
     a loss on both outputs gives the gradients of the same loss on `a01` alone with the two gradients added first
     (g_a01 + 2 g_alpha_out, what the wrapper used to do in two passes) -- grad_alpha_lr bit for bit (it is written,
-    not accumulated), grad_dist / grad_occ up to the order of their float atomics; and each output alone."""
-    from waldo_amd import _lib, functional as WF
-    b, t, tw, ncls, h, w = 2, 3, 2, 20, 16, 32
+    not accumulated), grad_dist / grad_occ up to the order of their float atomics; and each output alone.  Class
+    counts of 20 (the kFewCls instances) and 21 / 32 (the kMaxCls instances, wave_transpose_reduce<32> included)."""
+    from waldo_amd import functional as WF
+    b, t, tw, h, w = 2, 3, 2, 16, 32
     hd, wd = h * s, w * s
     g = torch.Generator(device=dev).manual_seed(35 + nl)
     alpha_lr = torch.rand(b * tw, nl, h, w, generator=g, device=dev)
@@ -499,20 +500,14 @@ def test_flow_ctx_alpha_backward_takes_both_output_gradients(dev, nl, s, rows):
         loss(a01, alpha).backward()
         return [x.grad for x in leaves]
 
-    if rows:
-        assert _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 1) == 0
-    try:
-        for name, two, one in (
-                ("both", lambda a01, alpha: (a01 * w1).sum() + (alpha * w2).sum(), lambda a01, alpha: (a01 * (w1 + 2.0 * w2)).sum()),
-                ("alpha_out alone", lambda a01, alpha: (alpha * w2).sum(), lambda a01, alpha: (a01 * (2.0 * w2)).sum()),
-                ("a01 alone", lambda a01, alpha: (a01 * w1).sum(), lambda a01, alpha: (a01 * w1).sum() + 0.0 * alpha.sum())):
-            got, want = grads(two), grads(one)
-            assert torch.equal(got[0], want[0]), f"{name}: grad_alpha_lr"
-            close(got[1], want[1], 1e-5, rel=True, what=f"{name}: grad_dist (float atomics)")
-            close(got[2], want[2], 1e-5, rel=True, what=f"{name}: grad_occ (float atomics)")
-    finally:
-        if rows:
-            _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 0)
+    for name, two, one in (
+            ("both", lambda a01, alpha: (a01 * w1).sum() + (alpha * w2).sum(), lambda a01, alpha: (a01 * (w1 + 2.0 * w2)).sum()),
+            ("alpha_out alone", lambda a01, alpha: (alpha * w2).sum(), lambda a01, alpha: (a01 * (2.0 * w2)).sum()),
+            ("a01 alone", lambda a01, alpha: (a01 * w1).sum(), lambda a01, alpha: (a01 * w1).sum() + 0.0 * alpha.sum())):
+        got, want = grads(two), grads(one)
+        assert torch.equal(got[0], want[0]), f"{name}: grad_alpha_lr"
+        close(got[1], want[1], 1e-5, rel=True, what=f"{name}: grad_dist (float atomics)")
+        close(got[2], want[2], 1e-5, rel=True, what=f"{name}: grad_occ (float atomics)")
 
 
 @pytest.mark.parametrize("over,ctx_only,include_self", [
@@ -521,8 +516,8 @@ def test_flow_ctx_alpha_backward_takes_both_output_gradients(dev, nl, s, rows):
     (dict(num_obj=5, dim=16, load_dim=48, allow_ghost=True), True, False),   # x3
     (dict(num_obj=3, dim=16, load_dim=32, no_filter=True), False, False),    # no layout filter
     (dict(num_obj=4, dim=16, load_dim=16, weight_cls=True, min_cls=0.05), False, True),
-    # 9 .. 17 layers: the lane-layer kernels (csrc/flow_ctx_bwd_rows.hip.h) -- padding lanes (L = 11), the layout filter
-    # with weighted classes, x2 and x1, ghost mask on and off
+    # 9 .. 17 layers (the <12> / <17> instances; L = 11 pads): the layout filter with weighted classes, x2 and x1, ghost
+    # mask on and off
     (dict(num_obj=10, dim=16, load_dim=32, use_lyt_filtering=True, weight_cls=True, min_cls=0.05), True, False),
     (dict(num_obj=16, obj_shape=[2, 2], dim=16, load_dim=0, use_lyt_filtering=True, use_lyt_opacity=True), False, True),
     (dict(num_obj=8, dim=16, load_dim=16, no_filter=True), False, False),
@@ -592,24 +587,6 @@ def _hd_backward_case(dev, opt, ctx_only, include_self, b, t, nl, seed, per_op=T
         fh = wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow
         grads[fused], _ = run(fh, wp.input_to_output, dev, lh)
     wp.fuse_hd = True
-    if 9 <= cfg.num_obj + 1 <= 17:
-        # the same chain with the lane-layer kernels (WALDO_DEBUG_FCB_ROWS; csrc/flow_ctx_bwd_rows.hip.h: round 5's
-        # experiment): they form the occlusion products in butterfly order instead of layer order -- rounding apart,
-        # the same gradients, held to the oracle bound as well
-        from waldo_amd import _lib
-        assert _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 1) == 0
-        try:
-            g_px, _ = run(fh, wp.input_to_output, dev, [x.clone().to(dev).requires_grad_() for x in base])
-        finally:
-            _lib.load().waldo_set_debug_option(_lib.DEBUG_FCB_ROWS, 0)
-        for i, name in enumerate(names):
-            if g_o[i] is not None:
-                close(g_px[i], g_o[i], rel=True, what=f"lane-layer kernels vs oracle: grad {name}", exact=g_64[i])
-            if g_px[i] is not None:
-                # (grad cls sums +-g over pixels by the SIGN of dist - pr: where the two kernels' class probabilities
-                # differ in the last bit a term flips)
-                close(grads[True][i], g_px[i], tol=2e-4 if name == "cls" else 2e-5, rel=True,
-                      what=f"per-pixel vs lane-layer kernels: grad {name}")
     for i, name in enumerate(names):
         if g_o[i] is None:
             assert grads[True][i] is None or grads[True][i].abs().max() == 0, name
@@ -621,37 +598,43 @@ def _hd_backward_case(dev, opt, ctx_only, include_self, b, t, nl, seed, per_op=T
             close(grads[False][i], g_o[i], rel=True, what=f"per-op vs oracle: grad {name}", exact=g_64[i])
 
 
-def test_fused_hd_passes_at_recipe_size(dev):
-    """The reference's real Cityscapes recipe R (scripts/cityscapes/train_wif.sh:12-14,28): L = 17
-    layers, Nl = 20 classes, 128x256 -> 512x1024, B = 1, Tc = 4, Tp = 1 -- the fused passes of
-    grid_to_flow_ctx and input_to_output at full size against the CPU oracle (which materialises
-    the reference's multi-GB broadcasts; ~1 min on the host)."""
+def _recipe_size_case(dev, ctx_only):
+    """The reference's real Cityscapes recipe R (scripts/cityscapes/train_wif.sh:12-14,28): L = 17 layers, Nl = 20
+    classes, 128x256 -> 512x1024, B = 1, Tc = 4, Tp = 1 -- the fused passes of grid_to_flow_ctx (``ctx_only``:
+    --s_restrict_to_ctx, what demo.sh / test.sh pass: alphas composited on the Tc context frames, ghost mask) or of the
+    UNRESTRICTED grid_to_flow (what train_wif.sh runs: alphas composited on all T frames, no ghost mask), and
+    input_to_output, at full size against the CPU oracle in fp32 and fp64 (which materialises the reference's multi-GB
+    broadcasts; ~1-2 min on the host)."""
     from waldo_amd.nets import Warper
     opt = opt_ns(num_obj=16, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=512,
                  aspect_ratio=2, use_lyt_filtering=True)
     cfg = WO.WarperCfg.from_opt(opt)
     wp = Warper(opt).to(dev)
     b, t, nl = 1, 5, 20
-    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=21)
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=21 if ctx_only else 22)
     ctx_ts = torch.arange(4).view(1, 4, 1)
     pred_ts = torch.tensor([4])
+    fo = WO.grid_to_flow_ctx if ctx_only else WO.grid_to_flow
+    tag = "R size, restricted" if ctx_only else "R size, UNRESTRICTED"
     with torch.no_grad():
         grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
-        ro = WO.grid_to_flow_ctx(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
+        ro = fo(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
         out_o, raw_o = WO.input_to_output(cfg, inp, ro[3], ro[0], ctx_ts)
         # float64 evaluation of the same two steps on the same fp32 inputs (the second on the fp32 flow /
         # alphas, like out_o): the measured allowance of close()
-        r64 = WO.grid_to_flow_ctx(cfg, *dbl((inp, grid_o, occ, obj_alpha, bg_alpha, cls)), ctx_ts, pred_ts)
+        r64 = fo(cfg, *dbl((inp, grid_o, occ, obj_alpha, bg_alpha, cls)), ctx_ts, pred_ts)
         out64, raw64 = WO.input_to_output(cfg, inp.double(), ro[3].double(), ro[0].double(), ctx_ts)
         args = (inp.to(dev), [x.to(dev) for x in grid_o], occ.to(dev), obj_alpha.to(dev), bg_alpha.to(dev),
                 cls.to(dev), ctx_ts.to(dev), pred_ts.to(dev))
         assert wp.fuse_hd and wp._fused_ok(list(args[:1]), cfg.num_obj + 1, nl)
-        rf = wp.grid_to_flow_ctx(*args)
+        rf = (wp.grid_to_flow_ctx if ctx_only else wp.grid_to_flow)(*args)
         # the frame warp on the ORACLE's flow / alpha: fed its own flow, a 1e-4 difference in grid units
         # is 0.05 px at 1024 columns and moves a frame value by up to ~1e-2 -- that would measure
         # the flow's tolerance a second time, not this kernel
         out_f, raw_f = wp.input_to_output(args[0], ro[3].to(dev), ro[0].to(dev), args[6])
+    wp.check_time_indices()
     assert rf[0].shape == (1, 4, 1, 2, 512, 1024) and rf[3].shape == (1, 4, 1, 17, 512, 1024)
+    assert rf[2].shape == (1, 4 if ctx_only else 5, 17, 512, 1024)  # `alpha`: on the context frames / on all T frames
     for x, y, z, name in zip(rf, ro, r64, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
         if y is None:
             assert x is None, name
@@ -659,9 +642,22 @@ def test_fused_hd_passes_at_recipe_size(dev):
         # alpha_ctx / disocc sample the composited HD alpha at flow-displaced positions: at 1024 px a
         # position is good to ~1e-5 grid units in fp32 on either side, which a steep alpha edge turns
         # into ~1e-4 of value -- in the fp32 oracle too, which is what `exact` measures
-        close(x, y, what="R size, fused vs oracle: " + name, exact=z)
-    close(out_f, out_o, what="R size: output", exact=out64)
-    close(raw_f, raw_o, what="R size: raw_output", exact=raw64)
+        close(x, y, what=f"{tag}, fused vs oracle: " + name, exact=z)
+    close(out_f, out_o, what=f"{tag}: output", exact=out64)
+    close(raw_f, raw_o, what=f"{tag}: raw_output", exact=raw64)
+
+
+def test_fused_hd_passes_at_recipe_size(dev):
+    """grid_to_flow_ctx (the RESTRICTED path of demo.sh / test.sh, lvd.py:707-828) + input_to_output at the recipe's
+    full size.  (train_wif.sh itself runs the unrestricted twin: the next test.)"""
+    _recipe_size_case(dev, ctx_only=True)
+
+
+def test_fused_hd_passes_unrestricted_at_recipe_size(dev):
+    """grid_to_flow (lvd.py:602-705: the path scripts/cityscapes/train_wif.sh takes, it does not pass
+    --s_restrict_to_ctx) + input_to_output at the recipe's full size: the <17> tall-tile / four-pixels-per-thread
+    instances with the alphas composited on all T = 5 frames and no ghost mask."""
+    _recipe_size_case(dev, ctx_only=False)
 
 
 @pytest.mark.parametrize("include_self", [False, True])
@@ -772,7 +768,8 @@ def test_frame_warp_fuse_staged_boxes_same_bits(dev, tc, include_self, hw, amp_p
 def test_alpha_ctx_written_into_raw_slots(dev, include_self, shape):
     """waldo_flow_ctx_warp_raw_fwd + waldo_frame_warp_fuse_raw_fwd (the context alphas composited straight into
     raw_output's slots, one score plane per context) == waldo_flow_ctx_warp_fwd + waldo_frame_warp_fuse_fwd,
-    bit for bit, for every output; a write to the alpha view between the two calls falls back to the long way."""
+    bit for bit, for every output; frame_warp_fuse on the alpha VIEW (the long way: it reads and copies the alphas)
+    gives the same bits again, also after the caller edited the view in place."""
     from waldo_amd import functional as WF
     b, t, tc, tp, c, nl, h, w, s, tw, ghost = shape
     if include_self:
@@ -791,11 +788,10 @@ def test_alpha_ctx_written_into_raw_slots(dev, include_self, shape):
         flow, actx, dis, amax = WF.flow_ctx_warp(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True)
         out, raw = WF.frame_warp_fuse(inp, flow.view(b, tc, tp, 2, hd, wd), actx.view(b, tc, tp, nl, hd, wd), ctx_ts,
                                       include_self=include_self)
-        flow2, actx2, dis2, amax2 = WF.flow_ctx_warp_into_raw(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, c,
-                                                              include_self, layer_max=True)
+        flow2, actx2, dis2, amax2, slots = WF.flow_ctx_warp_into_raw(flow_lr, isobj, a01, ctx_ts, pred_ts, occ, tw, s, c,
+                                                                     include_self, layer_max=True)
         assert tuple(actx2.shape) == (b, tc, tp, nl, hd, wd) and not actx2.is_contiguous()
-        slots = actx2._waldo_raw
-        out2, raw2 = WF.frame_warp_fuse(inp, flow2.view(b, tc, tp, 2, hd, wd), actx2, ctx_ts, include_self=include_self)
+        out2, raw2 = WF.frame_warp_fuse_raw(inp, flow2.view(b, tc, tp, 2, hd, wd), slots, ctx_ts)
         assert raw2.data_ptr() == slots.raw.data_ptr()  # the short way: raw is the tensor the alphas went into
         for x, y, name in ((flow, flow2, "flow"), (actx.view(b, tc, tp, nl, hd, wd), actx2, "alpha_ctx"), (dis, dis2, "disocc"),
                            (amax, amax2, "alpha max"), (out, out2, "out"), (raw, raw2, "raw")):
@@ -805,14 +801,16 @@ def test_alpha_ctx_written_into_raw_slots(dev, include_self, shape):
         for l in range(1, nl):
             sc = sc + (actx.view(b, tc, tp, nl, hd, wd)[:, :, :, l] + 1) / 2
         assert torch.equal(slots.score, sc)
-        # a caller that edits the view in place gets the long way (and the edited values)
-        actx2[:, 0, 0, 0] = 0.25
+        # the strided view is an ordinary tensor: the long way on it (a caller of Warper.input_to_output with the
+        # alpha_ctx that decode_output returned), before and after an in-place edit
         out3, raw3 = WF.frame_warp_fuse(inp, flow2.view(b, tc, tp, 2, hd, wd), actx2, ctx_ts, include_self=include_self)
-        assert raw3.data_ptr() != slots.raw.data_ptr()
+        assert raw3.data_ptr() != slots.raw.data_ptr() and torch.equal(out3, out) and torch.equal(raw3, raw)
+        actx2[:, 0, 0, 0] = 0.25
+        out4, raw4 = WF.frame_warp_fuse(inp, flow2.view(b, tc, tp, 2, hd, wd), actx2, ctx_ts, include_self=include_self)
         ref = actx.view(b, tc, tp, nl, hd, wd).clone()
         ref[:, 0, 0, 0] = 0.25
-        out4, raw4 = WF.frame_warp_fuse(inp, flow.view(b, tc, tp, 2, hd, wd), ref, ctx_ts, include_self=include_self)
-        assert torch.equal(out3, out4) and torch.equal(raw3, raw4)
+        out5, raw5 = WF.frame_warp_fuse(inp, flow.view(b, tc, tp, 2, hd, wd), ref, ctx_ts, include_self=include_self)
+        assert torch.equal(out4, out5) and torch.equal(raw4, raw5)
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 3, 4, 3, 6, 5, 7), (1, 3, 1, 1, 1, 2, 2, 3), (2, 4, 5, 2, 2, 8, 16, 8)])
@@ -856,28 +854,27 @@ def test_time_gather_against_the_spelled_out_expressions(dev, shape):
 
 def test_time_gather_of_every_frame_in_order_is_the_clip_itself(dev):
     """`x[:, pred_ts]` for one context with pred_ts = 0 .. T-1 (the LVD recipe's ctx_mode "prev": every frame is
-    predicted): `time_gather` hands out a VIEW of the clip -- the same values and gradients as the kernel's copy, no
-    launch either way -- once the index is KNOWN to be the identity (one read per (tensor, version)); after an in-place
-    change of the index, for a permutation, a shorter index or two contexts it is the kernel again."""
+    predicted): for an index MADE by `WF.arange_index` -- known on the host to be the identity, no device read --
+    `time_gather` hands out a VIEW of the clip: the same values and gradients as the kernel's copy.  A plain
+    `torch.arange`, the marked index after an in-place change, a permutation, a shorter index or two contexts go
+    through the kernel."""
     from waldo_amd import functional as WF
     b, t, no, h, w = 2, 5, 3, 6, 7
     g = torch.Generator(device=dev).manual_seed(8)
     x = torch.randn(b, t, no, h, w, 2, generator=g, device=dev, requires_grad=True)
     wgt = torch.randn(b, 1, t, no, h, w, 2, generator=g, device=dev)
-    pred = torch.arange(t, device=dev)
+    pred = WF.arange_index(t, dev)
+    assert pred.dtype == torch.int64 and WF.normalise_time_index(pred) is pred
     out = WF.time_gather(x, None, pred, num_ctx=1)
     assert out.shape == (b, 1, t, no, h, w, 2) and out.data_ptr() == x.data_ptr()
     (out * wgt).sum().backward()
     g_view = x.grad.clone()
     x.grad = None
     perm = torch.tensor([1, 0, 2, 3, 4], device=dev)
-    for idx, nctx in ((perm, 1), (pred[:3], 1), (pred, 2)):
+    for idx, nctx in ((perm, 1), (pred[:3], 1), (pred, 2), (torch.arange(t, device=dev), 1), (pred + 0, 1)):
         o = WF.time_gather(x, None, idx, num_ctx=nctx)
         assert o.data_ptr() != x.data_ptr()
         assert torch.equal(o, x[:, idx].unsqueeze(1).expand(-1, nctx, *([-1] * 5)))
-    pred2 = pred.clone()
-    copy = WF.time_gather(x, None, pred2.flip(0).flip(0).contiguous() + 0, num_ctx=1)  # equal values, another tensor: read once
-    assert torch.equal(copy, out)
     pred.mul_(0)                                                   # the same tensor object, a new version: frame 0 five times
     rep = WF.time_gather(x, None, pred, num_ctx=1)
     assert rep.data_ptr() != x.data_ptr() and torch.equal(rep, x[:, :1].expand(-1, t, -1, -1, -1, -1).unsqueeze(1))
@@ -908,8 +905,9 @@ def test_downscale_frames_matches_interpolate(dev, shape):
 
 
 def test_time_indices_outside_the_window_are_refused(dev):
-    """gather_time (lvd.py:462-467) raises for an index outside the time axis; the fused kernels index
-    with ctx_ts / pred_ts directly, so the wrappers validate them instead of clamping silently."""
+    """gather_time (lvd.py:462-467) fails for an index outside the time axis; the fused kernels index with
+    ctx_ts / pred_ts directly: they clamp (memory safety) and REPORT in the caller's status words
+    (include/waldo_hip.h: "Frame-index status").  A stand-alone call (no status given) checks before it returns."""
     from waldo_amd import _lib, functional as WF
     b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 1, 4, 3, 8, 16
     inp = torch.randn(b, t, c, hd, wd, device=dev)
@@ -917,24 +915,80 @@ def test_time_indices_outside_the_window_are_refused(dev):
     alpha = torch.zeros(b, tc, tp, nl, hd, wd, device=dev)
     ok = torch.tensor([[[0], [2]]], device=dev)
     WF.frame_warp_fuse(inp, flow, alpha, ok)
-    for bad in (torch.tensor([[[0], [3]]], device=dev), torch.tensor([[[-1], [1]]], device=dev)):
-        with pytest.raises(_lib.WaldoHipError, match="valid range"):
+    for bad, shown in ((torch.tensor([[[0], [3]]], device=dev), "index 3"), (torch.tensor([[[-1], [1]]], device=dev), "index -1")):
+        with pytest.raises(_lib.WaldoHipError, match=rf"ctx_ts holds the {shown}, valid range is \[0, 2\]"):
             WF.frame_warp_fuse(inp, flow, alpha, bad)
+    WF.frame_warp_fuse(inp, flow, alpha, ok)  # (the words were cleared by the raise)
     flow_lr = torch.zeros(b * tc * tp, nl, 2, hd, wd, device=dev)
     a01 = torch.rand(b * 2, nl, hd, wd, device=dev)  # window of tw = 2 frames
     occ = torch.zeros(b, t, nl, nl, device=dev)
     pred = torch.tensor([2], device=dev)
     WF.flow_ctx_warp(flow_lr, None, a01, torch.tensor([[[0], [1]]], device=dev), pred, occ, 2, 1)
-    with pytest.raises(_lib.WaldoHipError, match="valid range"):  # inside T, outside the context window
+    with pytest.raises(_lib.WaldoHipError, match=r"ctx_ts holds the index 2, valid range is \[0, 1\]"):  # inside T, outside the window
         WF.flow_ctx_warp(flow_lr, None, a01, ok, pred, occ, 2, 1)
-    with pytest.raises(_lib.WaldoHipError, match="valid range"):
+    with pytest.raises(_lib.WaldoHipError, match=r"pred_ts holds the index 3, valid range is \[0, 2\]"):
         WF.flow_ctx_warp(flow_lr, None, a01, torch.tensor([[[0], [1]]], device=dev), torch.tensor([3], device=dev), occ, 2, 1)
+    with pytest.raises(_lib.WaldoHipError, match="valid range"):
+        WF.flow_ctx_warp_into_raw(flow_lr, None, a01, ok, pred, occ, 2, 1, c, False)
+    # a caller with status words of its own decides when to look: nothing raises at the call ...
+    st = _lib.IndexStatus()
+    out_bad, _ = WF.frame_warp_fuse(inp, flow, alpha, torch.tensor([[[0], [7]]], device=dev), status=st)
+    out_clamped, _ = WF.frame_warp_fuse(inp, flow, alpha, torch.tensor([[[0], [2]]], device=dev), status=st)
+    assert torch.equal(out_bad, out_clamped)  # (memory-safe: the frame was clamped)
+    with pytest.raises(_lib.WaldoHipError, match=r"ctx_ts holds the index 7"):
+        st.check(sync=True)
+    st.check(sync=True)  # sticky until read, then clear
+
+
+def test_time_indices_are_checked_in_a_captured_step(dev):
+    """The same validation when the step is a HIP graph: the check is IN the kernels, so a bad index copied into
+    the graph's static index tensor is reported by the replay that meets it (the host-side check of rounds 3-5
+    could not run during capture and the kernels clamped silently)."""
+    from waldo_amd import _lib
+    from waldo_amd.graphs import GraphedCall
+    from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
+    opt = opt_ns()
+    cfg = WO.WarperCfg.from_opt(opt)
+    wp = Warper(opt).to(dev)
+    b, t, nl = 2, 3, 5
+    obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=8)
+    occ_score = torch.randn(b, t, cfg.num_obj, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        occ_d, oa, ba, grid = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev), obj_pose.to(dev),
+                                                      bg_pose.to(dev), occ_score.to(dev))
+    grid = [x.contiguous() for x in grid]
+    ctx_ts = torch.arange(2, device=dev).view(1, 2, 1).expand(b, 2, 1).contiguous()
+    pred_ts = torch.tensor([2], device=dev)
+    inp_d, cls_d = inp.to(dev), cls.to(dev)
+
+    def step(ctx, pred):
+        return decode_output(wp, inp_d, grid, occ_d, oa, ba, cls_d, ctx, pred)[0]
+
+    with torch.no_grad():
+        eager = step(ctx_ts, pred_ts).clone()
+    graphed = GraphedCall(step, ctx_ts, pred_ts)
+    assert torch.equal(graphed(ctx_ts, pred_ts), eager)
+    graphed.check()
+    # (a replay looks at the words without waiting: the report comes from the call or, at the latest, from check())
+    with pytest.raises(_lib.WaldoHipError, match=r"pred_ts holds the index 5, valid range is \[0, 2\]"):
+        graphed(ctx_ts, torch.tensor([5], device=dev))  # (copied into the graph's static pred_ts)
+        graphed.check()
+    bad_ctx = ctx_ts.clone()
+    bad_ctx[1, 0, 0] = 2  # inside T, outside the context window of restrict_to_ctx
+    with pytest.raises(_lib.WaldoHipError, match=r"ctx_ts holds the index 2, valid range is \[0, 1\]"):
+        graphed(bad_ctx, pred_ts)
+        graphed.check()
+    assert torch.equal(graphed(ctx_ts, pred_ts), eager)
+    graphed.check()
+    # eagerly through the module: reported at the latest by check_time_indices()
+    with pytest.raises(_lib.WaldoHipError, match=r"pred_ts holds the index 4"), torch.no_grad():
+        step(ctx_ts, torch.tensor([4], device=dev))
+        wp.check_time_indices()
 
 
 def test_index_validation_under_inference_mode(dev):
-    """Tensors made under torch.inference_mode() have no version counter (reading ``_version`` raises): the
-    index validation must work there -- every call re-reads a caller's inference tensor, Warper's own
-    normalised copy is read once -- and still refuse bad indices.  The whole decode runs under it."""
+    """Tensors made under torch.inference_mode() have no version counter: the device-side validation does not care --
+    an in-place change of the caller's index tensor is seen by the next launch -- and the whole decode runs under it."""
     from waldo_amd import _lib, functional as WF
     from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
     b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 1, 4, 3, 8, 16
@@ -948,9 +1002,10 @@ def test_index_validation_under_inference_mode(dev):
         ok.fill_(t)  # written in place, unseen by any version counter: the next call must notice
         with pytest.raises(_lib.WaldoHipError, match="valid range"):
             WF.frame_warp_fuse(inp, flow, alpha, ok)
-        priv = WF.normalise_time_index(torch.arange(tc, device=dev).view(1, tc, 1).expand(b, tc, tp))
-        assert priv.is_contiguous() and priv.dtype == torch.int64
-        WF.frame_warp_fuse(inp, flow, alpha, priv)
+        idx = WF.normalise_time_index(torch.arange(tc, device=dev).view(1, tc, 1).expand(b, tc, tp))
+        assert idx.is_contiguous() and idx.dtype == torch.int64
+        WF.frame_warp_fuse(inp, flow, alpha, idx)
+        assert WF.time_gather(inp.new_zeros(b, t, 2, 2), None, WF.arange_index(t, dev), num_ctx=1).shape == (b, 1, t, 2, 2)
     # the chain of test_decode_output_glue under inference mode == under no_grad, bit for bit
     opt = opt_ns()
     cfg = WO.WarperCfg.from_opt(opt)
@@ -966,6 +1021,7 @@ def test_index_validation_under_inference_mode(dev):
             occ_d, oa, ba, grid = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev), obj_pose.to(dev),
                                                           bg_pose.to(dev), occ_score.to(dev))
             outs.append(decode_output(wp, inp.to(dev), grid, occ_d, oa, ba, cls.to(dev), ctx_ts, pred_ts))
+    wp.check_time_indices()
     for x, y in zip(*outs):
         assert (x is None and y is None) or torch.equal(x, y)
 
@@ -1039,6 +1095,32 @@ def test_wif_forward_golden(dev, golden):
         lin.bias.copy_(g["bias"])
     wif = WIF(types.SimpleNamespace(ii_score=True, ii_ab=True), unet=lin).to(dev)
     close(wif(g["vid"].to(dev)), g["out"], what="wif")
+
+
+def test_wif_fuse_at_recipe_size(dev):
+    """waldo_wif_fuse_fwd / _bwd at the shape they exist for (wif.py:37-57 at train_wif.sh's sizes): 40-channel
+    raw_output (3 + 20 + 17) of 512 x 1024 frames, Tc = 4 contexts, one predicted frame of two clips, the UNet's 5
+    outputs (ii_score + ii_ab) -- forward, grad_vid and grad_net against the oracle's autograd."""
+    from waldo_amd import functional as WF
+    b, t, tc, c, h, w, co = 2, 1, 4, 40, 512, 1024, 5
+    g = torch.Generator().manual_seed(40)
+    vid = (torch.rand(b, t, tc, c, h, w, generator=g) * 2 - 1).requires_grad_()
+    vid.data[:, :, :, 4] = 5.0 * torch.randn(b, t, tc, h, w, generator=g)   # the layout logit the gate reads (wif.py:53)
+    net = torch.randn(b, t, tc, co, h, w, generator=g).requires_grad_()
+    ref = WO.wif_fuse(vid, net, ab=True)
+    wgt = torch.randn(ref.shape, generator=g)
+    (ref * wgt).sum().backward()
+    v2, n2 = vid.detach().to(dev).requires_grad_(), net.detach().to(dev).requires_grad_()
+    out = WF.wif_fuse(v2, n2, ab=True)
+    assert out.shape == (b, t, 3, h, w)
+    close(out, ref, what="R size: out")
+    (out * wgt.to(dev)).sum().backward()
+    close(v2.grad, vid.grad, rel=True, what="R size: grad_vid")
+    close(n2.grad, net.grad, rel=True, what="R size: grad_net")
+    # the training step's form: raw_output carries no gradient (it was made under no_grad) -- grad_net alone, same bits
+    n3 = net.detach().to(dev).requires_grad_()
+    (WF.wif_fuse(vid.detach().to(dev), n3, ab=True) * wgt.to(dev)).sum().backward()
+    assert torch.equal(n3.grad, n2.grad)
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 5, 3, 5, 4), (2, 3, 4, 40, 16, 32, 5), (1, 2, 5, 8, 33, 65, 4)])

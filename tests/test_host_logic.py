@@ -2,60 +2,48 @@
 import torch
 
 
-def test_private_index_copy_is_made_once_under_inference_mode():
-    """under torch.inference_mode() an index tensor has no version counter, so the wrappers work on a
-    private copy -- ONE copy per decode: normalising the copy again (decode_output, _flow_common and input_to_output
-    each do) hands the same object back instead of cloning and reading it back again."""
+def test_time_index_normalisation_makes_no_copy_of_a_ready_index():
+    """`normalise_time_index`: int64 + contiguous, the tensor itself when it already is (no clone, no read-back --
+    the kernels validate the indices on the device, `_lib.IndexStatus`), with or without a version counter."""
     from waldo_amd import functional as WF
-    with torch.inference_mode():
-        ts = torch.arange(6).view(1, 2, 3)
-        first = WF.normalise_time_index(ts)
-        assert first is not ts and torch.equal(first, ts)
-        again = WF.normalise_time_index(first)
-        assert again is first
-        assert WF.normalise_time_index(again) is first
-    # with a version counter nothing is copied at all
     ts2 = torch.arange(4).view(1, 1, 4)
     assert WF.normalise_time_index(ts2) is ts2
-
-
-def test_raw_slots_short_way_needs_a_version_counter_or_a_vouching_caller():
-    """RawSlots.still_describes cannot see a write to an inference tensor (no version counter): such a view
-    takes the short way through frame_warp_fuse only when the caller that kept it in its hands vouches for it."""
-    from waldo_amd.functional import RawSlots
-    raw = torch.zeros(1, 2, 3, 5, 4, 4)
-    view = raw[:, :, :3, 2:].permute(0, 2, 1, 3, 4, 5)
-    slots = RawSlots(raw, torch.zeros(1, 3, 2, 4, 4), 2, False, view)
-    assert slots.still_describes(view)
-    view.add_(1.0)  # a write bumps the version: the score sums would be stale
-    assert not slots.still_describes(view)
+    exp = torch.arange(2).view(1, 2, 1).expand(3, 2, 4)   # the expanded view of synthesizer.py:438
+    n = WF.normalise_time_index(exp)
+    assert n.is_contiguous() and n.dtype == torch.int64 and torch.equal(n, exp)
+    assert WF.normalise_time_index(torch.arange(3, dtype=torch.int32)).dtype == torch.int64
     with torch.inference_mode():
-        raw_i = torch.zeros(1, 2, 3, 5, 4, 4)
-        view_i = raw_i[:, :, :3, 2:].permute(0, 2, 1, 3, 4, 5)
-        slots_i = RawSlots(raw_i, torch.zeros(1, 3, 2, 4, 4), 2, False, view_i)
-        assert not slots_i.still_describes(view_i)  # nobody vouches: the copying kernel
-        slots_i.vouched = True
-        assert slots_i.still_describes(view_i)
-        assert not slots_i.still_describes(view_i[:, 1:])  # another view
+        ts = torch.arange(6).view(1, 2, 3)
+        assert WF.normalise_time_index(ts) is ts
 
 
-def test_index_bookkeeping_knows_an_identity_index_and_forgets_it_after_a_write():
-    """`time_gather` hands out the clip itself for `x[:, ts]` with ts = 0 .. n-1 (LVD ctx_mode "prev"): the wrappers
-    learn that from ONE read per (tensor, version) -- `_index_info` -- and `_known_arange` only ever answers from that
-    read (it is asked during HIP-graph capture, where nothing may be read back)."""
+def test_an_index_made_by_arange_index_is_known_to_be_the_identity_until_written_to():
+    """`time_gather` hands out the clip itself for `x[:, ts]` with ts = 0 .. n-1 (LVD ctx_mode "prev") only for an
+    index the CALLER built with `arange_index` (a host-side fact: no device read, also during HIP-graph capture);
+    the mark is tied to the tensor object and its version counter."""
+    import copy
     from waldo_amd import functional as WF
-    ts = torch.arange(5)
-    assert not WF._known_arange(ts)                      # never read: not known
-    assert WF._index_info(ts) == (0, 4, True) and WF._known_arange(ts)
-    assert WF._index_range(ts) == (0, 4)
-    ts[0] = 3                                            # a write bumps the version: read again, no longer the identity
-    assert not WF._known_arange(ts)
-    assert WF._index_info(ts) == (1, 4, False) and not WF._known_arange(ts)
-    assert WF._index_info(torch.arange(2, 6)) == (2, 5, False)            # a run that does not start at 0
-    assert WF._index_info(torch.arange(6).view(1, 2, 3)) == (0, 5, False)  # only 1-D indices select whole frames
-    with torch.inference_mode():
-        ti = WF.normalise_time_index(torch.arange(4))    # private copy, read once
-        assert WF._known_arange(ti) and WF._index_info(ti) == (0, 3, True)
+    ts = WF.arange_index(5)
+    assert ts.dtype == torch.int64 and ts.tolist() == [0, 1, 2, 3, 4]
+    assert WF._is_arange_index(ts) and WF.normalise_time_index(ts) is ts
+    assert not WF._is_arange_index(torch.arange(5))           # a plain tensor: never
+    assert not WF._is_arange_index(ts[:3]) and not WF._is_arange_index(ts + 0) and not WF._is_arange_index(ts.clone())
+    assert WF._is_arange_index(copy.deepcopy(ts))
+    ts[0] = 3                                                 # a write bumps the version
+    assert not WF._is_arange_index(ts) and not WF._is_arange_index(copy.deepcopy(ts))
+    with torch.inference_mode():                              # no version counter to vouch for it: a plain index
+        assert not WF._is_arange_index(WF.arange_index(4))
+
+
+def test_raw_slots_are_handed_over_explicitly():
+    """`flow_ctx_warp_into_raw` returns its `RawSlots` beside the alpha view and `frame_warp_fuse_raw` takes them as
+    an argument: nothing rides on a tensor attribute, `frame_warp_fuse` never inspects its alpha argument."""
+    import inspect
+    from waldo_amd import functional as WF
+    assert list(inspect.signature(WF.frame_warp_fuse_raw).parameters)[:4] == ["input", "flow", "slots", "ctx_ts"]
+    slots = WF.RawSlots(torch.zeros(1, 2, 3, 5, 4, 4), torch.zeros(1, 3, 2, 4, 4), 2, False)
+    assert slots.channels == 2 and not slots.include_self
+    assert "_waldo_raw" not in inspect.getsource(WF)
 
 
 def test_zero_filled_gradients_come_out_of_one_buffer():
@@ -63,7 +51,11 @@ def test_zero_filled_gradients_come_out_of_one_buffer():
     launch); every view starts on a 256-byte boundary and keeps its tensor's shape; None stays None."""
     from waldo_amd.functional import _zeros_like_each
     a, b, c = torch.ones(3, 5), torch.ones(7), torch.ones(2, 2, 2)
-    za, none, zb, zc = _zeros_like_each(a, None, b, c)
+    big = torch.ones(1 << 18)                            # 1 MB: a buffer of its own (ADVICE r5: it would pin the others)
+    za, none, zb, zc, zbig = _zeros_like_each(a, None, b, c, big)
+    assert zbig.shape == big.shape and float(zbig.sum()) == 0.0
+    assert zbig.untyped_storage().data_ptr() != za.untyped_storage().data_ptr()
+    assert zbig.untyped_storage().nbytes() == big.numel() * 4
     assert none is None and za.shape == a.shape and zb.shape == b.shape and zc.shape == c.shape
     assert float(za.sum() + zb.sum() + zc.sum()) == 0.0
     base = za.untyped_storage().data_ptr()

@@ -1,7 +1,7 @@
 set -e
 mkdir -p gpurun_out/r05c
 for i in 1 2 3; do
-  for opt in "" "--debug-option 3" "--lib tools_dev/_variants/nomap.so" "--lib tools_dev/_variants/ahead3.so" "--lib tools_dev/_variants/ahead3.so --debug-option 3"; do
+  for opt in "" "--lib tools_dev/_variants/pipe.so" "--lib tools_dev/_variants/nomap.so" "--lib tools_dev/_variants/ahead3.so" "--lib tools_dev/_variants/ahead3.so --lib tools_dev/_variants/pipe.so"; do
     python bench.py --no-cpu-baseline --steps 100 $opt 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']

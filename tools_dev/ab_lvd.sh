@@ -1,6 +1,6 @@
-# dev: LVD-recipe step, product kernels against a debug option (e.g. 4 = WALDO_DEBUG_FCB_PIXEL), interleaved on one box
+# dev: LVD-recipe step, product kernels against a debug option (or a variant library: tools_dev/dropped/README.md), interleaved on one box
 set -e
-OPT=${1:---debug-option 4}
+OPT=${1:---lib tools_dev/_variants/rows.so}
 mkdir -p gpurun_out/ab_lvd
 for i in 1 2 3; do
   for opt in "" "$OPT"; do

@@ -1,5 +1,5 @@
 # dev: LVD-recipe step, the product library with / without a debug option and variant libraries, interleaved on one box
-#   bash tools_dev/ab_lvd_opts.sh "--debug-option 4" "--debug-option 4 --lib tools_dev/_variants/a.so" ...
+#   bash tools_dev/ab_lvd_opts.sh "--lib tools_dev/_variants/rows.so" "--lib tools_dev/_variants/a.so" ...
 set -e
 mkdir -p gpurun_out/ab_lvd
 for i in 1 2; do

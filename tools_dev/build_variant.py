@@ -26,7 +26,10 @@ if any(f.startswith("-DWALDO_ABL_") for f in flags):
     if only is not None and "runtime" not in only:
         only = only + ["runtime"]
 prod_obj, prod_cflags = B.OBJ, list(B.CFLAGS)
-B.CFLAGS = B.CFLAGS + flags
+# rejected kernel variants live in tools_dev/dropped/ and compile only into variant builds:
+#   -DWALDO_VARIANT_FWD_PIPE   the staged forward with its frame loop software-pipelined (round 5; takes every launch it serves)
+#   -DWALDO_VARIANT_FCB_ROWS   the lane-layer backward kernels of the full-resolution flow passes, 9 .. 17 layers (round 5)
+B.CFLAGS = B.CFLAGS + flags + ["-I" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropped")]
 B.OBJ = os.path.join("/tmp", "waldo_variants", name)  # objects stay out of the tree (gpurun ships the tree)
 B.LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_variants", name + ".so")
 os.makedirs(B.OBJ, exist_ok=True)

@@ -28,7 +28,7 @@ pts = get_grid(4, 4).view(1, 16, 2).to(dev) + 0.05 * torch.randn(F * L, 16, 2, g
 occ = torch.rand(F, L, L, generator=g, device=dev) * 0.5
 tps = waldo_amd.TPSWarp(H, W, get_grid(4, 4).view(-1, 2)).to(dev)
 lib = _lib.load()
-if len(sys.argv) > 3:  # e.g. 3 = WALDO_DEBUG_FWD_PIPELINED
+if len(sys.argv) > 3:  # a debug option of the C ABI (round 6: the pipelined forward is a variant build, tools_dev/dropped/README.md)
     assert lib.waldo_set_debug_option(int(sys.argv[3]), 1) == 0
 with torch.no_grad():
     for _ in range(5):

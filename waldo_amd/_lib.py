@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1012
+ABI_VERSION = 1013
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -50,10 +50,10 @@ SIGNATURES = {
     "waldo_pose_affine_bwd": [_c_f] * 6 + [_i64, _int, _flt, _flt, _stream],
     "waldo_disocc_test_fwd": [_c_f, _c_f, _i64, _int, _int, _i64, _stream],
     "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
-    "waldo_flow_ctx_warp_fwd": [_c_f] * 10 + [_int] * 9 + [_stream],
-    "waldo_frame_warp_fuse_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
-    "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 11 + [_int] * 11 + [_stream],
-    "waldo_frame_warp_fuse_raw_fwd": [_c_f] * 6 + [_int] * 9 + [_flt, _stream],
+    "waldo_flow_ctx_warp_fwd": [_c_f] * 11 + [_int] * 9 + [_stream],
+    "waldo_frame_warp_fuse_fwd": [_c_f] * 7 + [_int] * 9 + [_flt, _stream],
+    "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 12 + [_int] * 11 + [_stream],
+    "waldo_frame_warp_fuse_raw_fwd": [_c_f] * 7 + [_int] * 9 + [_flt, _stream],
     "waldo_flow_ctx_alpha_bwd": [_c_f] * 10 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_bwd": [_c_f] * 8 + [_int] * 9 + [_flt, _stream],
@@ -62,7 +62,7 @@ SIGNATURES = {
     "waldo_wif_fuse_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _stream],
     "waldo_wif_fuse_bwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int,
                            _stream],
-    "waldo_time_gather_fwd": [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _i64, _i64, _int, _stream],
+    "waldo_time_gather_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _i64, _i64, _int, _stream],
     "waldo_time_gather_bwd": [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _i64, _i64, _int, _stream],
     "waldo_downscale_frames_fwd": [_c_f, _c_f] + [_int] * 8 + [_stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
@@ -77,14 +77,15 @@ PLAIN = {"waldo_version": (_int, []), "waldo_max_layers": (_int, []),
          "waldo_lyt_dist_workspace_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
          "waldo_warp_composite_pts_supported": (_int, [_int, _int, _int, _int]),
          "waldo_last_error_string": (ctypes.c_char_p, []),
-         "waldo_set_debug_option": (_int, [_int, _int])}
+         "waldo_set_debug_option": (_int, [_int, _int]),
+         "waldo_host_device_pointer": (_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)])}
 
-# include/waldo_hip.h: test-only switches between kernel variants (waldo_set_debug_option)
+# include/waldo_hip.h: test-only switches between kernel variants (waldo_set_debug_option: the library's one piece of
+# process-global state)
 DEBUG_FWD_PLAIN = 0
 DEBUG_IW_PASSES = 1
 DEBUG_BWD_GENERIC = 2
-DEBUG_FWD_PIPELINED = 3
-DEBUG_FCB_ROWS = 4
+INDEX_STATUS_WORDS = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -141,6 +142,71 @@ def load():
             fn.restype = res
         _lib = lib
     return _lib
+
+
+class IndexStatus:
+    """The caller's side of include/waldo_hip.h's "Frame-index status": four sticky int32 words in PINNED HOST memory
+    that the kernels write, through the words' device address, when ``ctx_ts`` / ``pred_ts`` hold a frame index
+    outside its time axis (they clamp it for memory safety and report; the reference's ``gather_time``,
+    models/nets/lvd.py:462-467, fails with a device-side assert there).  Reading the words costs no device
+    synchronisation, so an owner (``Warper``: one per module) checks them at every call for what EARLIER launches
+    reported, and ``check(sync=True)`` gives the raise-at-once behaviour.  Replaces the host-side index bookkeeping
+    of rounds 3-5 (one device -> host read per distinct index tensor and version)."""
+
+    _live = None  # weak set of every IndexStatus of the process (check_all: after a HIP-graph replay)
+
+    def __init__(self):
+        import weakref
+        self.words = torch.zeros(INDEX_STATUS_WORDS, dtype=torch.int32).pin_memory()
+        dev = ctypes.c_void_p()
+        if load().waldo_host_device_pointer(self.words.data_ptr(), ctypes.byref(dev)) != 0:
+            msg = load().waldo_last_error_string()
+            raise WaldoHipError(f"IndexStatus: {msg.decode() if msg else '?'}")
+        self.ptr = dev.value
+        self._np = self.words.numpy()
+        if IndexStatus._live is None:
+            IndexStatus._live = weakref.WeakSet()
+        IndexStatus._live.add(self)
+
+    def __deepcopy__(self, memo):  # (a copied module gets words of its own: the device address is not copyable)
+        return IndexStatus()
+
+    def __reduce__(self):
+        return (IndexStatus, ())
+
+    def check(self, sync=False):
+        """Raise ``WaldoHipError`` if a kernel has reported an index outside its range since the last check (and clear
+        the words).  ``sync``: wait for the current stream first, so that every launch queued so far has run.  A no-op
+        while a HIP graph is being captured."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        if self._np[0] or self._np[2]:
+            lim_c, bad_c, lim_p, bad_p = (int(v) for v in self._np)
+            self._np[:] = 0
+            what = [f"{name} holds the index {bad}, valid range is [0, {lim - 1}]"
+                    for name, lim, bad in (("ctx_ts", lim_c, bad_c), ("pred_ts", lim_p, bad_p)) if lim]
+            raise WaldoHipError("frame index outside its time axis (reported by a kernel; the frame was clamped): "
+                                + "; ".join(what))
+
+    @staticmethod
+    def check_all(sync=False):
+        for st in list(IndexStatus._live or ()):
+            st.check(sync)
+            sync = False
+
+
+_default_status = None
+
+
+def default_index_status():
+    """The status words of callers that pass none: ``functional`` checks them with a synchronisation before it
+    returns (the strict mode of a stand-alone call)."""
+    global _default_status
+    if _default_status is None:
+        _default_status = IndexStatus()
+    return _default_status
 
 
 def ptr(t):

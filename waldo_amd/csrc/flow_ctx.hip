@@ -207,8 +207,8 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
     float* __restrict__ alpha_ctx, ActxLayout lay, float* __restrict__ score, float* __restrict__ disocc,
-    float* __restrict__ alpha_max, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, int units,
-    int tiles, int nbands) {
+    float* __restrict__ alpha_max, int* __restrict__ status, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+    int units, int tiles, int nbands) {
   using G = FcwLds<LP, R>;
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
@@ -221,11 +221,12 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
 #endif
   const int tp = m % Tp, b = m / (Tc * Tp);
   const float rscale = 1.0f / (float)scale;
-  // frame of the context alpha (clamped: the index comes from device memory) and of the order
+  // frame of the context alpha (clamped: the index comes from device memory; an index outside the window is reported
+  // in `status`: checked_frame) and of the order
   // (read through the vector path, the frame indices land in VGPRs and every plane address derived from
   // them becomes per-lane 64-bit arithmetic: they are wave-uniform, say so)
-  const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(Tw - 1)));
-  const int tpred = __builtin_amdgcn_readfirstlane((int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1)));
+  const int ts = __builtin_amdgcn_readfirstlane(checked_frame(ctx_ts, m, Tw, status, kStatusCtx));
+  const int tpred = __builtin_amdgcn_readfirstlane(checked_frame(pred_ts, tp, T, status, kStatusPred));
 
   __shared__ __attribute__((aligned(16))) float lrimg[G::kCap];
   // the order of the predicted frame from LDS (OccLds): at L = 12 the scalar loads made the kernel issue as
@@ -534,8 +535,8 @@ template <int TCP>
 __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
     const float* __restrict__ score, const int64_t* __restrict__ ctx_ts, float* __restrict__ out,
-    float* __restrict__ raw, int T, int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
-    int units, int tiles, int nbands) {
+    float* __restrict__ raw, int* __restrict__ status, int T, int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self,
+    float eps, int units, int tiles, int nbands) {
   const int64_t HWd = (int64_t)Hd * Wd;
   int n, x, y;  // n = (b, tp)
 #if WALDO_FWF_TP_INNER
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void frame_warp_fuse_kernel(
     w01[tc] = t.w01;
     w10[tc] = t.w10;
     w11[tc] = t.w11;
-    const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)));  // wave-uniform
+    const int ts = __builtin_amdgcn_readfirstlane(checked_frame(ctx_ts, m, T, status, kStatusCtx));  // wave-uniform
     frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
     float s = 0.0f;
     if (score != nullptr) {
@@ -718,8 +719,8 @@ template <int TCP, bool FULL>
 __global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_lds_kernel(
     const float* __restrict__ input, const float* __restrict__ flow, const float* __restrict__ alpha,
     const float* __restrict__ score, const int64_t* __restrict__ ctx_ts, float* __restrict__ out,
-    float* __restrict__ raw, int T, int Tc_, int Tp, int C, int L, int Hd, int Wd, int include_self_, float eps,
-    int units, int tiles, int nbands) {
+    float* __restrict__ raw, int* __restrict__ status, int T, int Tc_, int Tp, int C, int L, int Hd, int Wd, int include_self_,
+    float eps, int units, int tiles, int nbands) {
   typedef float f32x2_fw __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   static_assert(kBlock * 4 == kFwfCap, "one float4 of the box per thread");
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(kBlock, WALDO_FWF_LDS_WAVES) void frame_warp_fuse_l
       wbox[wave][tc][0] = __builtin_bit_cast(int, lo);
       wbox[wave][tc][1] = __builtin_bit_cast(int, hi);
     }
-    const int ts = __builtin_amdgcn_readfirstlane((int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)));  // wave-uniform
+    const int ts = __builtin_amdgcn_readfirstlane(checked_frame(ctx_ts, m, T, status, kStatusCtx));  // wave-uniform
     frame[tc] = input + ((int64_t)b * T + ts) * C * HWd;
     float sv = 0.0f;
     if (score != nullptr) {
@@ -1039,7 +1040,7 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 #define WALDO_FCW_LAUNCH(LPV, SC, RV)                                                                          \
   hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV>), dim3((unsigned)fcw_grid), dim3(kBlock), 0, st,    \
                      flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc, alpha_max, \
-                     T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
+                     status, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
 #define WALDO_FCW_CASE(LPV)                                        \
   case LPV:                                                       \
     if (rows == 1) {                                              \
@@ -1057,7 +1058,7 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const float* isobj_lr, const float* a01,
                                 const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
                                 float* alpha_ctx, ActxLayout lay, float* score, float* disocc, float* alpha_max,
-                                int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                int* status, int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
                                 waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tc * Tp;
   int rc = check_flow_ctx(fn, N, L, H, W, scale);
@@ -1107,20 +1108,21 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
 
 extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                        const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int B,
-                                       int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
+                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int* status,
+                                       int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
                                        waldo_stream_t stream) {
   const int64_t plane = (int64_t)H * scale * W * scale;
   const ActxLayout lay = {(int64_t)Tc * Tp * L * plane, (int64_t)Tp * L * plane, (int64_t)L * plane};
   return flow_ctx_warp_launch("waldo_flow_ctx_warp_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
-                              alpha_ctx, lay, nullptr, disocc, alpha_max, B, T, Tw, Tc, Tp, L, H, W, scale, stream);
+                              alpha_ctx, lay, nullptr, disocc, alpha_max, status, B, T, Tw, Tc, Tp, L, H, W, scale,
+                              stream);
 }
 
 extern "C" int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                            const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
                                            float* flow, float* raw, float* score, float* disocc,
-                                           float* alpha_max, int B, int T, int Tw, int Tc, int Tp, int L, int H,
-                                           int W, int scale, int C, int Tcx, waldo_stream_t stream) {
+                                           float* alpha_max, int* status, int B, int T, int Tw, int Tc, int Tp,
+                                           int L, int H, int W, int scale, int C, int Tcx, waldo_stream_t stream) {
   if (C < 1 || Tcx < Tc || Tcx > Tc + 1 || !raw || !score) {
     set_error("waldo_flow_ctx_warp_raw_fwd: bad raw layout C=%d Tc'=%d for Tc=%d (need C >= 1, Tc <= Tc' <= Tc + 1, "
               "raw and score)", C, Tcx, Tc);
@@ -1129,14 +1131,14 @@ extern "C" int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* is
   const int64_t plane = (int64_t)H * scale * W * scale, ctx = (int64_t)(C + L) * plane;
   const ActxLayout lay = {(int64_t)Tp * Tcx * ctx, ctx, (int64_t)Tcx * ctx};
   return flow_ctx_warp_launch("waldo_flow_ctx_warp_raw_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
-                              raw + (int64_t)C * plane, lay, score, disocc, alpha_max, B, T, Tw, Tc, Tp, L, H, W,
-                              scale, stream);
+                              raw + (int64_t)C * plane, lay, score, disocc, alpha_max, status, B, T, Tw, Tc, Tp, L,
+                              H, W, scale, stream);
 }
 
 static int frame_warp_fuse_launch(const char* fn, const float* input, const float* flow, const float* alpha,
-                                  const float* score, const int64_t* ctx_ts, float* out, float* raw, int B, int T,
-                                  int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
-                                  waldo_stream_t stream) {
+                                  const float* score, const int64_t* ctx_ts, float* out, float* raw, int* status,
+                                  int B, int T, int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self,
+                                  float eps, waldo_stream_t stream) {
   if (B < 0 || T < 1 || Tc < 1 || Tc + (include_self ? 1 : 0) > kFwMaxCtx || Tp < 1 || C < 1 || L < 1 ||
       Hd < 1 || Wd < 1 || Hd > 32767 || Wd > 32767 || (include_self && Tp != T)) {
     set_error("%s: bad shape B=%d T=%d Tc=%d Tp=%d C=%d L=%d Hd=%d Wd=%d include_self=%d "
@@ -1176,8 +1178,8 @@ static int frame_warp_fuse_launch(const char* fn, const float* input, const floa
     // loads -- so one context compiled for four did four contexts' work: the LVD recipe's "prev" mode, 114 us per call)
 #define WALDO_FWF_LAUNCH(TCPV, FULLV)                                                                                   \
   hipLaunchKernelGGL((frame_warp_fuse_lds_kernel<TCPV, FULLV>), grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow, \
-                     alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, \
-                     geom.nbands)
+                     alpha, score, ctx_ts, out, raw, status, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units,     \
+                     geom.tiles, geom.nbands)
     if (Tc == 4 && !include_self) WALDO_FWF_LAUNCH(4, true);
     else if (Tc == 1) WALDO_FWF_LAUNCH(1, false);
     else if (Tc == 2) WALDO_FWF_LAUNCH(2, false);
@@ -1188,36 +1190,36 @@ static int frame_warp_fuse_launch(const char* fn, const float* input, const floa
 #endif
   if (Tc == 1)
     hipLaunchKernelGGL(frame_warp_fuse_kernel<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+                       alpha, score, ctx_ts, out, raw, status, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   else if (Tc <= 4)
     hipLaunchKernelGGL(frame_warp_fuse_kernel<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+                       alpha, score, ctx_ts, out, raw, status, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   else
     hipLaunchKernelGGL(frame_warp_fuse_kernel<8>, grid, dim3(kBlock), 0, (hipStream_t)stream, input, flow,
-                       alpha, score, ctx_ts, out, raw, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
+                       alpha, score, ctx_ts, out, raw, status, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, (int)units, geom.tiles, geom.nbands);
   return launch_status(fn);
 }
 
 extern "C" int waldo_frame_warp_fuse_fwd(const float* input, const float* flow, const float* alpha,
-                                         const int64_t* ctx_ts, float* out, float* raw, int B, int T,
+                                         const int64_t* ctx_ts, float* out, float* raw, int* status, int B, int T,
                                          int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self,
                                          float eps, waldo_stream_t stream) {
   if (B > 0 && !alpha) {
     set_error("waldo_frame_warp_fuse_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  return frame_warp_fuse_launch("waldo_frame_warp_fuse_fwd", input, flow, alpha, nullptr, ctx_ts, out, raw, B, T, Tc,
-                                Tp, C, L, Hd, Wd, include_self, eps, stream);
+  return frame_warp_fuse_launch("waldo_frame_warp_fuse_fwd", input, flow, alpha, nullptr, ctx_ts, out, raw, status, B, T,
+                                Tc, Tp, C, L, Hd, Wd, include_self, eps, stream);
 }
 
 extern "C" int waldo_frame_warp_fuse_raw_fwd(const float* input, const float* flow, const float* score,
-                                             const int64_t* ctx_ts, float* out, float* raw, int B, int T, int Tc,
-                                             int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
+                                             const int64_t* ctx_ts, float* out, float* raw, int* status, int B, int T,
+                                             int Tc, int Tp, int C, int L, int Hd, int Wd, int include_self, float eps,
                                              waldo_stream_t stream) {
   if (B > 0 && !score) {
     set_error("waldo_frame_warp_fuse_raw_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  return frame_warp_fuse_launch("waldo_frame_warp_fuse_raw_fwd", input, flow, nullptr, score, ctx_ts, out, raw, B, T,
-                                Tc, Tp, C, L, Hd, Wd, include_self, eps, stream);
+  return frame_warp_fuse_launch("waldo_frame_warp_fuse_raw_fwd", input, flow, nullptr, score, ctx_ts, out, raw, status,
+                                B, T, Tc, Tp, C, L, Hd, Wd, include_self, eps, stream);
 }

@@ -510,13 +510,19 @@ static int acc_tiles(int64_t units, int64_t tiles) {  // tiles per workgroup: ke
   return (int)min((int64_t)kAccTilesMax, max((int64_t)1, units * tiles / WALDO_FCB_MIN_WGS));
 }
 
-// the lane-layer kernels (flow_ctx_bwd_rows.hip.h) serve 9 .. 17 layers; measured no faster than the per-pixel ones at
-// the LVD recipe (warp 0.210 against 0.217 ms, alpha 0.206 against 0.165), so only behind WALDO_DEBUG_FCB_ROWS
-static bool rows_kernels(int L) { return L >= 9 && L <= 17 && debug_option(WALDO_DEBUG_FCB_ROWS); }
+// the lane-layer kernels (tools_dev/dropped/flow_ctx_bwd_rows.hip.h: round 5's experiment) serve 9 .. 17 layers; measured
+// no faster than the per-pixel ones at the LVD recipe (warp 0.210 against 0.217 ms, alpha 0.206 against 0.165): they
+// exist in VARIANT builds only (tools_dev/build_variant.py NAME -DWALDO_VARIANT_FCB_ROWS), where they take every
+// launch they can serve
+#ifdef WALDO_VARIANT_FCB_ROWS
+static bool rows_kernels(int L) { return L >= 9 && L <= 17; }
+#endif
 
 }  // namespace waldo
 
+#ifdef WALDO_VARIANT_FCB_ROWS
 #include "flow_ctx_bwd_rows.hip.h"
+#endif
 
 using namespace waldo;
 
@@ -555,6 +561,7 @@ extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* inpu
   const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
   const int tpb = acc_tiles(N, tiles), groups = (tiles + tpb - 1) / tpb;
   float* gup = scale > 1 ? workspace : grad_alpha_lr;
+#ifdef WALDO_VARIANT_FCB_ROWS
   if (rows_kernels(L)) {
     if (dist == nullptr || Nl <= 20)
       hipLaunchKernelGGL(flow_ctx_alpha_bwd_rows_kernel<20>, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, alpha_lr,
@@ -564,7 +571,9 @@ extern "C" int waldo_flow_ctx_alpha_bwd(const float* alpha_lr, const float* inpu
       hipLaunchKernelGGL(flow_ctx_alpha_bwd_rows_kernel<32>, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, alpha_lr,
                          input, dist, occ, grad_a01, grad_alpha_out, gup, grad_dist, grad_occ, T, Tw, L, Nl, C, chan_off, H, W,
                          scale, tiles, tpb, groups);
-  } else {
+  } else
+#endif
+  {
     // (the class probabilities of a pixel live in registers: compiled for up to kFewCls classes and for kMaxCls)
 #define WALDO_FCAB_CASE(LPV)                                                                                             \
   case LPV:                                                                                                              \
@@ -616,11 +625,14 @@ extern "C" int waldo_flow_ctx_warp_bwd(const float* flow_lr, const float* isobj_
   const int tiles = (int)(((int64_t)H * scale * W * scale + kBlock - 1) / kBlock);
   const int tpb = acc_tiles(N, tiles), groups = (tiles + tpb - 1) / tpb;
   float* gup = scale > 1 ? workspace : grad_flow_lr;
+#ifdef WALDO_VARIANT_FCB_ROWS
   if (rows_kernels(L))
     hipLaunchKernelGGL(flow_ctx_warp_bwd_rows_kernel, dim3((unsigned)(N * groups)), dim3(kBlock), 0, st, flow_lr, isobj_lr,
                        a01, ctx_ts, pred_ts, occ, grad_flow, grad_alpha_ctx, grad_disocc, gup, grad_a01, grad_occ, T, Tw,
                        Tc, Tp, L, H, W, scale, tiles, tpb, groups);
-  else switch (flow_ctx_pad_l(L)) {
+  else
+#endif
+  switch (flow_ctx_pad_l(L)) {
     WALDO_FCB_CASE(4, flow_ctx_warp_bwd_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, grad_flow, grad_alpha_ctx, grad_disocc, gup, grad_a01, grad_occ, T, Tw, Tc, Tp, L, H, W, scale, tiles, tpb, groups)
     WALDO_FCB_CASE(8, flow_ctx_warp_bwd_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, grad_flow, grad_alpha_ctx, grad_disocc, gup, grad_a01, grad_occ, T, Tw, Tc, Tp, L, H, W, scale, tiles, tpb, groups)
     WALDO_FCB_CASE(12, flow_ctx_warp_bwd_kernel, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, grad_flow, grad_alpha_ctx, grad_disocc, gup, grad_a01, grad_occ, T, Tw, Tc, Tp, L, H, W, scale, tiles, tpb, groups)

@@ -72,7 +72,7 @@ bool debug_option(int option) {
 #ifdef WALDO_TIMING_ONLY_BUILD
 extern "C" int waldo_version(void) { return 0; }
 #else
-extern "C" int waldo_version(void) { return 1012; }
+extern "C" int waldo_version(void) { return 1013; }
 #endif
 
 extern "C" int waldo_set_debug_option(int option, int value) {
@@ -81,6 +81,22 @@ extern "C" int waldo_set_debug_option(int option, int value) {
     return WALDO_EINVAL;
   }
   waldo::g_debug[option].store(value, std::memory_order_relaxed);
+  return WALDO_OK;
+}
+
+extern "C" int waldo_host_device_pointer(void* host, void** device) {
+  if (!host || !device) {
+    waldo::set_error("waldo_host_device_pointer: null pointer");
+    return WALDO_EINVAL;
+  }
+  void* dev = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+  if (e != hipSuccess || dev == nullptr) {
+    (void)hipGetLastError();  // (the failed query must not show up as the next launch's status)
+    waldo::set_error("waldo_host_device_pointer: %p is not pinned, mapped host memory (%s)", host, hipGetErrorString(e));
+    return WALDO_EINVAL;
+  }
+  *device = dev;
   return WALDO_OK;
 }
 

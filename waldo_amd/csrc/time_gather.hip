@@ -21,11 +21,12 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // out frame m = (b, tc, tp); P pairs per frame; HW > 0: pair q = n * HW + hw goes to planes (n, c) at hw
 __global__ __launch_bounds__(kBlock) void time_gather_fwd_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ ctx_ts, const int64_t* __restrict__ pred_ts,
-    float* __restrict__ out, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract, int blocks_per_frame) {
+    float* __restrict__ out, int* __restrict__ status, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
+    int blocks_per_frame) {
   const int m = blockIdx.x / blocks_per_frame;
   const int tp = m % Tp, b = m / (Tc * Tp);
-  const int tpr = (int)min(max(pred_ts[tp], (int64_t)0), (int64_t)(T - 1));
-  const int ta = ctx_ts != nullptr ? (int)min(max(ctx_ts[m], (int64_t)0), (int64_t)(T - 1)) : tpr;
+  const int tpr = checked_frame(pred_ts, tp, T, status, kStatusPred);
+  const int ta = ctx_ts != nullptr ? checked_frame(ctx_ts, m, T, status, kStatusCtx) : tpr;
   const f32x2_t* xa = reinterpret_cast<const f32x2_t*>(x) + ((int64_t)b * T + ta) * P;
   const f32x2_t* xs = reinterpret_cast<const f32x2_t*>(x) + ((int64_t)b * T + tpr) * P;
   for (int64_t q = (int64_t)(blockIdx.x % blocks_per_frame) * kBlock + threadIdx.x; q < P;
@@ -135,14 +136,14 @@ static int frame_blocks(int64_t frames, int64_t P) {
 using namespace waldo;
 
 extern "C" int waldo_time_gather_fwd(const float* x, const int64_t* ctx_ts, const int64_t* pred_ts, float* out,
-                                     int B, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
+                                     int* status, int B, int T, int Tc, int Tp, int64_t P, int64_t HW, int subtract,
                                      waldo_stream_t stream) {
   const int rc = check_time_gather("waldo_time_gather_fwd", x, pred_ts, out, B, T, Tc, Tp, P, HW, subtract, ctx_ts);
   if (rc) return rc < 0 ? WALDO_OK : rc;
   const int64_t frames = (int64_t)B * Tc * Tp;
   const int bpf = frame_blocks(frames, P);
   time_gather_fwd_kernel<<<dim3((unsigned)(frames * bpf)), dim3(kBlock), 0, (hipStream_t)stream>>>(
-      x, ctx_ts, pred_ts, out, T, Tc, Tp, P, HW, subtract, bpf);
+      x, ctx_ts, pred_ts, out, status, T, Tc, Tp, P, HW, subtract, bpf);
   return launch_status("waldo_time_gather_fwd");
 }
 

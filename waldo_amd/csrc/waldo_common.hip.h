@@ -40,6 +40,28 @@ constexpr int kWave = 64;   // gfx950 wavefront
 constexpr int kBlock = 256; // 4 waves, one per SIMD of a CU
 
 // ---------------------------------------------------------------------------------------
+// Frame indices from device memory (ctx_ts / pred_ts: the reference's gather_time, models/nets/lvd.py:462-467, where
+// `tensor.gather(1, ts)` RAISES for an index outside the time axis).  The kernels index with them directly: the value
+// is clamped for memory safety and a violation is REPORTED in the caller's sticky status words (include/waldo_hip.h:
+// "Frame-index status": words `slot`, `slot + 1` = the limit that was violated (never 0), an offending value) instead
+// of passing silently.  The status words may be pinned host memory (the caller reads them without a device
+// synchronisation): plain system-scope stores, error path only; every reporting lane writes the same limit.
+// ---------------------------------------------------------------------------------------
+constexpr int kStatusCtx = 0, kStatusPred = 2;  // word pairs of WALDO_INDEX_STATUS_WORDS
+
+__device__ __forceinline__ int checked_frame(const int64_t* __restrict__ ts, int64_t i, int limit,
+                                             int* __restrict__ status, int slot) {
+  const int64_t raw = ts[i];
+  const int64_t c = min(max(raw, (int64_t)0), (int64_t)(limit - 1));
+  if (status != nullptr && raw != c) {
+    __hip_atomic_store(status + slot, limit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(status + slot + 1, (int)min(max(raw, (int64_t)INT32_MIN), (int64_t)INT32_MAX), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------
 // XCD-aware work mapping.  MI355X deals consecutive workgroup ids round-robin over its 8 XCDs,
 // each with a private 4 MiB L2 (observed behaviour; used for SPEED only, never for correctness).
 // Work = nA outer units (frames / frame chunks / layer planes) x nB inner tiles.  Outer unit a is

@@ -368,7 +368,9 @@ void launch_splat(const float* rec, const float* grad_rgb, const int* cellbox,
 }  // namespace waldo
 
 #include "warp_composite_fwd_lds.hip.h"
+#ifdef WALDO_VARIANT_FWD_PIPE  // tools_dev/build_variant.py only: round 5's rejected experiment (tools_dev/dropped/)
 #include "warp_composite_fwd_pipe.hip.h"
+#endif
 #include "warp_composite_bwd_px16.hip.h"
 
 namespace waldo {
@@ -435,10 +437,12 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
       };
       using T = std::true_type;
       using N = std::false_type;
-      if constexpr (WALDO_FWD_PIPE != 0 && NW == 4 && LP >= 2 && LP <= 8) {
-        // round 5's experiment (warp_composite_fwd_pipe.hip.h): the frame loop software-pipelined; same bits, measured
-        // 2.5 % SLOWER at the headline shape, so only behind the debug switch (bench.py --debug-option 3)
-        if (L == LP && debug_option(WALDO_DEBUG_FWD_PIPELINED)) {
+#ifdef WALDO_VARIANT_FWD_PIPE
+      if constexpr (NW == 4 && LP >= 2 && LP <= 8) {
+        // a VARIANT build (tools_dev/build_variant.py NAME -DWALDO_VARIANT_FWD_PIPE): round 5's software-pipelined frame
+        // loop (tools_dev/dropped/warp_composite_fwd_pipe.hip.h; same bits, 2.5 % slower at the headline shape) takes
+        // every launch it can serve -- the product library does not contain it
+        if (L == LP) {
           if (src_pts != nullptr)
             hipLaunchKernelGGL((warp_composite_fwd_pipe_kernel<LP, true>), grid16, dim3(NW * kWave), 0, st, layers,
                                basis_t, mapping, inv_kernel, src_pts, occ, rgb, alpha, F, H, W, fpb, ntx16, nt16,
@@ -450,6 +454,7 @@ static void launch_fwd(const float* layers, const float* basis_t, const float* m
           return;
         }
       }
+#endif
       if (src_pts != nullptr) {
         if (L == LP) go(T{}, T{}); else go(N{}, T{});
       } else {

@@ -5,7 +5,6 @@ function has a CPU or eager-PyTorch fallback (``_lib.check_cuda`` raises on CPU 
 PyTorch is used for memory (output allocation), streams and autograd bookkeeping only.
 """
 import math
-import weakref
 
 import torch
 
@@ -16,15 +15,19 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_MERGE_FILL_BYTES = 1 << 20
+
+
 def _zeros_like_each(*tensors):
     """Zero-filled tensors shaped like each argument (None -> None), carved out of ONE buffer and filled by ONE launch:
     the gradients a backward kernel accumulates into with atomics -- at the LVD recipe a fill is a 4 us launch whatever
     its size, and a backward call that zeroed two or three small tensors paid for each.  Every view starts on a
     256-byte boundary."""
-    want = [t for t in tensors if t is not None]
-    if not want:
-        return [None] * len(tensors)
-    if len(want) == 1:
+    # (only SMALL tensors share a buffer: a view keeps the whole buffer alive until every view is consumed -- a
+    # full-resolution gradient tied to a tiny one that waits for another op's backward, or that AccumulateGrad keeps
+    # as a leaf's .grad, would stay allocated that long)
+    want = [t for t in tensors if t is not None and t.numel() * t.element_size() < _MERGE_FILL_BYTES]
+    if len(want) < 2:
         return [torch.zeros_like(t) if t is not None else None for t in tensors]
     sizes = [(t.numel() + 63) // 64 * 64 for t in want]
     flat = torch.zeros(sum(sizes), dtype=want[0].dtype, device=want[0].device)
@@ -33,99 +36,60 @@ def _zeros_like_each(*tensors):
     for t in tensors:
         if t is None:
             out.append(None)
-            continue
-        n = next(it)
-        out.append(flat[at:at + t.numel()].view(t.shape))
-        at += n
+        elif t.numel() * t.element_size() >= _MERGE_FILL_BYTES:
+            out.append(torch.zeros_like(t))
+        else:
+            n = next(it)
+            out.append(flat[at:at + t.numel()].view(t.shape))
+            at += n
     return out
 
 
-_INDEX_RANGE = {}  # id(index tensor) -> (weak reference to it, {version: (lowest, highest) index it holds})
+class ArangeIndex(torch.Tensor):
+    """A frame index KNOWN on the host to be 0, 1, ..., n - 1 (``arange_index``): ``time_gather`` may then hand out
+    the clip itself instead of a gathered copy.  Plain tensors never take that short cut -- telling would need a
+    device -> host read."""
+    __torch_function__ = torch._C._disabled_torch_function_impl  # (results of ops on it are plain tensors)
+
+    def __deepcopy__(self, memo):
+        if _is_arange_index(self):
+            return arange_index(self.numel(), self.device)
+        return self.as_subclass(torch.Tensor).clone()
 
 
-def _index_entry(ts):
-    key = id(ts)
-    ent = _INDEX_RANGE.get(key)
-    if ent is None or ent[0]() is not ts:  # (tensors compare element-wise: identity, not ==)
-        ent = (weakref.ref(ts, lambda _ref, k=key: _INDEX_RANGE.pop(k, None)), {})
-        _INDEX_RANGE[key] = ent
-    return ent[1]
+def arange_index(n, device=None):
+    """``torch.arange(n)`` (int64) for ``pred_ts`` when every frame is predicted in order (the LVD recipe's
+    ``ctx_mode "prev"``, models/synthesizer.py:833-835), marked as such: ``time_gather(x, None, pred_ts, num_ctx=1)``
+    returns a VIEW of ``x`` for it (no copy forward, autograd's own sum backward) -- an alias of the caller's clip,
+    unlike the reference's ``x[:, pred_ts]``; do not write to the result in place.  The mark holds for this very
+    tensor while nobody writes to it (version counter).  Under HIP-graph capture the choice is frozen into the
+    graph like every host-side decision."""
+    t = torch.arange(int(n), device=device, dtype=torch.int64)
+    if t.is_inference():  # (no version counter to vouch for it: a plain index, gathered by the kernel)
+        return t
+    t = t.as_subclass(ArangeIndex)
+    t._waldo_arange = (int(n), t._version)
+    return t
 
 
-def _index_version(ts):
-    """Version counter of ``ts``, or None for a tensor without one (made under ``torch.inference_mode()``:
-    reading ``_version`` raises there)."""
-    if ts.is_inference():
-        return None
-    return ts._version
-
-
-def _index_info(ts, private=False):
-    """(lowest, highest, is_arange) of ``ts``: ONE device -> host read per distinct (tensor, version), whatever
-    limits it is checked against afterwards.  A tensor without a version counter (inference mode) is read on
-    every call -- its owner could have written to it in place unseen -- unless it is ``private``: a copy
-    ``normalise_time_index`` made and nobody else holds.  ``is_arange``: a 1-D index equal to 0, 1, ..., n - 1
-    (``x[:, ts]`` is then ``x[:, :n]``: ``time_gather`` hands out the clip itself instead of a copy of it)."""
-    seen = _index_entry(ts)
-    ver = _index_version(ts)
-    key = ver if ver is not None else ("private" if (private or "private" in seen) else None)
-    if key is not None and key in seen:
-        return seen[key]
-    if ts.ndim == 1:
-        same = (ts == torch.arange(ts.numel(), device=ts.device, dtype=ts.dtype)).all().to(ts.dtype)
-        lo, hi, same = torch.stack([ts.min(), ts.max(), same]).tolist()
-        info = (int(lo), int(hi), bool(same))
-    else:
-        info = tuple(int(v) for v in torch.aminmax(ts)) + (False,)
-    if key is not None:
-        seen[key] = info
-    return info
-
-
-def _index_range(ts, private=False):
-    return _index_info(ts, private)[:2]
-
-
-def _known_arange(ts):
-    """True when ``ts`` is KNOWN to be 0, 1, ..., n - 1 from an earlier read of this very (tensor, version) -- never
-    reads the device, so it also answers while a HIP graph is being captured (the warm-up steps before the capture
-    made the read)."""
-    seen = _index_entry(ts)
-    ver = _index_version(ts)
-    key = ver if ver is not None else ("private" if "private" in seen else None)
-    info = seen.get(key) if key is not None else None
-    return bool(info is not None and info[2])
+def _is_arange_index(ts):
+    mark = getattr(ts, "_waldo_arange", None)
+    return mark is not None and not ts.is_inference() and mark == (ts.numel(), ts._version)
 
 
 def normalise_time_index(ts):
     """``ctx_ts`` / ``pred_ts`` as the kernels take them (int64, contiguous), made ONCE per decode by the
-    caller (``Warper``) and handed to every op of the chain: the ops then find the same tensor object and its
-    range in the cache instead of converting an expanded view (synthesizer.py:438) into a fresh temporary --
-    and reading it back -- per op.  Under ``torch.inference_mode()`` the result is always a private copy."""
-    out = _c(ts.long())
-    if out.numel() == 0 or (out.is_cuda and torch.cuda.is_current_stream_capturing()):
-        return out
-    if out.is_inference():
-        if out is ts:
-            if "private" in _index_entry(ts):
-                return ts  # already the private copy an earlier call of the same decode made: no clone, no read-back
-            out = ts.clone()
-        _index_range(out, private=True)
-    else:
-        _index_range(out)
-    return out
+    caller (``Warper``) and handed to every op of the chain instead of converting an expanded view
+    (synthesizer.py:438) into a fresh temporary per op.  No read-back: the kernels validate the indices on the
+    device (``_lib.IndexStatus``)."""
+    return _c(ts.long())
 
 
-def _check_time_index(fn, name, ts, limit):
-    """The reference's ``gather_time`` (models/nets/lvd.py:462-467, ``tensor.gather(1, ts)``) raises for an
-    index outside [0, limit); the fused kernels index with it directly, so it is validated here instead of
-    being clamped silently.  Costs one device -> host read per distinct (tensor, version) -- a loop that
-    reuses its index tensors pays it once -- and nothing while a HIP graph is being captured."""
-    if ts.numel() == 0 or torch.cuda.is_current_stream_capturing():
-        return
-    lo, hi = _index_range(ts)
-    if lo < 0 or hi >= limit:
-        raise _lib.WaldoHipError(f"{fn}: {name} holds indices in [{lo}, {hi}], valid range is [0, {int(limit) - 1}]")
+def _status(status):
+    """(IndexStatus to hand to the kernels, whether this call checks it itself): a caller that passes its own status
+    words checks them when it chooses (``Warper``: lazily, without a synchronisation); a stand-alone call uses the
+    module's and is checked -- with a synchronisation -- before it returns, as the reference's ``gather`` raises."""
+    return (status, False) if status is not None else (_lib.default_index_status(), True)
 
 
 # --------------------------------------------------------------------------------------
@@ -842,7 +806,7 @@ def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale, want_alpha=T
 
 class _FlowCtxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max):
+    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max, status_ptr):
         m, nl, _, h, w = flow_lr.shape
         b, tc, tp = ctx_ts.shape
         t = occ.shape[1]
@@ -854,8 +818,8 @@ class _FlowCtxWarp(torch.autograd.Function):
         with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
-                      _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, b, t, tw, tc, tp, nl, h, w, scale,
-                      _lib.current_stream(flow_lr.device))
+                      _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, status_ptr, b, t, tw, tc, tp, nl, h, w,
+                      scale, _lib.current_stream(flow_lr.device))
         ctx.save_for_backward(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ)
         ctx.cfg = (tw, scale)
         ctx.mark_non_differentiable(amax)
@@ -881,7 +845,7 @@ class _FlowCtxWarp(torch.autograd.Function):
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(g_flow), _lib.ptr(g_actx),
                       _lib.ptr(g_dis), _lib.ptr(g_lr), _lib.ptr(g_a01), _lib.ptr(g_occ), _lib.ptr(ws), b, t, tw,
                       tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
-        return g_lr, None, g_a01, None, None, g_occ, None, None, None
+        return g_lr, None, g_a01, None, None, g_occ, None, None, None, None
 
 
 def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
@@ -898,8 +862,6 @@ def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sc
         raise _lib.WaldoHipError(
             f"{fn}: inconsistent shapes flow_lr={tuple(flow_lr.shape)} a01={tuple(a01.shape)} "
             f"ctx_ts={tuple(ctx_ts.shape)} pred_ts={tuple(pred_ts.shape)} occ={tuple(occ.shape)}")
-    _check_time_index(fn, "ctx_ts", ctx_ts, tw)
-    _check_time_index(fn, "pred_ts", pred_ts, t)
     if isobj_lr is not None:
         _lib.check_cuda(isobj_lr)
         isobj_lr = _c(isobj_lr.detach())
@@ -908,7 +870,7 @@ def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sc
     return flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ
 
 
-def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False):
+def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False, status=None):
     """Context-alpha warp + ghost mask + disocclusion + second occlusion product + flow compositing
     (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
     a01 (B*Tw, L, Hd, Wd) from flow_ctx_alpha; ctx_ts (B, Tc, Tp) long; pred_ts (Tp) long;
@@ -916,48 +878,35 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer
     disocc (M, Hd, Wd).  Differentiable w.r.t. flow_lr, a01 and occ (the thresholded ghost mask
     carries no gradient, as in the reference).  ``layer_max``: a fourth result, ``alpha_ctx.amax(dim=1)``
     (M, Hd, Wd) -- what Synthesizer.predict's disocclusion test computes from alpha_ctx (synthesizer.py:447) --
-    as a by-product (no gradient)."""
+    as a by-product (no gradient).  ``ctx_ts`` must lie in [0, tw), ``pred_ts`` in [0, T): validated on the device
+    (``status``: the caller's ``_lib.IndexStatus``, checked when the caller chooses; None: checked before returning)."""
     flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = _flow_ctx_warp_args("flow_ctx_warp", flow_lr, isobj_lr, a01, ctx_ts,
                                                                        pred_ts, occ, tw, scale)
+    st, strict = _status(status)
     flow, alpha_ctx, disocc, amax = _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale,
-                                                       bool(layer_max))
+                                                       bool(layer_max), st.ptr)
+    if strict:
+        st.check(sync=True)
     return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
 
 
 class RawSlots:
-    """What ``flow_ctx_warp_into_raw`` leaves for ``frame_warp_fuse``: the ``raw`` tensor of
+    """What ``flow_ctx_warp_into_raw`` leaves for ``frame_warp_fuse_raw``: the ``raw`` tensor of
     Warper.input_to_output, (B, Tp, Tc', C + L, Hd, Wd), with the alpha slots of its Tc contexts filled, and
-    ``score`` (B, Tc, Tp, Hd, Wd) = the per-context sums of (alpha + 1) / 2 (lvd.py:841).  It rides on the
-    ``alpha_ctx`` view as the attribute ``_waldo_raw``: only that very tensor object, unmodified, takes the
-    short way through ``frame_warp_fuse``."""
+    ``score`` (B, Tc, Tp, Hd, Wd) = the per-context sums of (alpha + 1) / 2 (lvd.py:841)."""
 
-    def __init__(self, raw, score, channels, include_self, alpha_view):
+    def __init__(self, raw, score, channels, include_self):
         self.raw, self.score, self.channels, self.include_self = raw, score, channels, include_self
-        self.version = _index_version(alpha_view)
-        self.ptr, self.strides = alpha_view.data_ptr(), alpha_view.stride()
-        self.vouched = False  # set by a caller that hands the view straight on, unmodified (decode_output)
-
-    def still_describes(self, alpha):
-        """``alpha`` is the view this was made for and nobody wrote to it since (a write went into ``raw``
-        as well, but the sums in ``score`` would be stale).  A tensor made under ``torch.inference_mode()`` has no
-        version counter, so a write in between cannot be seen: it takes the short way only when the caller that
-        kept it in its own hands says so (``vouched``: decode_output); otherwise frame_warp_fuse reads and copies it."""
-        if alpha.data_ptr() != self.ptr or alpha.stride() != self.strides:
-            return False
-        ver = _index_version(alpha)
-        if ver is None:
-            return self.vouched and self.version is None
-        return ver == self.version
 
 
 def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self,
-                           layer_max=False):
-    """``flow_ctx_warp`` for the caller that runs ``frame_warp_fuse`` on the result next
+                           layer_max=False, status=None):
+    """``flow_ctx_warp`` for the caller that runs ``frame_warp_fuse_raw`` on the result next
     (LVD.forward(mode="decode_output"), lvd.py:141-153), WITHOUT autograd: ``alpha_ctx`` is written straight
     into the alpha slots of input_to_output's ``raw`` tensor (lvd.py:846) and returned as a strided
     (B*Tc*Tp -> B, Tc, Tp, L, Hd, Wd) view of it.  ``channels`` = C of the frames that will be warped,
     ``include_self``: whether ``raw`` gets the extra self context.  Returns (flow, alpha_ctx view (B, Tc, Tp, L,
-    Hd, Wd), disocc[, amax]); the view carries a ``RawSlots`` as ``_waldo_raw``."""
+    Hd, Wd), disocc, amax or None, slots): ``slots`` (a ``RawSlots``) goes to ``frame_warp_fuse_raw``."""
     if torch.is_grad_enabled() and any(x is not None and x.requires_grad for x in (flow_lr, a01, occ)):
         raise _lib.WaldoHipError("flow_ctx_warp_into_raw: no gradient flows through the raw-slot path; use flow_ctx_warp")
     flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = _flow_ctx_warp_args("flow_ctx_warp_into_raw", flow_lr, isobj_lr, a01,
@@ -967,6 +916,7 @@ def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sca
     t = occ.shape[1]
     hd, wd = a01.shape[-2:]
     tcx = tc + (1 if include_self else 0)
+    st, strict = _status(status)
     with torch.no_grad():
         flow = flow_lr.new_empty(m, 2, hd, wd)
         raw = flow_lr.new_empty(b, tp, tcx, channels + nl, hd, wd)
@@ -976,11 +926,12 @@ def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sca
         with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_raw_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(raw),
-                      _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax), b, t, tw, tc, tp, nl, h, w, scale,
+                      _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax), st.ptr, b, t, tw, tc, tp, nl, h, w, scale,
                       int(channels), tcx, _lib.current_stream(flow_lr.device))
         alpha_ctx = raw[:, :, :tc, channels:].permute(0, 2, 1, 3, 4, 5)  # (B, Tc, Tp, L, Hd, Wd), strided
-    alpha_ctx._waldo_raw = RawSlots(raw, score, int(channels), bool(include_self), alpha_ctx)
-    return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
+    if strict:
+        st.check(sync=True)
+    return flow, alpha_ctx, disocc, amax, RawSlots(raw, score, int(channels), bool(include_self))
 
 
 MAX_FUSE_CTX = 8
@@ -988,7 +939,7 @@ MAX_FUSE_CTX = 8
 
 class _FrameWarpFuse(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, flow, alpha, ctx_ts, include_self, eps):
+    def forward(ctx, input, flow, alpha, ctx_ts, include_self, eps, status_ptr):
         b, t, c, hd, wd = input.shape
         _, tc, tp, nl = alpha.shape[:4]
         tcx = tc + (1 if include_self else 0)
@@ -999,7 +950,7 @@ class _FrameWarpFuse(torch.autograd.Function):
         raw = input.new_empty(b, tp, tcx, c + nl, hd, wd)
         with _lib.on_device(input.device):
             _lib.call("waldo_frame_warp_fuse_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
-                      _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
+                      _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), status_ptr, b, t, tc, tp, c, nl, hd, wd,
                       1 if include_self else 0, float(eps), _lib.current_stream(input.device))
         ctx.save_for_backward(input, flow, alpha, ctx_ts)
         ctx.cfg = (bool(include_self), float(eps))
@@ -1022,19 +973,18 @@ class _FrameWarpFuse(torch.autograd.Function):
             _lib.call("waldo_frame_warp_fuse_bwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(alpha),
                       _lib.ptr(ctx_ts), _lib.ptr(g_out), _lib.ptr(g_raw), _lib.ptr(g_flow), _lib.ptr(g_alpha), b, t,
                       tc, tp, c, nl, hd, wd, 1 if include_self else 0, eps, _lib.current_stream(input.device))
-        return None, g_flow, g_alpha, None, None, None
+        return None, g_flow, g_alpha, None, None, None, None
 
 
-def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
+def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6, status=None):
     """Warper.input_to_output (models/nets/lvd.py:830-853).  input (B,T,C,Hd,Wd);
     flow (B,Tc,Tp,2,Hd,Wd); alpha (B,Tc,Tp,L,Hd,Wd) in [-1,1]; ctx_ts (B,Tc,Tp) long.
     Returns (out (B,Tp,C+1,Hd,Wd), raw (B,Tc',Tp,C+L,Hd,Wd)).  Differentiable w.r.t. flow and alpha;
-    the frames in ``input`` are data (no gradient is produced for them).  An ``alpha`` that
-    ``flow_ctx_warp_into_raw`` produced already sits in ``raw``: it is neither read nor copied."""
+    the frames in ``input`` are data (no gradient is produced for them).  ``ctx_ts`` must lie in [0, T): validated
+    on the device (``status``: see ``flow_ctx_warp``)."""
     _lib.check_cuda(input, flow, alpha)
     if not ctx_ts.is_cuda:
         raise _lib.WaldoHipError("frame_warp_fuse: ctx_ts must be on the GPU")
-    slots = getattr(alpha, "_waldo_raw", None)
     input, flow = _c(input.detach()), _c(flow)
     ctx_ts = _c(ctx_ts.long())
     b, t, c, hd, wd = input.shape
@@ -1044,16 +994,44 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
         raise _lib.WaldoHipError(
             f"frame_warp_fuse: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
             f"alpha={tuple(alpha.shape)} ctx_ts={tuple(ctx_ts.shape)}")
-    _check_time_index("frame_warp_fuse", "ctx_ts", ctx_ts, t)
-    if slots is not None and slots.channels == c and slots.include_self == bool(include_self) \
-            and slots.still_describes(alpha) and not (torch.is_grad_enabled() and flow.requires_grad):
-        raw, out = slots.raw, input.new_empty(b, tp, c + 1, hd, wd)
-        with torch.no_grad(), torch.cuda.device(input.device):
-            _lib.call("waldo_frame_warp_fuse_raw_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(slots.score),
-                      _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), b, t, tc, tp, c, nl, hd, wd,
-                      1 if include_self else 0, float(eps), _lib.current_stream(input.device))
-        return out, raw.permute(0, 2, 1, 3, 4, 5)
-    return _FrameWarpFuse.apply(input, flow, _c(alpha), ctx_ts, bool(include_self), eps)
+    st, strict = _status(status)
+    res = _FrameWarpFuse.apply(input, flow, _c(alpha), ctx_ts, bool(include_self), eps, st.ptr)
+    if strict:
+        st.check(sync=True)
+    return res
+
+
+def frame_warp_fuse_raw(input, flow, slots, ctx_ts, eps=1e-6, status=None):
+    """``frame_warp_fuse`` behind ``flow_ctx_warp_into_raw`` (no autograd): the context alphas already sit in
+    ``slots.raw`` and their per-context sums in ``slots.score``, so they are neither read nor copied -- one score
+    plane per context instead of L alpha planes.  The same bits as ``frame_warp_fuse`` on the alpha view
+    (tests/test_gpu_warper.py::test_alpha_ctx_written_into_raw_slots).  Returns (out, raw as (B, Tc', Tp, ...))."""
+    _lib.check_cuda(input, flow)
+    if not ctx_ts.is_cuda:
+        raise _lib.WaldoHipError("frame_warp_fuse_raw: ctx_ts must be on the GPU")
+    if torch.is_grad_enabled() and flow.requires_grad:
+        raise _lib.WaldoHipError("frame_warp_fuse_raw: no gradient flows through the raw-slot path; use frame_warp_fuse")
+    input, flow = _c(input.detach()), _c(flow.detach())
+    ctx_ts = _c(ctx_ts.long())
+    b, t, c, hd, wd = input.shape
+    raw, score = slots.raw, slots.score
+    _, tc, tp = score.shape[:3]
+    nl = raw.shape[3] - c
+    tcx = tc + (1 if slots.include_self else 0)
+    if slots.channels != c or tuple(raw.shape) != (b, tp, tcx, c + nl, hd, wd) or tuple(score.shape) != (b, tc, tp, hd, wd) \
+            or tuple(flow.shape) != (b, tc, tp, 2, hd, wd) or tuple(ctx_ts.shape) != (b, tc, tp):
+        raise _lib.WaldoHipError(
+            f"frame_warp_fuse_raw: inconsistent shapes input={tuple(input.shape)} flow={tuple(flow.shape)} "
+            f"raw={tuple(raw.shape)} score={tuple(score.shape)} ctx_ts={tuple(ctx_ts.shape)}")
+    st, strict = _status(status)
+    out = input.new_empty(b, tp, c + 1, hd, wd)
+    with torch.no_grad(), _lib.on_device(input.device):
+        _lib.call("waldo_frame_warp_fuse_raw_fwd", _lib.ptr(input), _lib.ptr(flow), _lib.ptr(score),
+                  _lib.ptr(ctx_ts), _lib.ptr(out), _lib.ptr(raw), st.ptr, b, t, tc, tp, c, nl, hd, wd,
+                  1 if slots.include_self else 0, float(eps), _lib.current_stream(input.device))
+    if strict:
+        st.check(sync=True)
+    return out, raw.permute(0, 2, 1, 3, 4, 5)
 
 
 # --------------------------------------------------------------------------------------
@@ -1061,14 +1039,14 @@ def frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=False, eps=1e-6):
 # --------------------------------------------------------------------------------------
 class _TimeGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ctx_ts, pred_ts, tc, hw, subtract):
+    def forward(ctx, x, ctx_ts, pred_ts, tc, hw, subtract, status_ptr):
         b, t = x.shape[:2]
         p = math.prod(x.shape[2:]) // 2
         tp = pred_ts.numel()
         out = x.new_empty(b, tc, tp, *((p // hw, 2, hw) if hw else (p, 2)))
         with _lib.on_device(x.device):
             _lib.call("waldo_time_gather_fwd", _lib.ptr(x), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(out),
-                      b, t, tc, tp, p, hw, int(subtract), _lib.current_stream(x.device))
+                      status_ptr, b, t, tc, tp, p, hw, int(subtract), _lib.current_stream(x.device))
         ctx.save_for_backward(ctx_ts, pred_ts)
         ctx.cfg = (tuple(x.shape), tc, hw, subtract)
         return out
@@ -1084,10 +1062,10 @@ class _TimeGather(torch.autograd.Function):
             _lib.call("waldo_time_gather_bwd", _lib.ptr(grad_out), _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(gx),
                       b, t, tc, pred_ts.numel(), math.prod(shape[2:]) // 2, hw, int(subtract),
                       _lib.current_stream(grad_out.device))
-        return gx, None, None, None, None, None
+        return gx, None, None, None, None, None, None
 
 
-def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=False):
+def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=False, status=None):
     """``gather_time`` (models/nets/lvd.py:462-467) and the frame arithmetic of the flow synthesis
     (lvd.py:660-668, 780-787) on a clip's grids ``x`` (B, T, ..., 2):
 
@@ -1096,7 +1074,9 @@ def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=
     - otherwise ``gather_time(x, ctx_ts)``.
 
     ``channel_first``: x is (B, T, N, H, W, 2) and the result (B, Tc, Tp, N, 2, H, W) -- the
-    ``permute(0, 1, 2, 3, 6, 4, 5)`` of lvd.py:662.  Differentiable w.r.t. ``x``."""
+    ``permute(0, 1, 2, 3, 6, 4, 5)`` of lvd.py:662.  Differentiable w.r.t. ``x``.  Frame indices must lie in [0, T):
+    validated on the device (``status``: see ``flow_ctx_warp``).  For ONE context and a ``pred_ts`` made by
+    ``arange_index(T)`` the result is a VIEW of ``x`` (see there)."""
     _lib.check_cuda(x)
     if x.ndim < 3 or x.shape[-1] != 2 or (channel_first and x.ndim != 6):
         raise _lib.WaldoHipError(f"time_gather: x {tuple(x.shape)} is not a clip of grids (B, T, ..., 2)")
@@ -1110,19 +1090,20 @@ def time_gather(x, ctx_ts, pred_ts, num_ctx=None, subtract=False, channel_first=
         if ctx_ts.ndim != 3 or ctx_ts.shape[0] != b or ctx_ts.shape[2] != pred_ts.numel():
             raise _lib.WaldoHipError(f"time_gather: ctx_ts {tuple(ctx_ts.shape)} against B={b}, Tp={pred_ts.numel()}")
         tc = ctx_ts.shape[1]
-        _check_time_index("time_gather", "ctx_ts", ctx_ts, t)
     else:
         if subtract or num_ctx is None:
             raise _lib.WaldoHipError("time_gather: without ctx_ts give num_ctx (and no difference)")
         tc = int(num_ctx)
-    _check_time_index("time_gather", "pred_ts", pred_ts, t)
     tp = pred_ts.numel()
-    if ctx_ts is None and tc == 1 and tp == t and not channel_first and _known_arange(pred_ts):
+    if ctx_ts is None and tc == 1 and tp == t and not channel_first and _is_arange_index(pred_ts):
         # x[:, [0, 1, ..., T - 1]] for one context: the clip itself (a view: no copy, and the backward is autograd's sum
         # instead of a scatter kernel) -- the LVD recipe's `ctx_mode "prev"`, where every frame is predicted
         return x.view(b, 1, t, *x.shape[2:])
     hw = x.shape[3] * x.shape[4] if channel_first else 0
-    out = _TimeGather.apply(x, ctx_ts, pred_ts, tc, hw, bool(subtract))
+    st, strict = _status(status)
+    out = _TimeGather.apply(x, ctx_ts, pred_ts, tc, hw, bool(subtract), st.ptr)
+    if strict:
+        st.check(sync=True)
     if channel_first:
         return out.view(b, tc, tp, x.shape[2], 2, x.shape[3], x.shape[4])
     return out.view(b, tc, tp, *x.shape[2:])

@@ -8,13 +8,19 @@ single launch: 54.6 us -> 25.9 us per C2 forward on MI355X (tools_dev/bench_grap
 """
 import torch
 
+from . import _lib
+
 
 class GraphedCall:
     """Captures ``fn(*inputs)`` (forward only, fixed shapes) and replays it.
 
     ``inputs`` are copied into static buffers on every call (``self.inputs``: pass those themselves
     to skip the copy); the returned tensors are the graph's static outputs (clone them if they must
-    survive the next call)."""
+    survive the next call).
+
+    Frame indices (``ctx_ts`` / ``pred_ts``) are validated by the kernels on the device, in a replay as in an eager
+    call: what the replays so far have reported is raised after each replay (no synchronisation; ``check()`` waits
+    for the stream first)."""
 
     def __init__(self, fn, *example_inputs, warmup=3):
         self._static = [x.clone() if torch.is_tensor(x) else x for x in example_inputs]
@@ -40,4 +46,9 @@ class GraphedCall:
                 if src is not dst:  # identity only: a view or a recycled pointer may alias other contents
                     dst.copy_(src)
         self._graph.replay()
+        _lib.IndexStatus.check_all()
         return self._out
+
+    def check(self):
+        """Wait for the replays queued so far and raise if a kernel met a frame index outside its time axis."""
+        _lib.IndexStatus.check_all(sync=True)

@@ -136,6 +136,23 @@ class Warper(nn.Module):
         self.return_alpha = True
         self.alpha_ctx_max = None
         self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused
+        self._index_status = None
+
+    @property
+    def index_status(self):
+        """This module's frame-index status words (``_lib.IndexStatus``: pinned host memory the kernels report into when
+        ``ctx_ts`` / ``pred_ts`` hold an index outside the time axis, where the reference's ``gather_time`` fails,
+        lvd.py:462-467).  Checked without a synchronisation at the start and the end of every flow synthesis / frame
+        warp -- an error of an earlier launch surfaces at the next call, as a device-side assert does on the
+        reference's GPU path -- and on demand by ``check_time_indices()``."""
+        if self._index_status is None:
+            from .._lib import IndexStatus
+            self._index_status = IndexStatus()
+        return self._index_status
+
+    def check_time_indices(self):
+        """Wait for the launches queued so far and raise if one of them met a frame index outside its range."""
+        self.index_status.check(sync=True)
 
     # ------------------------------------------------------------------ image -> layer space
     def layer_from_input(self, input, grid):
@@ -359,22 +376,24 @@ class Warper(nn.Module):
         tc, tp = ctx_ts.size(1), pred_ts.size(0)
         h, w = self.src_shape
         ho, wo = self.tgt_shape
-        obj_flow = WF.time_gather(tgt_grid_obj, ctx_ts, pred_ts, subtract=True, channel_first=True)
-        bg_flow = WF.time_gather(tgt_grid_bg.unsqueeze(2), ctx_ts, pred_ts, subtract=True, channel_first=True)
+        st = self.index_status
+        obj_flow = WF.time_gather(tgt_grid_obj, ctx_ts, pred_ts, subtract=True, channel_first=True, status=st)
+        bg_flow = WF.time_gather(tgt_grid_bg.unsqueeze(2), ctx_ts, pred_ts, subtract=True, channel_first=True, status=st)
         if torch.is_grad_enabled() and (src_grid_obj.requires_grad or src_grid_bg.requires_grad or
                                         tgt_grid_obj.requires_grad or tgt_grid_bg.requires_grad):
-            sgo = WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=tc).reshape(b * tc, tp, no, h, w, 2)
-            sgb = WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=tc).reshape(b * tc, tp, h, w, 2)
+            sgo = WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=tc, status=st).reshape(b * tc, tp, no, h, w, 2)
+            sgb = WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=tc, status=st).reshape(b * tc, tp, h, w, 2)
         else:  # inference: the Tc copies are never made (TimeRepeat)
-            sgo = TimeRepeat(WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=1).reshape(b, tp, no, h, w, 2), tc)
-            sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1).reshape(b, tp, h, w, 2), tc)
+            sgo = TimeRepeat(WF.time_gather(src_grid_obj, None, pred_ts, num_ctx=1, status=st).reshape(b, tp, no, h, w, 2), tc)
+            sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1, status=st).reshape(b, tp, h, w, 2), tc)
         return obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w), sgo, sgb
 
-    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=False):
+    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None):
         """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
         the low resolution goes through the same per-op kernels as the unfused path.  ``into_raw``
-        (decode_output, no autograd): alpha_ctx is written into the slots it will occupy in
-        input_to_output's ``raw`` tensor and comes back as a view of it (WF.flow_ctx_warp_into_raw)."""
+        (decode_output, no autograd; a list): alpha_ctx is written into the slots it will occupy in
+        input_to_output's ``raw`` tensor and comes back as a view of it; the list receives the ``WF.RawSlots``
+        that ``WF.frame_warp_fuse_raw`` takes (WF.flow_ctx_warp_into_raw)."""
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
         tc, tp = ctx_ts.size(1), pred_ts.size(0)
@@ -418,30 +437,33 @@ class Warper(nn.Module):
             is_obj = is_obj.reshape(b * tc * tp, no, h, w)
         else:
             flow_lr = self.layer_to_output(obj_flow, bg_flow, gridp, delta_bg=0, delta_obj=0)
-        if into_raw:
+        if into_raw is not None:
             res = WF.flow_ctx_warp_into_raw(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts,
                                             occ, tw, s, input.size(2), self.include_self and tp == t,
-                                            layer_max=self.keep_alpha_ctx_max)
+                                            layer_max=self.keep_alpha_ctx_max, status=self.index_status)
+            into_raw.append(res[4])
         else:
             res = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts, occ, tw, s,
-                                   layer_max=self.keep_alpha_ctx_max)
+                                   layer_max=self.keep_alpha_ctx_max, status=self.index_status)
         flow, alpha_ctx, disocc = res[:3]
         # by-product for Synthesizer.predict's disocclusion test (synthesizer.py:447: alpha_ctx.max(dim=3)[0])
         self.alpha_ctx_max = res[3].view(b, tc, tp, hd, wd) if self.keep_alpha_ctx_max else None
         alpha_out = alpha_out.view(b, tw, nl, hd, wd) if alpha_out is not None else None
         return (flow.view(b, tc, tp, 2, hd, wd), (alpha_out if self.fast else None), alpha_out,
-                (alpha_ctx if into_raw else alpha_ctx.view(b, tc, tp, nl, hd, wd)), disocc.view(b, tc, tp, 1, hd, wd))
+                (alpha_ctx if into_raw is not None else alpha_ctx.view(b, tc, tp, nl, hd, wd)),
+                disocc.view(b, tc, tp, 1, hd, wd))
 
-    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=False):
-        # int64 + contiguous ONCE: every op below finds the same tensor object (and its validated range)
+    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None):
+        # int64 + contiguous ONCE for every op below; what earlier launches reported about their indices surfaces here
         ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)
+        self.index_status.check()
         if self.fuse_hd and self._fused_ok([input, occ, obj_alpha, bg_alpha, cls, *grid],
                                            grid[1].shape[2] + 1, input.size(2) - 3):
             no_grad = not (torch.is_grad_enabled() and any(
                 x is not None and x.requires_grad for x in (occ, obj_alpha, bg_alpha, cls, *grid)))
+            raw_ok = into_raw is not None and no_grad and self._frame_warp_fused(input, ctx_ts.size(1), pred_ts.size(0))
             return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only,
-                                    into_raw=into_raw and no_grad and self._frame_warp_fused(input, ctx_ts.size(1),
-                                                                                             pred_ts.size(0)))
+                                    into_raw=into_raw if raw_ok else None)
         self.alpha_ctx_max = None  # (only the fused pass produces it)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
@@ -514,7 +536,9 @@ class Warper(nn.Module):
         ctx_ts = WF.normalise_time_index(ctx_ts)
         self_slot = self.include_self and tp == input.size(1)
         if self._frame_warp_fused(input, tc, tp):
-            return WF.frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=self_slot, eps=eps)
+            st = self.index_status
+            st.check()
+            return WF.frame_warp_fuse(input, flow, alpha, ctx_ts, include_self=self_slot, eps=eps, status=st)
         hd, wd = self.src_shape_hd
         c = input.size(-3)
         samp = self.src_grid_hd + flow.permute(0, 1, 2, 4, 5, 3).reshape(b * tc * tp, hd, wd, 2)
@@ -575,17 +599,16 @@ def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pr
     is a strided VIEW into ``raw_output``'s storage (the reference returns two tensors; the values are the same): an
     in-place write to either shows in the other, and the view keeps the whole buffer alive -- clone it to detach."""
     ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)  # shared by both calls
-    # (without autograd the context alphas are composited straight into raw_output's slots: into_raw)
+    # (without autograd the context alphas are composited straight into raw_output's slots: `slots` receives what
+    # the frame warp needs to know about them)
+    slots = []
     flow, alpha_unflt, alpha, alpha_ctx, disocc = warper._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts,
-                                                                      pred_ts, restrict_to_ctx, into_raw=True)
-    slots = getattr(alpha_ctx, "_waldo_raw", None)
-    try:
-        if slots is not None:
-            slots.vouched = True  # the view goes from the flow pass to the frame warp in this function's hands
+                                                                      pred_ts, restrict_to_ctx, into_raw=slots)
+    if slots:
+        output, raw_output = WF.frame_warp_fuse_raw(input, flow, slots[0], ctx_ts, status=warper.index_status)
+    else:
         output, raw_output = warper.input_to_output(input, alpha_ctx, flow, ctx_ts)
-    finally:
-        if slots is not None:
-            del alpha_ctx._waldo_raw  # the view goes to the caller as a plain tensor, whatever happened above
+    warper.index_status.check()  # (no synchronisation: whatever has been reported by now)
     # (ONE split instead of two slices of `output`: backward is a concatenation of the two gradients, where two
     # SliceBackward nodes each zero-fill a buffer of the full size and autograd adds them)
     output, raw_alpha = torch.split(output, [output.size(2) - 1, 1], dim=2)

@@ -13,6 +13,7 @@ import types
 
 import torch
 
+from .. import functional as WF
 from ..nets import Warper, decode_output, estimate_alpha_grid_occ, flp
 from ..nets.lvd import decoder_tail
 from .utils import get_grid
@@ -55,7 +56,8 @@ class LvdStep:
         self.bg_alpha = torch.ones(1, 1, h, w, device=device)
         # ctx_mode "prev" (synthesizer.py:833-835): every frame is predicted from the one before it
         self.ctx_ts = torch.roll(torch.arange(t, device=device), 1).view(1, 1, t).expand(b, -1, -1).contiguous()
-        self.pred_ts = torch.arange(t, device=device)
+        # (every frame is predicted, in order: an index MARKED as 0 .. T-1 lets time_gather hand out the clip itself)
+        self.pred_ts = WF.arange_index(t, device)
         self.leaves = [self.raw, self.pose_o, self.pose_b, self.score, self.cls_logit]
         self.shape = (b, t, no, lo, lb, ho)
 
