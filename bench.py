@@ -298,11 +298,14 @@ def settle_gpu(step, fence, seconds=SETTLE_SECONDS):
     return round((time.perf_counter() - t0) * 1e3, 1)
 
 
-def timed_blocks(step, fence, steps, dist=None, device=None, backend="nccl", nblocks=TIMED_BLOCKS):
+def timed_blocks(step, fence, steps, dist=None, device=None, backend="nccl", nblocks=TIMED_BLOCKS, between=None):
     """`nblocks` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize (`fence`); returns the
-    blocks' seconds, the MAX over ranks of each.  No events are recorded inside them."""
+    blocks' seconds, the MAX over ranks of each.  No events are recorded inside them.  `between` (untimed) runs before
+    every block."""
     blocks = []
     for _ in range(nblocks):
+        if between is not None:
+            between()
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -392,6 +395,9 @@ def main():
                          "--gpus > 1")
     ap.add_argument("--north-star-config", choices=["C4", "C5"], default="C5",
                     help="recipe of the north_star block's pipeline job (C5 = Cityscapes 512x1024, the north star's)")
+    ap.add_argument("--fresh-inputs-per-block", action="store_true",
+                    help="experiment: free and re-create the workload's tensors before every timed block (does the "
+                         "placement of the buffers explain run-to-run differences of a few per cent?)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -504,11 +510,29 @@ def main():
         fence()
         return time.perf_counter() - t0
 
+    box = {"seed": rank}
+
+    def fresh_inputs():
+        nonlocal layers, pts, occ
+        layers = pts = occ = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        box["seed"] += 1000
+        layers, pts, occ = synth(frames, nl, h, w, device, seed=box["seed"], sigma=args.sigma)
+        if mode == "train":
+            layers.requires_grad_()
+            pts.requires_grad_()
+        for _ in range(3):
+            step()
+
+    for _ in range(3):  # (the interpreter settles first: its full collection is a pause of the launch queue)
+        step()
+    settle_interpreter()
     settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
-    settle_interpreter()
-    blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
+    blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend,
+                          between=fresh_inputs if args.fresh_inputs_per_block else None)
     elapsed = median_block(blocks)
     # the same step with the loss gradient 2 * rgb / N written as ONE elementwise kernel (_SquareMean) instead of
     # autograd's four-pass chain: reported next to the headline, never as it
@@ -833,10 +857,12 @@ def run_lvd(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):  # (the interpreter settles first: its full collection is a pause of the launch queue)
+        step()
+    settle_interpreter()
     settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
-    settle_interpreter()
     blocks_eager = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
     # forward, loss and backward captured ONCE and replayed (the library launches on the current stream and never
     # synchronises; the frame indices are validated by the kernels, in a replay as in an eager call).  The step is ~90
@@ -935,10 +961,12 @@ def run_wif(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):  # (the interpreter settles first: its full collection is a pause of the launch queue)
+        step()
+    settle_interpreter()
     settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
-    settle_interpreter()
     blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
     elapsed = median_block(blocks)
     # the no-grad half alone (what `inpaint` computes before net_ii): its share of the step
@@ -1056,10 +1084,12 @@ def run_pipeline(args, clips, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):  # (the interpreter settles first: its full collection is a pause of the launch queue)
+        step()
+    settle_interpreter()
     settle_ms = settle_gpu(step, fence)
     for _ in range(args.warmup):
         step()
-    settle_interpreter()
     blocks = timed_blocks(step, fence, args.steps, dist, device, args.dist_backend)
     elapsed = median_block(blocks)
     # one GPU, eager line: the same step replayed from ONE HIP graph beside it (the GPU's time without the launch

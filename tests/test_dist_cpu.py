@@ -111,17 +111,45 @@ def test_cpu_budget_is_within_the_affinity_mask():
 
 
 def test_unit_segments_cover_a_block_in_order():
-    from waldo_amd.tools.demo import unit_segments
+    from waldo_amd.tools.demo import rec_unit_order, unit_segments
     for per_clip in (1, 5, 10, 14):
-        for u0 in range(0, 3 * per_clip + 1):
-            for u1 in range(u0, 3 * per_clip + 1):
-                units = []
-                for b0, b1, f0, f1 in unit_segments(u0, u1, per_clip):
-                    assert 0 <= f0 < f1 <= per_clip and b0 < b1
-                    assert b1 - b0 == 1 or (f0, f1) == (0, per_clip)  # several clips only as whole clips
-                    units += [b * per_clip + f for b in range(b0, b1) for f in range(f0, f1)]
-                assert units == list(range(u0, u1)), (per_clip, u0, u1)
-    assert unit_segments(7, 23, 10) == [(0, 1, 7, 10), (1, 2, 0, 10), (2, 3, 0, 3)]
+        for order in (None, rec_unit_order(per_clip, 4)):
+            dealt = list(range(per_clip)) if order is None else order
+            for u0 in range(0, 3 * per_clip + 1):
+                for u1 in range(u0, 3 * per_clip + 1):
+                    units = []
+                    for b0, b1, frames in unit_segments(u0, u1, per_clip, order):
+                        assert frames == sorted(frames) and len(set(frames)) == len(frames) > 0 and b0 < b1
+                        assert set(frames) <= set(range(per_clip))
+                        assert b1 - b0 == 1 or frames == list(range(per_clip))  # several clips only as whole clips
+                        units += [b * per_clip + f for b in range(b0, b1) for f in frames]
+                    want = [(u // per_clip) * per_clip + dealt[u % per_clip] for u in range(u0, u1)]
+                    assert sorted(units) == sorted(want), (per_clip, u0, u1)
+                    if order is None:
+                        assert units == want
+    assert unit_segments(7, 23, 10) == [(0, 1, [7, 8, 9]), (1, 2, list(range(10))), (2, 3, [0, 1, 2])]
+
+
+def test_reconstruction_units_are_dealt_so_that_ranks_invert_the_same_number_of_new_grids():
+    """dealt in frame order, a rank whose block of a clip held no context frame inverted 11 frames'
+    grids, its neighbour 7.  `rec_unit_order` spreads the context frames: over the ranks that share a clip the number
+    of frames beyond the context differs by at most one, and every rank's units still cover the job exactly once."""
+    from waldo_amd.tools.demo import local_unit_ids, rec_unit_order
+    assert rec_unit_order(14, 4) == [13, 12, 11, 0, 10, 9, 1, 8, 7, 6, 2, 5, 4, 3]
+    assert sorted(rec_unit_order(9, 4)) == list(range(9)) and sorted(rec_unit_order(3, 4)) == [0, 1, 2]
+    for b, t, ctx, world in ((4, 14, 4, 8), (8, 9, 4, 8), (4, 14, 4, 4), (1, 14, 4, 2), (2, 14, 4, 3), (1, 9, 4, 5)):
+        ids = [local_unit_ids("rec", b, t, ctx, r, world) for r in range(world)]
+        assert sorted(i for blk in ids for i in blk) == list(range(b * t))
+        new = [len({(i // t, i % t) for i in blk if i % t >= ctx}) for blk in ids if blk]
+        assert max(new) - min(new) <= (1 if (b * t) % world == 0 else t - ctx), (b, t, world, new)
+        pred = [local_unit_ids("pred", b, t, ctx, r, world) for r in range(world)]
+        assert [i for blk in pred for i in blk] == list(range(b * (t - ctx)))  # the prediction stays in frame order
+    c5 = [local_unit_ids("rec", 4, 14, 4, r, 8) for r in range(8)]
+    assert all(len(blk) == 7 and sum(1 for i in blk if i % 14 >= 4) == 5 for blk in c5)
+    # ... and the rank that PREDICTS a clip's early frames reconstructs its late ones: the same distances from the context
+    for r in range(8):
+        far = sorted([i % 14 for i in c5[r] if i % 14 >= 4] + [4 + i % 10 for i in local_unit_ids("pred", 4, 14, 4, r, 8)])
+        assert far == list(range(4, 14)), (r, far)
 
 
 def _gather_predict_worker(rank, world, port, q):
@@ -129,7 +157,7 @@ def _gather_predict_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     from waldo_amd.dist import init_distributed, shard_range
-    from waldo_amd.tools.demo import gather_predict
+    from waldo_amd.tools.demo import gather_predict, local_unit_ids
     init_distributed(backend="gloo")
     b, t, ctx, hd, wd = 2, 7, 4, 3, 5
     tp = t - ctx
@@ -140,11 +168,11 @@ def _gather_predict_worker(rank, world, port, q):
             "pred_flow": torch.rand(b, ctx, tp, 2, hd, wd, generator=torch.Generator().manual_seed(3)),
             "rec_vid": torch.rand(b, t, 3, hd, wd, generator=torch.Generator().manual_seed(4))}
     u0, u1 = shard_range(b * tp, rank, world)
-    r0, r1 = shard_range(b * t, rank, world)
+    rec_ids = torch.tensor(local_unit_ids("rec", b, t, ctx, rank, world))  # (the reconstruction's dealing order)
     local = {"inp_pred_vid": full["inp_pred_vid"][:, ctx:].reshape(b * tp, 3, hd, wd)[u0:u1],
              "pred_disocc": full["pred_disocc"].reshape(b * tp, 1, hd, wd)[u0:u1],
              "pred_flow": full["pred_flow"].permute(0, 2, 1, 3, 4, 5).reshape(b * tp, ctx * 2, hd, wd)[u0:u1],
-             "rec_vid": full["rec_vid"].reshape(b * t, 3, hd, wd)[r0:r1]}
+             "rec_vid": full["rec_vid"].reshape(b * t, 3, hd, wd)[rec_ids]}
     got = gather_predict(local, real_vid, ctx)
     q.put((rank, all(torch.equal(got[k], full[k]) for k in full), sorted(got)))
     dist.barrier()

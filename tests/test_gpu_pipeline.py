@@ -50,20 +50,19 @@ def test_c5_pipeline_one_clip(dev, motion):
         assert torch.equal(out[k], again[k]), k
     # the same predict with the raw-slot short cut switched off (alpha_ctx in a tensor of its own, read and copied by
     # the frame warp): bit for bit the same products
-    into_raw = WF.flow_ctx_warp_into_raw
-    calls = []
+    long_way, calls = WF.frame_warp_fuse, []
 
-    def two_tensor_path(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self, layer_max=False):
+    def counted(*a, **kw):
         calls.append(1)
-        res = WF.flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=layer_max)
-        b, tc, tp = ctx_ts.shape
-        return (res[0], res[1].view(b, tc, tp, *res[1].shape[1:])) + tuple(res[2:])
+        return long_way(*a, **kw)
 
-    WF.flow_ctx_warp_into_raw = two_tensor_path
+    WF.frame_warp_fuse = counted
+    pipe.warper.raw_slots = False
     try:
         plain = pipe()
     finally:
-        WF.flow_ctx_warp_into_raw = into_raw
+        WF.frame_warp_fuse = long_way
+        pipe.warper.raw_slots = True
     assert len(calls) == 2  # reconstruction and prediction both went the long way
     for k in out:
         assert torch.equal(out[k], plain[k]), k
@@ -72,7 +71,7 @@ def test_c5_pipeline_one_clip(dev, motion):
 def test_predict_replays_from_one_hip_graph(dev):
     """The whole hot-path part of predict() -- producers, both Warper.forward calls, both decodes, both WIF fusions,
     ~200 launches -- is capturable into ONE HIP graph (the library launches on the caller's stream and never
-    synchronises; the path's constant tensors live on the device; index validation is skipped during capture) and the
+    synchronises; the path's constant tensors live on the device; the kernels validate the frame indices themselves) and the
     replay has the same bits as the eager call, also after the clip changes."""
     from waldo_amd.graphs import GraphedCall
     from waldo_amd.tools import demo
@@ -93,19 +92,14 @@ def test_predict_replays_from_one_hip_graph(dev):
 
 
 def _assemble(pipe_full, blocks, key):
-    """The ranks' unit blocks of one key, in rank order, shaped as predict() returns that key."""
+    """The ranks' unit blocks of one key, in rank order, shaped as predict() returns that key (what gather_predict does
+    with the all-gathered blocks: the reconstruction's units go back from their dealing order to frame order)."""
     from waldo_amd.tools import demo
     b, t, ctx = pipe_full.clips, pipe_full.frames, pipe_full.ctx_len
     full = torch.cat([blk[key] for blk in blocks], dim=0)
     per_clip = t if key in demo.UNIT_KEYS["rec"] else t - ctx
     assert full.shape[0] == b * per_clip, (key, full.shape)
-    full = full.view(b, per_clip, *full.shape[1:])
-    if key == "pred_flow":
-        hd, wd = full.shape[-2:]
-        return full.view(b, per_clip, -1, 2, hd, wd).permute(0, 2, 1, 3, 4, 5)
-    if key in ("pred_vid", "inp_pred_vid"):
-        return torch.cat([pipe_full.vid[:, :ctx], full], dim=1)
-    return full
+    return demo.units_to_clips(key, full, b, t, ctx, len(blocks), pipe_full.vid)
 
 
 @pytest.mark.parametrize("name,clips,worlds", [("C4", 1, (2, 5, 8)), ("C4", 2, (3, 4)), ("C5", 1, (8,))])

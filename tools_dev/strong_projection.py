@@ -20,21 +20,20 @@ dev = torch.device("cuda:0")
 pipe = pipeline.Pipeline(name, clips, dev, shard=(0, 1))
 
 
-def timeit(fn, n=6):
-    """The better of two blocks of n calls after three warm-up calls (the first block of a new shard shape has shown
+def timeit(fn, n=10):
+    """The median of five blocks of n calls after five warm-up calls (the first block of a new shard shape has shown
     one-off allocator work -- rank 0 of 2: 15 - 18 ms against 11 -- that is no part of a steady step)."""
-    for _ in range(3):
+    for _ in range(5):
         fn()
-    best = None
-    for _ in range(2):
+    ms = []
+    for _ in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
-        best = ms if best is None else min(best, ms)
-    return best
+        ms.append((time.perf_counter() - t0) / n * 1e3)
+    return sorted(ms)[2]
 
 
 res = {"config": name, "clips": clips, "frames": clips * pipe.frames, "worlds": {}}
@@ -51,6 +50,7 @@ with torch.no_grad():
         res["worlds"][world] = {"eager_ms_per_rank": eager, "graph_ms_per_rank": graph}
 t1e, t1g = res["worlds"][1]["eager_ms_per_rank"][0], res["worlds"][1]["graph_ms_per_rank"][0]
 for world, row in res["worlds"].items():
+    row["rank_max_over_min_eager"] = round(max(row["eager_ms_per_rank"]) / min(row["eager_ms_per_rank"]), 3)
     row["projected_speedup_eager"] = round(t1e / max(row["eager_ms_per_rank"]), 2)
     row["projected_speedup_graph"] = round(t1g / max(row["graph_ms_per_rank"]), 2)
     row["projected_speedup_graph_over_eager_1gpu"] = round(t1e / max(row["graph_ms_per_rank"]), 2)

@@ -136,6 +136,9 @@ class Warper(nn.Module):
         self.return_alpha = True
         self.alpha_ctx_max = None
         self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused
+        # decode_output without autograd: the flow pass composites alpha_ctx straight into raw_output's slots (False: into
+        # a tensor of its own that the frame warp reads and copies -- the same bits, for tests)
+        self.raw_slots = True
         self._index_status = None
 
     @property
@@ -388,12 +391,57 @@ class Warper(nn.Module):
             sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1, status=st).reshape(b, tp, h, w, 2), tc)
         return obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w), sgo, sgb
 
-    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None):
+    def _composited_alphas(self, input, grid, occ, obj_alpha, bg_alpha, cls, tw, filt):
+        """First half of the fused flow synthesis (lvd.py:716-766 / 602-652): the rough alphas of frames 0 .. tw - 1 warped
+        to the image, the layout filter's class distribution, and the full-resolution pass that upsamples, filters and
+        composites them.  Returns ``(a01, alpha_out)`` (WF.flow_ctx_alpha).  With ``restrict_to_ctx`` these depend on the
+        CONTEXT frames alone (their grids, frames and occlusion matrices): ``context_products``."""
+        tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
+        b, _, no = src_grid_obj.shape[:3]
+        nl = no + 1
+        h, w = self.src_shape
+        hd, wd = self.src_shape_hd
+        s = int(self.scale_hd)
+        # the rough alphas of the Tw frames that are used (lvd.py:716-722 warps all T and slices: with four contexts of
+        # fourteen frames ten of them for nothing); (x + 1) / 2 folded into the taps
+        ga = grid if tw >= src_grid_obj.size(1) else [None, src_grid_obj[:, :tw], None, src_grid_bg[:, :tw]]
+        alpha = self.layer_to_output(obj_alpha, bg_alpha, ga, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # B Tw L 1 H W
+        dist = None
+        if filt:
+            if s >= 2 and s & (s - 1) == 0 and input.is_cuda and hd % s == 0 and wd % s == 0:
+                lyt = WF.downscale_frames(input, tw, 3, s)  # the same bits in one pass (waldo_downscale_frames_fwd)
+            else:
+                lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
+            dist = self._lyt_dist(alpha, lyt, cls)
+        occ = occ.reshape(b, -1, nl, nl)
+        # (an input of the context frames alone -- _clip_length -- goes with the occlusion matrices of those frames)
+        occ_in = occ if input.size(1) == occ.size(1) else occ[:, :input.size(1)]
+        return WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s,
+                                 want_alpha=self.return_alpha)
+
+    def context_products(self, input, grid, occ, obj_alpha, bg_alpha, cls, num_ctx):
+        """What ``grid_to_flow_ctx`` (``restrict_to_ctx``) computes from the CONTEXT frames alone: the composited
+        full-resolution alphas of frames 0 .. num_ctx - 1.  ``input`` (B, >= num_ctx, C, Hd, Wd), ``grid`` / ``occ`` with
+        at least the context frames on their time axis.  A caller that decodes the same context twice -- the
+        reconstruction and the prediction of ``Synthesizer.predict`` (synthesizer.py:445, 472), or two blocks of one clip's
+        frames on one rank -- computes them once and hands them to ``decode_output(..., ctx_products=...)``; every value
+        depends on its own (b, t) frame only, so the bits are those of the call that computes them itself.
+        Inference only (no gradient flows through the hand-over)."""
+        if not (self.fuse_hd and self._fused_ok([input], grid[1].shape[2] + 1, input.size(2) - 3)):
+            return None
+        with torch.no_grad():
+            g = [x[:, :num_ctx] if x is not None else None for x in grid]
+            oc = occ.reshape(occ.shape[0], -1, *occ.shape[-2:])[:, :num_ctx]
+            return self._composited_alphas(input[:, :num_ctx], g, oc, obj_alpha, bg_alpha, cls, num_ctx, True)
+
+    def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None,
+                    ctx_products=None):
         """_flow_common with the two full-resolution passes fused (csrc/flow_ctx.hip); everything at
         the low resolution goes through the same per-op kernels as the unfused path.  ``into_raw``
         (decode_output, no autograd; a list): alpha_ctx is written into the slots it will occupy in
         input_to_output's ``raw`` tensor and comes back as a view of it; the list receives the ``WF.RawSlots``
-        that ``WF.frame_warp_fuse_raw`` takes (WF.flow_ctx_warp_into_raw)."""
+        that ``WF.frame_warp_fuse_raw`` takes (WF.flow_ctx_warp_into_raw).  ``ctx_products``: ``context_products``'
+        result for the same context (``ctx_only``): the first half is not run again."""
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
         tc, tp = ctx_ts.size(1), pred_ts.size(0)
@@ -404,22 +452,15 @@ class Warper(nn.Module):
         ho, wo = self.tgt_shape
         s = int(self.scale_hd)
         tw = tc if ctx_only else t
-        # the rough alphas of the Tw frames that are used (lvd.py:716-722 warps all T and slices: with four contexts of
-        # fourteen frames ten of them for nothing); (x + 1) / 2 folded into the taps
-        ga = grid if tw >= src_grid_obj.size(1) else [None, src_grid_obj[:, :tw], None, src_grid_bg[:, :tw]]
-        alpha = self.layer_to_output(obj_alpha, bg_alpha, ga, delta_bg=0, delta_obj=0, pre=(0.5, 0.5))  # B Tw L 1 H W
-        dist = None
-        if ctx_only or not self.no_filter:
-            if s >= 2 and s & (s - 1) == 0 and input.is_cuda and hd % s == 0 and wd % s == 0:
-                lyt = WF.downscale_frames(input, tw, 3, s)  # the same bits in one pass (waldo_downscale_frames_fwd)
-            else:
-                lyt = scale(input[:, :tw, 3:], 1 / self.scale_hd)
-            dist = self._lyt_dist(alpha, lyt, cls)
         occ = occ.reshape(b, t, nl, nl)
-        # (an input of the context frames alone -- _clip_length -- goes with the occlusion matrices of those frames)
-        occ_in = occ if input.size(1) == t else occ[:, :input.size(1)]
-        a01, alpha_out = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s,
-                                           want_alpha=self.return_alpha)
+        if ctx_products is not None and ctx_only:
+            a01, alpha_out = ctx_products
+            if tuple(a01.shape) != (b * tw, nl, hd, wd):
+                raise ValueError(f"ctx_products hold alphas of shape {tuple(a01.shape)}, this decode needs "
+                                 f"{(b * tw, nl, hd, wd)}")
+        else:
+            a01, alpha_out = self._composited_alphas(input, grid, occ, obj_alpha, bg_alpha, cls, tw,
+                                                     ctx_only or not self.no_filter)
 
         obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
@@ -453,7 +494,8 @@ class Warper(nn.Module):
                 (alpha_ctx if into_raw is not None else alpha_ctx.view(b, tc, tp, nl, hd, wd)),
                 disocc.view(b, tc, tp, 1, hd, wd))
 
-    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None):
+    def _flow_common(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None,
+                     ctx_products=None):
         # int64 + contiguous ONCE for every op below; what earlier launches reported about their indices surfaces here
         ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)
         self.index_status.check()
@@ -461,9 +503,10 @@ class Warper(nn.Module):
                                            grid[1].shape[2] + 1, input.size(2) - 3):
             no_grad = not (torch.is_grad_enabled() and any(
                 x is not None and x.requires_grad for x in (occ, obj_alpha, bg_alpha, cls, *grid)))
-            raw_ok = into_raw is not None and no_grad and self._frame_warp_fused(input, ctx_ts.size(1), pred_ts.size(0))
+            raw_ok = into_raw is not None and self.raw_slots and no_grad and \
+                self._frame_warp_fused(input, ctx_ts.size(1), pred_ts.size(0))
             return self._flow_fused(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only,
-                                    into_raw=into_raw if raw_ok else None)
+                                    into_raw=into_raw if raw_ok else None, ctx_products=ctx_products if no_grad else None)
         self.alpha_ctx_max = None  # (only the fused pass produces it)
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
@@ -589,7 +632,7 @@ def estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose, bg_pose, occ_
 
 
 def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, restrict_to_ctx=True,
-                  use_disocc=False):
+                  use_disocc=False, ctx_products=None):
     """``LVD.forward(mode="decode_output")`` (lvd.py:141-153): flow / alpha synthesis, frame warp and
     temporal fusion, the ``use_disocc`` concatenation (lvd.py:148-151) and the split of the score
     channel.  Returns ``(output, flow, alpha_unflt, alpha, raw_alpha, raw_output, alpha_ctx)``.
@@ -597,13 +640,16 @@ def decode_output(warper, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pr
     ``input`` holds all T frames as in the reference -- or, with ``restrict_to_ctx`` and no ``include_self``, just the
     context frames the path reads (``Warper._clip_length``).  Without autograd and without ``use_disocc``, ``alpha_ctx``
     is a strided VIEW into ``raw_output``'s storage (the reference returns two tensors; the values are the same): an
-    in-place write to either shows in the other, and the view keeps the whole buffer alive -- clone it to detach."""
+    in-place write to either shows in the other, and the view keeps the whole buffer alive -- clone it to detach.
+    ``ctx_products``: ``Warper.context_products`` of the same context frames (``restrict_to_ctx``, no autograd), computed
+    once by a caller that decodes that context more than once."""
     ctx_ts, pred_ts = WF.normalise_time_index(ctx_ts), WF.normalise_time_index(pred_ts)  # shared by both calls
     # (without autograd the context alphas are composited straight into raw_output's slots: `slots` receives what
     # the frame warp needs to know about them)
     slots = []
     flow, alpha_unflt, alpha, alpha_ctx, disocc = warper._flow_common(input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts,
-                                                                      pred_ts, restrict_to_ctx, into_raw=slots)
+                                                                      pred_ts, restrict_to_ctx, into_raw=slots,
+                                                                      ctx_products=ctx_products)
     if slots:
         output, raw_output = WF.frame_warp_fuse_raw(input, flow, slots[0], ctx_ts, status=warper.index_status)
     else:

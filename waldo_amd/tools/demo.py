@@ -183,45 +183,112 @@ def _block_net(opt, net, b, t, b0, b1, sel, device):
                 cls=net["cls"][b0:b1])
 
 
-def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames):
-    """One decode of predict() (estimate_alpha_grid_occ -> decode_output -> disocclusion test -> WIF fusion,
-    synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (ascending frame numbers: the
-    context frames 0 .. ctx_len - 1 and the frames to decode), producing the frames ``frames`` (a contiguous run of
-    ``sel``).  ``net`` holds the stand-ins' outputs for exactly those clips and frames (_block_net); ``real_input``
-    (nb, >= ctx_len, C, Hd, Wd) at least the context frames.  Returns (output (nb, n, 3, Hd, Wd), disocc (nb, n, 1, Hd,
-    Wd), inpainted (nb, n, 3, Hd, Wd), flow (nb, Tc, n, 2, Hd, Wd)).  Every kernel of the chain works per (b, t)
-    unit (the layout filter's class distribution per clip, over its context frames), so the bits of a frame do not
-    depend on which other frames or clips are decoded beside it (tests/test_gpu_pipeline.py)."""
+class SharedContext:
+    """What the decodes of one step compute from a clip's CONTEXT alone -- the object alphas (decoder tail + padding
+    mask), the context frames' control points, grids, inverted grids and occlusion matrices, and the composited
+    full-resolution context alphas (``Warper.context_products``) -- kept from the first decode for the next one.
+    ``Synthesizer.predict`` runs them once per decode (synthesizer.py:434-445 and 470-472); its second decode receives
+    the context poses "as they came in" (flp.py:275-290), so the products are the same tensors' functions: reused when
+    the stand-ins' outputs and the input frames are the SAME tensor objects, unmodified (identity + version counter),
+    computed afresh otherwise.  Every value depends on its own (b, t) frame, so a decode that reuses them has the bits
+    of one that does not (tests/test_gpu_pipeline.py)."""
+
+    def __init__(self):
+        self.key, self.value, self.held = None, None, ()
+
+    @staticmethod
+    def _key(tensors):
+        return tuple((id(x), None if x.is_inference() else x._version) for x in tensors)
+
+    def get(self, tensors, make):
+        key = self._key(tensors)
+        if self.key != key or any(a is not b for a, b in zip(self.held, tensors)):
+            self.value, self.key, self.held = make(), key, tuple(tensors)  # (held: ids are not recycled meanwhile)
+        return self.value
+
+
+def _points_grids_occ(opt, warper, net, nb, nt):
+    """Pose heads' affine (flp.py:259-273), Warper.forward and compute_occ for the ``nt`` frames of ``net``."""
+    from ..nets.lvd import compute_occ
     no = opt.num_obj
     lo = opt.obj_shape[0] * opt.obj_shape[1]
     lb = opt.latent_shape[0] * opt.latent_shape[1]
-    dev = real_input.device
-    nt, n = len(sel), len(frames)
-    buf = pose_buffers(opt, dev)
-    mask = obj_alpha_mask(opt, dev)
-    bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
-    # pose heads' affine (flp.py:259-273), decoder tail (lvd.py:245-254), then
-    # LVD.forward(mode="estimate_alpha_grid_occ") (lvd.py:126-135)
+    buf = pose_buffers(opt, net["pred_obj_pose"].device)
     obj_pose = flp.obj_pose_to_points(net["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
     bg_pose = flp.bg_pose_to_points(net["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"])
-    obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
-    obj_alpha = obj_alpha.view(nb, no, 1, *obj_alpha.shape[-2:])
-    occ, obj_alpha, bga, grid = estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(nb, nt, no, lo, 2),
-                                                        bg_pose.view(nb, nt, 1, lb, 2), net["occ_score"],
-                                                        obj_alpha_mask=mask)
-    first = sel.index(frames[0])
+    grid = warper(obj_pose.view(nb, nt, no, lo, 2), bg_pose.view(nb, nt, 1, lb, 2))
+    return grid, compute_occ(net["occ_score"])
+
+
+def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, shared=None, shared_key=None):
+    """One decode of predict() (estimate_alpha_grid_occ -> decode_output -> disocclusion test -> WIF fusion,
+    synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (ascending frame numbers: the
+    context frames 0 .. ctx_len - 1 and the frames to decode), producing the frames ``frames`` (ascending, a subset of
+    ``sel``).  ``net`` holds the stand-ins' outputs for exactly those clips and frames (_block_net); ``real_input``
+    (nb, >= ctx_len, C, Hd, Wd) at least the context frames.  ``shared`` (a ``SharedContext``): what depends on the
+    context alone is taken from / left for the other decodes of the step (``shared_key``: the tensors whose identity
+    vouches for it, when ``net`` is a per-block copy of them).  Returns (output (nb, n, 3, Hd, Wd), disocc
+    (nb, n, 1, Hd, Wd), inpainted (nb, n, 3, Hd, Wd), flow (nb, Tc, n, 2, Hd, Wd)).  Every kernel of the chain works
+    per (b, t) unit (the layout filter's class distribution per clip, over its context frames), so the bits of a frame
+    do not depend on which other frames or clips are decoded beside it (tests/test_gpu_pipeline.py)."""
+    no = opt.num_obj
+    dev = real_input.device
+    nt, n = len(sel), len(frames)
+    assert list(sel[:ctx_len]) == list(range(ctx_len)), "the compact time axis starts with the context frames"
+    mask = obj_alpha_mask(opt, dev)
+    bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
+
+    def frames_of(x, lo, hi):  # (nb * nt, ...) -> (nb * (hi - lo), ...)
+        return x.view(nb, nt, *x.shape[1:])[:, lo:hi].reshape(-1, *x.shape[1:])
+
+    def context_part():
+        # decoder tail (lvd.py:245-254) + the alpha arithmetic of estimate_alpha_grid_occ (lvd.py:128-132); the context
+        # frames' part of its Warper.forward and compute_occ (lvd.py:133-134); what decode_output computes from them
+        obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
+        obj_alpha = obj_alpha.view(nb, no, 1, *obj_alpha.shape[-2:])
+        ctx_net = dict(pred_obj_pose=frames_of(net["pred_obj_pose"], 0, ctx_len),
+                       pred_bg_pose=frames_of(net["pred_bg_pose"], 0, ctx_len), occ_score=net["occ_score"][:, :ctx_len])
+        # (estimate_alpha_grid_occ with the context frames' poses: occ, masked object alphas, expanded bg alpha, grids)
+        lo = opt.obj_shape[0] * opt.obj_shape[1]
+        lb = opt.latent_shape[0] * opt.latent_shape[1]
+        buf = pose_buffers(opt, dev)
+        obj_pose = flp.obj_pose_to_points(ctx_net["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+        bg_pose = flp.bg_pose_to_points(ctx_net["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"])
+        occ, obj_alpha, bga, grid = estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(nb, ctx_len, no, lo, 2),
+                                                            bg_pose.view(nb, ctx_len, 1, lb, 2), ctx_net["occ_score"],
+                                                            obj_alpha_mask=mask)
+        prev = warper.return_alpha
+        warper.return_alpha = False
+        try:
+            products = warper.context_products(real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_len)
+        finally:
+            warper.return_alpha = prev
+        return occ, obj_alpha, bga, grid, products
+
+    if shared is not None:
+        key = shared_key if shared_key is not None else (net["raw"], net["pred_obj_pose"], net["pred_bg_pose"],
+                                                          net["occ_score"], net["cls"], real_input)
+        occ_c, obj_alpha, bga, grid_c, products = shared.get(key, context_part)
+    else:
+        occ_c, obj_alpha, bga, grid_c, products = context_part()
+    if nt > ctx_len:  # the frames beyond the context: their control points, grids and occlusion matrices
+        new_net = dict(pred_obj_pose=frames_of(net["pred_obj_pose"], ctx_len, nt),
+                       pred_bg_pose=frames_of(net["pred_bg_pose"], ctx_len, nt), occ_score=net["occ_score"][:, ctx_len:])
+        grid_n, occ_n = _points_grids_occ(opt, warper, new_net, nb, nt - ctx_len)
+        grid = [torch.cat([a, b], dim=1) for a, b in zip(grid_c, grid_n)]
+        occ = torch.cat([occ_c, occ_n], dim=1)
+    else:
+        grid, occ = list(grid_c), occ_c
+    where = [sel.index(f) for f in frames]
 
     def make_ctx_ts():  # synthesizer.py:438-442
         ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
         return WF.normalise_time_index(ts[:, -opt.last_n_ctx:] if opt.last_n_ctx > 0 else ts)
 
-    # the frame indices of a decode, made ONCE per shape and kept (int64, contiguous: as the kernels take them): the
-    # wrappers validate an index tensor against the time axis with one device -> host read per (tensor, version) --
-    # built afresh per call (synthesizer.py:438-444 does, its gather() checks on the device) every decode stopped
-    # the launch queue four times
+    # the frame indices of a decode, made ONCE per shape and kept (int64, contiguous: as the kernels take them): built
+    # afresh per call (synthesizer.py:438-444 does) each would be a small host-to-device copy in the launch queue
     ctx_ts = _cached_by(("ctx_ts", str(dev), ctx_len, nb, n, opt.last_n_ctx), make_ctx_ts)
-    pred_ts = _cached_by(("pred_ts", str(dev), first, n),
-                         lambda: torch.arange(first, first + n, device=dev, dtype=torch.int64))
+    pred_ts = _cached_index(where, dev)
     # decode_output + max_l alpha_ctx, which the fused flow pass produces as a by-product (the warper's switch and its
     # result are restored / cleared afterwards: no state is left on the module)
     prev, prev_alpha = warper.keep_alpha_ctx_max, warper.return_alpha
@@ -229,7 +296,7 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames):
     warper.return_alpha = False  # (`alpha` / `alpha_unflt` are dropped two lines below, as in synthesizer.py:445)
     try:
         output, flow, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
-                                                                     net["cls"], ctx_ts, pred_ts)
+                                                                     net["cls"], ctx_ts, pred_ts, ctx_products=products)
         mx = warper.alpha_ctx_max
     finally:
         warper.keep_alpha_ctx_max, warper.return_alpha = prev, prev_alpha
@@ -257,13 +324,16 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     # that is handed all T frames)
     n_in = t if getattr(opt, "include_self", False) else ctx_len
     real_input = torch.cat([real_vid[:, :n_in], real_lyt[:, :n_in]], dim=2)
-    rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every)
+    # what both decodes compute from the context alone, once (the second decode is handed the same context poses)
+    shared = SharedContext() if not getattr(opt, "include_self", False) else None
+    rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every, shared=shared)
     out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
     if not opt.no_future:
         # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
         # poses as they came in, the future ones predicted (flp.py:275-290) -- here the synthetic poses
         # of all T frames stand for them (synthesizer.py:464-472)
-        pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every[ctx_len:])
+        pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every[ctx_len:],
+                                             shared=shared)
         out["pred_disocc"] = dis
         out["pred_flow"] = flow
         out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred], dim=1)
@@ -271,22 +341,61 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     return out
 
 
-def unit_segments(u0, u1, per_clip):
-    """The (b, t) units u = b * per_clip + f of the block [u0, u1) as runs of clips that decode the SAME frames:
-    [(b0, b1, f0, f1)] in unit order -- a partial first clip, the whole clips in the middle as one batch, a partial
-    last clip."""
+def rec_unit_order(t, ctx_len):
+    """The order in which a clip's T RECONSTRUCTION units are dealt to the ranks (frame numbers).  Two things make units
+    unequal: a frame beyond the context costs its rank a control-point grid and a grid inversion of its own (the context
+    frames' every rank that shares the clip holds anyway), and a frame far from the context is warped further (larger
+    footprint boxes in the frame warp: 1.34 against 1.23 ms per rank and step at the Cityscapes recipe on 8 ranks).
+    Dealt in frame order, the rank that got frames 0 .. 6 of a 14-frame clip inverted 7 frames' grids and its neighbour
+    11, and the neighbour also predicted the five LATE frames.  Here the context frames are spread evenly among the
+    others, and the others are dealt in DESCENDING order: the rank that predicts a clip's early frames (the prediction is
+    dealt in frame order) reconstructs its late ones."""
+    nc = min(ctx_len, t)
+    order, ctx, rest = [], list(range(nc)), list(range(t - 1, nc - 1, -1))
+    for i in range(t):  # (a context frame wherever i * nc / t passes an integer)
+        if ctx and ((i + 1) * nc // t > i * nc // t or not rest):
+            order.append(ctx.pop(0))
+        else:
+            order.append(rest.pop(0))
+    return order
+
+
+def unit_segments(u0, u1, per_clip, order=None):
+    """The units [u0, u1) of a phase's dealing order as runs of clips that decode the SAME frames: [(b0, b1, frames)] --
+    a partial first clip, the whole clips in the middle as one batch, a partial last clip.  Unit u is clip u // per_clip,
+    position u % per_clip of ``order`` (None: the natural order); ``frames`` are clip-relative unit numbers 0 ..
+    per_clip - 1, ASCENDING within a segment -- the order in which ``predict_sharded`` returns them (``local_unit_ids``)."""
+    order = list(range(per_clip)) if order is None else list(order)
     segs, u = [], u0
     while u < u1:
-        b, f = divmod(u, per_clip)
-        if f == 0 and u1 - u >= per_clip:
+        b, i = divmod(u, per_clip)
+        if i == 0 and u1 - u >= per_clip:
             nb = (u1 - u) // per_clip
-            segs.append((b, b + nb, 0, per_clip))
+            segs.append((b, b + nb, list(range(per_clip))))
             u += nb * per_clip
         else:
-            f1 = min(per_clip, f + (u1 - u))
-            segs.append((b, b + 1, f, f1))
-            u += f1 - f
+            i1 = min(per_clip, i + (u1 - u))
+            segs.append((b, b + 1, sorted(order[i:i1])))
+            u += i1 - i
     return segs
+
+
+def phase_order(phase, t, ctx_len):
+    """Dealing order of a phase's per-clip units: reconstruction -> ``rec_unit_order``; prediction -> frame order (every
+    predicted frame costs the same)."""
+    return rec_unit_order(t, ctx_len) if phase == "rec" else list(range(t - ctx_len))
+
+
+def local_unit_ids(phase, b, t, ctx_len, rank, world):
+    """Natural unit numbers (clip * per_clip + clip-relative unit) of the units ``predict_sharded`` returns for this rank
+    and phase, in the order it returns them."""
+    from ..dist import shard_range
+    per_clip = t if phase == "rec" else t - ctx_len
+    u0, u1 = shard_range(b * per_clip, rank, world)
+    ids = []
+    for b0, b1, frames in unit_segments(u0, u1, per_clip, phase_order(phase, t, ctx_len)):
+        ids += [c * per_clip + f for c in range(b0, b1) for f in frames]
+    return ids
 
 
 UNIT_KEYS = {"rec": ("rec_vid", "rec_disocc", "inp_rec_vid"), "pred": ("pred_vid", "pred_disocc", "inp_pred_vid",
@@ -297,14 +406,16 @@ UNIT_KEYS = {"rec": ("rec_vid", "rec_disocc", "inp_rec_vid"), "pred": ("pred_vid
 def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, world, phases=("rec", "pred")):
     """This rank's share of predict() when ONE job (B clips) is split over ``world`` ranks: the
     (b, t) output units of each decode -- B * T reconstructed frames, B * (T - Tc) predicted ones -- are dealt in
-    contiguous blocks (dist.shard_range).  A rank keeps the context frames of the clips its block touches and their
-    stand-in network outputs, runs the producers and Warper.forward for the context frames and ITS frames only (the
-    context part -- Tc of a clip's grids, the layout filter's class distribution, the first occlusion product: 0.8 of
-    C5's 22 ms -- is replicated on every rank that shares the clip, which needs no collective), and decodes its block.
-    Returns {key: (units, C, Hd, Wd)} with the rank's units in order, for the keys of UNIT_KEYS (``pred_vid`` /
-    ``inp_pred_vid``: the predicted frames only; ``pred_flow``: Tc * 2 channels); ``gather_predict`` puts the ranks'
-    blocks together into predict()'s dict.  Reference: the data-parallel split of tools/engine.py:63-64, here over
-    frames instead of clips so that one clip can use every GPU."""
+    contiguous blocks of the phase's dealing order (dist.shard_range over ``phase_order``: the reconstruction's spreads
+    the context frames over the ranks that share a clip, so that every rank inverts the same number of new grids).  A
+    rank keeps the context frames of the clips its block touches and their stand-in network outputs, runs the producers
+    and Warper.forward for the context frames and ITS frames only, and decodes its block; what depends on a clip's
+    context alone (its grids, the layout filter's class distribution, the first occlusion product) is computed ONCE per
+    step and clip range (``SharedContext``) and replicated on every rank that shares the clip, which needs no collective.
+    Returns {key: (units, C, Hd, Wd)} with the rank's units in the order of ``local_unit_ids``, for the keys of UNIT_KEYS
+    (``pred_vid`` / ``inp_pred_vid``: the predicted frames only; ``pred_flow``: Tc * 2 channels); ``gather_predict`` puts
+    the ranks' blocks together into predict()'s dict.  Reference: the data-parallel split of tools/engine.py:63-64, here
+    over frames instead of clips so that one clip can use every GPU."""
     from ..dist import shard_range
     if opt.include_self:
         raise ValueError("predict_sharded: include_self appends the predicted frame itself as a context "
@@ -313,7 +424,8 @@ def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, wo
     dev = real_vid.device
     hd, wd = real_vid.shape[-2:]
     out = {}
-    inputs = {}  # clips b0:b1 -> cat of their context frames and layouts (shared by the phases)
+    inputs, shared = {}, {}  # clips b0:b1 -> cat of their context frames and layouts / their context's products
+    job = (net["raw"], net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], net["cls"])
     for phase in phases:
         if phase == "pred" and opt.no_future:
             continue
@@ -321,14 +433,16 @@ def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, wo
         per_clip = t - first
         u0, u1 = shard_range(b * per_clip, rank, world)
         parts = {k: [] for k in UNIT_KEYS[phase]}
-        for b0, b1, f0, f1 in unit_segments(u0, u1, per_clip):
-            frames = list(range(first + f0, first + f1))
+        for b0, b1, units in unit_segments(u0, u1, per_clip, phase_order(phase, t, ctx_len)):
+            frames = [first + f for f in units]
             sel = sorted(set(range(ctx_len)) | set(frames))
             if (b0, b1) not in inputs:
                 inputs[(b0, b1)] = torch.cat([real_vid[b0:b1, :ctx_len], real_lyt[b0:b1, :ctx_len]], dim=2)
+                shared[(b0, b1)] = SharedContext()
             blk = _block_net(opt, net, b, t, b0, b1, sel, dev)
-            vid, dis, inp, flow = _decode_block(opt, warper, wif, inputs[(b0, b1)], blk, ctx_len, b1 - b0, sel, frames)
-            n = f1 - f0
+            vid, dis, inp, flow = _decode_block(opt, warper, wif, inputs[(b0, b1)], blk, ctx_len, b1 - b0, sel, frames,
+                                                shared=shared[(b0, b1)], shared_key=job + (inputs[(b0, b1)],))
+            n = len(frames)
             parts[phase + "_vid"].append(vid.reshape(-1, 3, hd, wd))
             parts[phase + "_disocc"].append(dis.reshape(-1, 1, hd, wd))
             parts["inp_" + phase + "_vid"].append(inp.reshape(-1, 3, hd, wd))
@@ -343,23 +457,41 @@ def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, wo
     return out
 
 
+def units_to_clips(key, units, b, t, ctx_len, world, real_vid=None):
+    """The ranks' unit blocks of one key, concatenated in rank order (what the all-gather returns), shaped as predict()
+    returns that key: the reconstruction's units go back from dealing order to frame order (one index copy; the
+    prediction's are in frame order already), ``pred_flow`` to (B, Tc, Tp, 2, Hd, Wd), the context frames in front of
+    ``pred_vid`` / ``inp_pred_vid`` (``real_vid``)."""
+    phase = "rec" if key in UNIT_KEYS["rec"] else "pred"
+    per_clip = t if phase == "rec" else t - ctx_len
+    if phase == "rec" and world > 1:
+        ids = [i for r in range(world) for i in local_unit_ids(phase, b, t, ctx_len, r, world)]
+        if ids != list(range(b * per_clip)):
+            natural = torch.empty_like(units)
+            natural[_cached_index(ids, units.device)] = units
+            units = natural
+    full = units.view(b, per_clip, *units.shape[1:])
+    if key == "pred_flow":  # units x (Tc * 2) -> (B, Tc, Tp, 2, Hd, Wd)
+        hd, wd = full.shape[-2:]
+        return full.view(b, per_clip, -1, 2, hd, wd).permute(0, 2, 1, 3, 4, 5).contiguous()
+    if key in ("pred_vid", "inp_pred_vid") and real_vid is not None:
+        return torch.cat([real_vid[:, :ctx_len], full], dim=1)
+    return full
+
+
 def gather_predict(local, real_vid, ctx_len, keys=None, group=None):
-    """All-gather the ranks' blocks of ``predict_sharded`` (one collective per key, dist.all_gather_frames: RCCL over
-    xGMI, or gloo in the tests) and shape them as predict() returns them."""
-    from ..dist import all_gather_frames
+    """All-gather the ranks' blocks of ``predict_sharded`` (one collective per key, ALL issued before the first is waited
+    for -- dist.all_gather_frames_async: RCCL over xGMI, or gloo in the tests) and shape them as predict() returns them."""
+    import torch.distributed as dist
+    from ..dist import all_gather_frames_async
     b, t = real_vid.shape[:2]
-    hd, wd = real_vid.shape[-2:]
-    out = {}
-    for k in (keys or local.keys()):
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    keys = list(keys or local.keys())
+    pending = {}
+    for k in keys:
         per_clip = t if k in UNIT_KEYS["rec"] else t - ctx_len
-        full = all_gather_frames(local[k], b * per_clip, group=group, collective_for_one=False)
-        full = full.view(b, per_clip, *full.shape[1:])
-        if k == "pred_flow":  # units x (Tc * 2) -> (B, Tc, Tp, 2, Hd, Wd)
-            full = full.view(b, per_clip, -1, 2, hd, wd).permute(0, 2, 1, 3, 4, 5).contiguous()
-        elif k in ("pred_vid", "inp_pred_vid"):
-            full = torch.cat([real_vid[:, :ctx_len], full], dim=1)
-        out[k] = full
-    return out
+        pending[k] = all_gather_frames_async(local[k], b * per_clip, group=group)
+    return {k: units_to_clips(k, pending[k].wait(), b, t, ctx_len, world, real_vid) for k in keys}
 
 
 def run(clip_dir, out_dir=None, dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20, frames=6, ctx_len=4, seed=0,

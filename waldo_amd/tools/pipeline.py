@@ -87,7 +87,8 @@ class Pipeline:
         return demo.gather_predict(local, self.vid, self.ctx_len, keys=keys, group=group)
 
     def local_units(self, phase="pred"):
-        """[start, stop) of this rank's (b, t) units of a phase ("rec": B * T, "pred": B * (T - Tc))."""
+        """[start, stop) of this rank's (b, t) units of a phase ("rec": B * T, "pred": B * (T - Tc)) in the phase's
+        dealing order (demo.phase_order: frame order for "pred")."""
         from ..dist import shard_range
         per_clip = self.frames if phase == "rec" else self.frames - self.ctx_len
         rank, world = self.shard if self.shard is not None else (0, 1)
