@@ -1165,7 +1165,10 @@ def run_pipeline(args, clips, world, rank, device, dist):
                                    f"{o.num_obj} objects + background, {o.num_lyt} layout classes; "
                                    f"Synthesizer.predict's call order: reconstruction of all {t} frames and prediction "
                                    f"of the last {tp}; networks outside the path replaced by seeded "
-                                   f"stand-ins (UNet stand-in costs nothing), background motion '{pipe.motion}'",
+                                   f"stand-ins (UNet stand-in costs nothing), background motion '{pipe.motion}'; what the two "
+                                   f"decodes compute from the context alone runs once per step; `alpha` (2a'-1 of the context "
+                                   f"frames, read by net_ii.inpaint with an inpainter only) is "
+                                   f"{'written' if getattr(o, 'use_inpainter', False) else 'NOT produced (use_inpainter off)'}",
                        "frames_per_gpu": clips * t if not strong else round(clips * t / (emulated[1] if emulated else world), 2),
                        "layers": o.num_obj + 1, "height": hd, "width": wd, "parallelism": par},
             "roofline": roof,

@@ -426,15 +426,16 @@ def test_flow_ctx_warp_tile_shapes_agree_with_the_launcher(dev, nl, scale, hw):
     close(amax, ractx.amax(dim=1), what="max")
 
 
-@pytest.mark.parametrize("poison", ["none", "occ", "dist", "logits", "alpha"])
-def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison):
+@pytest.mark.parametrize("poison,ncls", [("none", 20), ("occ", 20), ("dist", 20), ("logits", 20), ("alpha", 20),
+                                         ("none", 21), ("logits", 32), ("none", 5)])
+def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison, ncls):
     """The same short cuts in flow_ctx_alpha_kernel (layers whose upsampled alpha is 0 in all 64 lanes skip their
     filter weight and leave the occlusion product) against the spelled-out expression of lvd.py:731-766, with most
     objects absent from most wavefronts, and with a NaN / inf in the order, the class distributions, the layout
-    logits or the rough alphas."""
+    logits or the rough alphas.  20 classes and fewer run the kFewCls instances of the kernel, 21 .. 32 the kMaxCls ones."""
     import torch.nn.functional as F
     from waldo_amd import functional as WF
-    b, t, tw, nl, ncls, h, w, s = 2, 3, 2, 12, 20, 16, 32, 4
+    b, t, tw, nl, h, w, s = 2, 3, 2, 12, 16, 32, 4
     hd, wd = h * s, w * s
     g = torch.Generator(device=dev).manual_seed(33)
     yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
@@ -690,14 +691,14 @@ def test_frame_warp_fuse(dev, include_self, shape):
     close(raw_f, raw_u, what="raw vs per-op")
 
 
-@pytest.mark.parametrize("amp_px", [10.0, 50.0, 150.0])
-def test_frame_warp_fuse_at_256x512(dev, amp_px):
+@pytest.mark.parametrize("amp_px,tc", [(10.0, 2), (50.0, 2), (150.0, 2), (50.0, 1)])
+def test_frame_warp_fuse_at_256x512(dev, amp_px, tc):
     """input_to_output at a 256 x 512 raster with flows of 10 and 50 px amplitude, smooth over 32-pixel cells (the
     regimes the C4 / C5 pipelines operate in; the small-raster test above cannot leave a tile's neighbourhood), and of
     150 px (neighbouring cells land far apart: the folded warp of the pipelines' `--motion wild`, local stretch up to
     ~10): forward against the oracle in fp32 and fp64, backward (flow and alpha gradients) against its autograd."""
     from waldo_amd import functional as WF
-    b, t, tc, tp, c, nl, hd, wd = 1, 3, 2, 2, 5, 3, 256, 512
+    b, t, tp, c, nl, hd, wd = 1, 3, 2, 5, 3, 256, 512  # (tc = 1: the <1> instances of the forward and backward kernels)
     opt = opt_ns(num_obj=nl - 1, dim=hd, aspect_ratio=2.0, load_dim=hd)
     cfg = WO.WarperCfg.from_opt(opt)
     g = torch.Generator().manual_seed(int(amp_px))
@@ -728,7 +729,7 @@ def test_frame_warp_fuse_at_256x512(dev, amp_px):
     close(a.grad, r32[3], rel=True, what=f"{amp_px} px: grad_alpha", exact=r64[3])
 
 
-@pytest.mark.parametrize("tc,include_self", [(4, False), (2, False), (3, True), (4, True)])
+@pytest.mark.parametrize("tc,include_self", [(4, False), (2, False), (3, True), (4, True), (1, False), (1, True)])
 @pytest.mark.parametrize("hw", [(64, 128), (37, 100), (8, 36), (128, 256)])
 @pytest.mark.parametrize("amp_px", [3.0, 40.0])
 def test_frame_warp_fuse_staged_boxes_same_bits(dev, tc, include_self, hw, amp_px):

@@ -131,8 +131,10 @@ class Warper(nn.Module):
         # ask the fused flow pass for max_l alpha_ctx as a by-product (read it from .alpha_ctx_max after the call)
         self.keep_alpha_ctx_max = False
         # False: the fused flow pass does not write `alpha` / `alpha_unflt` (2 a' - 1 on the Tw frames: as large as
-        # what it keeps) and decode_output returns None for them -- for callers that drop them, as Synthesizer.predict
-        # does (synthesizer.py:445, 472: `rec_output, _, _, _, _, raw_output, alpha_ctx = ...`).  Inference only.
+        # what it keeps) and decode_output returns None for them -- for callers that drop them, as Synthesizer.predict's
+        # reconstruction does (synthesizer.py:445: `rec_output, _, _, _, _, raw_output, alpha_ctx = ...`).  Its
+        # prediction KEEPS `alpha` (synthesizer.py:472) for net_ii.inpaint, which reads it when the inpainter is on
+        # (wif.py:103): leave this True there (tools/demo.py ties it to opt.use_inpainter).  Inference only.
         self.return_alpha = True
         self.alpha_ctx_max = None
         self.fuse_hd = True  # run the full-resolution passes of grid_to_flow[_ctx] / input_to_output fused

@@ -35,7 +35,7 @@ def demo_opt(dim=128, aspect_ratio=1.0, num_obj=3, num_lyt=20, **over):
              scale_factor=2, dim=dim, aspect_ratio=aspect_ratio, load_dim=0, num_perm_grid=1,
              normalize_alpha=False, use_lyt_filtering=True, use_lyt_opacity=False, weight_cls=True,
              min_cls=0.05, include_self=False, no_filter=False, allow_ghost=False, num_lyt=num_lyt,
-             ii_score=True, ii_ab=True, last_n_ctx=0, no_future=False, pad_obj_alpha=2)
+             ii_score=True, ii_ab=True, last_n_ctx=0, no_future=False, pad_obj_alpha=2, use_inpainter=False)
     d.update(over)
     return types.SimpleNamespace(**d)
 
@@ -220,7 +220,8 @@ def _points_grids_occ(opt, warper, net, nb, nt):
     return grid, compute_occ(net["occ_score"])
 
 
-def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, shared=None, shared_key=None):
+def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, shared=None, shared_key=None,
+                  out_alpha=None):
     """One decode of predict() (estimate_alpha_grid_occ -> decode_output -> disocclusion test -> WIF fusion,
     synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (ascending frame numbers: the
     context frames 0 .. ctx_len - 1 and the frames to decode), producing the frames ``frames`` (ascending, a subset of
@@ -235,6 +236,10 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
     dev = real_input.device
     nt, n = len(sel), len(frames)
     assert list(sel[:ctx_len]) == list(range(ctx_len)), "the compact time axis starts with the context frames"
+    # `alpha` (2 a' - 1 on the context frames) is dropped by the reconstruction (synthesizer.py:445) and handed by the
+    # prediction to net_ii.inpaint (synthesizer.py:472, 484), which reads it only with the inpainter on (wif.py:103):
+    # without one the flow pass does not write it (as large as the a' it keeps)
+    want_alpha = bool(getattr(opt, "use_inpainter", False))
     mask = obj_alpha_mask(opt, dev)
     bg_alpha = _cached("bg_alpha", opt, dev, lambda: torch.ones(1, 1, opt.dim, int(opt.dim * opt.aspect_ratio), device=dev))
 
@@ -258,7 +263,7 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
                                                             bg_pose.view(nb, ctx_len, 1, lb, 2), ctx_net["occ_score"],
                                                             obj_alpha_mask=mask)
         prev = warper.return_alpha
-        warper.return_alpha = False
+        warper.return_alpha = want_alpha
         try:
             products = warper.context_products(real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_len)
         finally:
@@ -293,10 +298,10 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
     # result are restored / cleared afterwards: no state is left on the module)
     prev, prev_alpha = warper.keep_alpha_ctx_max, warper.return_alpha
     warper.keep_alpha_ctx_max = True
-    warper.return_alpha = False  # (`alpha` / `alpha_unflt` are dropped two lines below, as in synthesizer.py:445)
+    warper.return_alpha = want_alpha
     try:
-        output, flow, _, _, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
-                                                                     net["cls"], ctx_ts, pred_ts, ctx_products=products)
+        output, flow, _, alpha, _, raw_output, alpha_ctx = decode_output(warper, real_input, grid, occ, obj_alpha, bga,
+                                                                         net["cls"], ctx_ts, pred_ts, ctx_products=products)
         mx = warper.alpha_ctx_max
     finally:
         warper.keep_alpha_ctx_max, warper.return_alpha = prev, prev_alpha
@@ -306,6 +311,8 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
     if mx is None:  # == alpha_ctx.max(dim=3)[0] (NaN-propagating, as torch's), without the fused pass's by-product
         mx = alpha_ctx.amax(dim=3)
     dmax = WF.disocc_test(mx)
+    if out_alpha is not None:
+        out_alpha.append(alpha)
     return output[:, :, :3], dmax.unsqueeze(2), wif(raw_output), flow  # (wif: synthesizer.py:460)
 
 
@@ -332,8 +339,11 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
         # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
         # poses as they came in, the future ones predicted (flp.py:275-290) -- here the synthetic poses
         # of all T frames stand for them (synthesizer.py:464-472)
+        alpha = []
         pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every[ctx_len:],
-                                             shared=shared)
+                                             shared=shared, out_alpha=alpha)
+        if alpha[0] is not None:  # (with opt.use_inpainter: what the prediction hands to net_ii.inpaint, synthesizer.py:484)
+            out["pred_alpha"] = alpha[0]
         out["pred_disocc"] = dis
         out["pred_flow"] = flow
         out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred], dim=1)

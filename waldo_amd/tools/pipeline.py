@@ -114,8 +114,12 @@ class Pipeline:
             lr = m * (nl * 2 + ghost) * hw                      # per-layer flows and object masks, low resolution
             fcw_out = m * (2 + nl + 1 + 1) * hwd                # flow, alpha_ctx, disocc, layer maximum
             add = {
-                # (a01 alone is written: predict drops `alpha` = 2 a01 - 1 and asks the pass not to write it)
-                "waldo_flow_ctx_alpha_fwd": 4 * (b * tc * nl * hw + b * tc * ncls * hwd + b * tc * nl * hwd),
+                # (a01 alone is written: without an inpainter -- opt.use_inpainter, off in the stand-in pipeline --
+                # nothing reads `alpha` = 2 a01 - 1 and the pass is asked not to write it; the pass itself runs ONCE per
+                # step, its result shared by the two decodes: tools/demo.py:SharedContext)
+                "waldo_flow_ctx_alpha_fwd": (4 * (b * tc * nl * hw + b * tc * ncls * hwd
+                                                  + (2 if getattr(o, "use_inpainter", False) else 1) * b * tc * nl * hwd)
+                                             if tp == t else 0),
                 "waldo_flow_ctx_warp_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out),
                 "waldo_flow_ctx_warp_raw_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out + m * hwd),  # + score
                 "waldo_frame_warp_fuse_fwd": 4 * (b * tc * c * hwd + m * (2 + nl) * hwd + b * tp * (c + 1) * hwd
