@@ -12,7 +12,15 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--waldo-lib", default=None,
+                     help="run the suite against another build of the library (a tools_dev/build_variant.py variant)")
+
+
 def pytest_configure(config):
+    if config.getoption("--waldo-lib", default=None):
+        from waldo_amd import _lib
+        _lib.use_library(config.getoption("--waldo-lib"))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "live_ref: differential test against /root/reference (build container only)")
 

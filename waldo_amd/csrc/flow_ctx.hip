@@ -201,7 +201,14 @@ __device__ __forceinline__ float nan_max(float a, float b) { return __builtin_el
 // paid per 256 pixels; timing-only ablations put everything but the gathers, the product and the stores at 5 of the
 // kernel's 7.8 ms per C5 pipeline step.  With R = 4 a 16 x 64 tile stages 6 x 18 cells where four 4 x 64 tiles staged
 // 4 x (3 x 18).
-template <int LP, bool SCORE, int R>
+#ifndef WALDO_FCW_COMPACT_CHUNK
+#define WALDO_FCW_COMPACT_CHUNK 4  // slots whose loads are in flight together
+#endif
+#ifndef WALDO_FCW_COMPACT
+#define WALDO_FCW_COMPACT 0  // > 0 (variant builds only): slots of the per-TILE compact layer list, round 6's bounded experiment --
+                             // bit-identical and 8-13 % SLOWER (tools_dev/dropped/flow_ctx_warp_compact.hip.h); 0: not compiled
+#endif
+template <int LP, bool SCORE, int R, int KS = 0>
 __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R > 1 && LP <= 17) ? 4 : 1)) void flow_ctx_warp_kernel(
     const float* __restrict__ flow_lr, const float* __restrict__ isobj_lr,
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
@@ -249,6 +256,10 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   if (R > 1 && !fits_lds) return;  // (never taken: see the launcher)
   const bool staged = R > 1 ? true : fits_lds;
   bool flow_bad = false;
+#if WALDO_FCW_COMPACT
+  unsigned mine = 0;  // bit l: this thread staged a cell of layer l whose object mask may pass the ghost test
+  __shared__ unsigned wave_bits[kBlock / kWave];
+#endif
   if (staged) {
     // thread = (cell, layer group): kBlock / area groups share the layers of a cell
     const int ngrp = kBlock / area;
@@ -264,16 +275,33 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
         const float* fl = flow_lr + (((int64_t)m * L + lc) * 2) * HW + off;
         f32x4 rec = {fl[0], fl[HW], 0.0f, 0.0f};
         if (nob && lc >= 1) rec[2] = isobj_lr[((int64_t)m * (L - 1) + (lc - 1)) * HW + off];
+#if WALDO_FCW_COMPACT
+        // (a pixel's mask is a convex combination of four cells, rounded: 0.8999 keeps a margin below the test's 0.9;
+        // a NaN cell counts as present)
+        if (KS > 0 && l < L && !(rec[2] <= 0.8999f)) mine |= 1u << l;
+#endif
         flow_bad |= !(fabsf(rec[0]) <= 3.0e38f) | !(fabsf(rec[1]) <= 3.0e38f);
         *reinterpret_cast<f32x4*>(lrimg + cell * G::kCell + 4 * l) = rec;
       }
   }
+#if WALDO_FCW_COMPACT
+  if (KS > 0) {  // the wavefront's OR of `mine`, one word per wavefront (read behind the barrier below)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine |= (unsigned)__shfl_xor((int)mine, d, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_bits[threadIdx.x >> 6] = mine;
+  }
+#endif
   // (the barrier doubles as the vote: a non-finite entry anywhere in the order or in the tile's low-resolution flows
   // switches the skipping below off; a tile whose patch is not staged is not examined: dense)
   const bool dense = WALDO_FCW_SPARSE ? (__syncthreads_or(occ_bad | flow_bad | !staged) != 0) : (__syncthreads(), true);
+  int rr_first = 0;
+#if WALDO_FCW_COMPACT  // (variant builds only: round 6's rejected experiment, tools_dev/dropped/)
+#include "flow_ctx_warp_compact.hip.h"
+#else
   if (x >= Wd) return;
+#endif
 #pragma unroll 1
-  for (int rr = 0; rr < R; ++rr) {
+  for (int rr = rr_first; rr < R; ++rr) {
   const int y = y_first + kHdRows * rr;
   if (y >= Hd) break;
   const int64_t p = (int64_t)y * Wd + x;
@@ -1038,7 +1066,8 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 }
 
 #define WALDO_FCW_LAUNCH(LPV, SC, RV)                                                                          \
-  hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV>), dim3((unsigned)fcw_grid), dim3(kBlock), 0, st,    \
+  hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV, (RV == kFcwRows && kFcwRows > 1 && LPV >= 8 && LPV <= 17) ? WALDO_FCW_COMPACT : 0>), \
+                     dim3((unsigned)fcw_grid), dim3(kBlock), 0, st,                                           \
                      flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc, alpha_max, \
                      status, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
 #define WALDO_FCW_CASE(LPV)                                        \
