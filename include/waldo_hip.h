@@ -254,18 +254,25 @@ int waldo_disocc_test_fwd(const float* layer_max, float* out, int64_t B, int Tc,
  *   ctx_ts   (B,Tc,Tp) int64, pred_ts (Tp) int64, occ (B,T,L,L)
  *   flow (M,2,Hd,Wd), alpha_ctx (M,L,Hd,Wd) in [-1,1], disocc (M,Hd,Wd)      outputs
  * ------------------------------------------------------------------------------------- */
+/* layer_bits, optional (NULL to skip), (B*Tw, Hd, ceil(Wd / 64)) uint32: bit l of word (n, y, s) is set when a01 of
+ * layer l is non-zero (or NaN) somewhere in columns [64 s, 64 s + 64) of row y of frame n -- the first pass's map of
+ * where each layer IS, for the second pass on the path that has no ghost mask (Warper.grid_to_flow, lvd.py:602-705):
+ * waldo_flow_ctx_warp_* skip, per tile, the layers that are absent from every segment the tile's samples can reach. */
 int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const float* dist,
-                             const float* occ, float* a01, float* alpha_out, int B, int T, int Tw,
-                             int L, int Nl, int C, int chan_off, int H, int W, int scale,
+                             const float* occ, float* a01, float* alpha_out, unsigned* layer_bits, int B, int T,
+                             int Tw, int L, int Nl, int C, int chan_off, int H, int W, int scale,
                              waldo_stream_t stream);
 /* alpha_max (M,Hd,Wd), optional (NULL to skip): max over the layers of alpha_ctx -- what
  * Synthesizer.predict's disocclusion test takes from it (models/synthesizer.py:447, `alpha_ctx.max(dim=3)[0]`:
  * a pass over the largest tensor but one of the pipeline, here a by-product of writing it). */
-/* ctx_ts must lie in [0, Tw), pred_ts in [0, T): violations are reported in `status` ("Frame-index status" above). */
+/* ctx_ts must lie in [0, Tw), pred_ts in [0, T): violations are reported in `status` ("Frame-index status" above).
+ * layer_bits, optional: waldo_flow_ctx_alpha_fwd's by-product for the SAME a01 (NULL: every layer is sampled in every
+ * pixel unless the ghost mask excludes it).  The values do not depend on it. */
 int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                             const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                            float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int* status, int B,
-                            int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, waldo_stream_t stream);
+                            float* flow, float* alpha_ctx, float* disocc, float* alpha_max,
+                            const unsigned* layer_bits, int* status, int B, int T, int Tw, int Tc, int Tp, int L,
+                            int H, int W, int scale, waldo_stream_t stream);
 /* The same pass for a caller that runs waldo_frame_warp_fuse_raw_fwd next (LVD.forward(mode="decode_output"),
  * lvd.py:141-153, without autograd): the composited context alphas are written straight into the slots they
  * occupy in A10's `raw` tensor, raw[b, tp, tc, C + l] (lvd.py:846: `raw_output = cat(output, alpha)`), instead of
@@ -276,9 +283,9 @@ int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const f
  * of contexts 0 .. Tc-1 are written.  The reference's alpha_ctx (B,Tc,Tp,L,Hd,Wd) is a strided view of raw. */
 int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                 const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
-                                float* raw, float* score, float* disocc, float* alpha_max, int* status, int B,
-                                int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale, int C, int Tcx,
-                                waldo_stream_t stream);
+                                float* raw, float* score, float* disocc, float* alpha_max,
+                                const unsigned* layer_bits, int* status, int B, int T, int Tw, int Tc, int Tp, int L,
+                                int H, int W, int scale, int C, int Tcx, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A10: Warper.input_to_output (models/nets/lvd.py:830-853): warp of the context frames

@@ -426,6 +426,64 @@ def test_flow_ctx_warp_tile_shapes_agree_with_the_launcher(dev, nl, scale, hw):
     close(amax, ractx.amax(dim=1), what="max")
 
 
+@pytest.mark.parametrize("cfg", [(17, 4, 32, 64, 0.02), (17, 4, 32, 64, 0.5), (12, 2, 40, 72, 0.1), (5, 4, 16, 48, 2.5),
+                                 (8, 3, 24, 40, 0.05)])
+@pytest.mark.parametrize("poison", ["none", "alpha"])
+def test_layer_occupancy_map_skips_absent_layers_exactly(dev, cfg, poison):
+    """The path WITHOUT a ghost mask (Warper.grid_to_flow, lvd.py:602-705: what train_wif.sh runs): the alpha pass leaves
+    `layer_bits` -- per (frame, row, 64-pixel segment) the layers that are non-zero there -- and the flow pass skips, per
+    tile, the layers that are absent from every segment its samples can reach (round 6).  (i) the map is what it says;
+    (ii) every output of the flow pass has the same bits with and without it, for small, large and off-frame flows
+    (a box of several hundred words, a box beyond the frame) and with a NaN in the source alphas (NaN counts as present)."""
+    from waldo_amd import _lib, functional as WF
+    nl, s, h, w, amp = cfg
+    b, t, tw, tc, tp, ncls = 2, 3, 3, 2, 2, 6
+    hd, wd = h * s, w * s
+    g = torch.Generator(device=dev).manual_seed(nl * 7 + s)
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    cy = torch.rand(b * tw, nl, 1, 1, generator=g, device=dev) * h
+    cx = torch.rand(b * tw, nl, 1, 1, generator=g, device=dev) * w
+    alpha_lr = torch.rand(b * tw, nl, h, w, generator=g, device=dev) * (((yy - cy) ** 2 + (xx - cx) ** 2) < 9).float()
+    alpha_lr[:, 0] = 1.0
+    alpha_lr[0, 0, : h // 2] = 0.0                       # (the background absent from half a frame as well)
+    inp = torch.randn(b, t, 3 + ncls, hd, wd, generator=g, device=dev)
+    dist = torch.rand(b, nl - 1, ncls, generator=g, device=dev).softmax(dim=2)
+    occ = torch.rand(b, t, nl, nl, generator=g, device=dev) * 0.5
+    if poison == "alpha":
+        alpha_lr[1, 3, 2, 5] = float("nan")
+    with torch.no_grad():
+        a01, _, bits = WF.flow_ctx_alpha(alpha_lr, inp, dist, occ, tw, 3, s, want_alpha=False, want_bits=True)
+        a01_b, alpha_b = WF.flow_ctx_alpha(alpha_lr, inp, dist, occ, tw, 3, s)
+    assert torch.equal(torch.nan_to_num(a01, nan=7.0), torch.nan_to_num(a01_b, nan=7.0))
+    nseg = (wd + 63) // 64
+    assert bits.shape == (b * tw, hd, nseg) and bits.dtype == torch.int32
+    pad = nseg * 64 - wd
+    nzp = torch.nn.functional.pad((a01 != 0).to(torch.int64), (0, pad)).view(b * tw, nl, hd, nseg, 64).amax(dim=-1)
+    want = (nzp << torch.arange(nl, device=dev).view(1, nl, 1, 1)).sum(dim=1)
+    assert torch.equal(bits.to(torch.int64), want)
+    m = b * tc * tp
+    fl = amp * torch.randn(m, nl, 2, max(h // 8, 1), max(w // 8, 1), generator=g, device=dev)
+    flow_lr = torch.nn.functional.interpolate(fl.view(m * nl, 2, *fl.shape[-2:]), size=(h, w), mode="bilinear").view(m, nl, 2, h, w)
+    ctx_ts = torch.randint(0, tw, (b, tc, tp), generator=g, device=dev)
+    pred_ts = torch.randint(0, t, (tp,), generator=g, device=dev)
+    with torch.no_grad():
+        plain = WF.flow_ctx_warp(flow_lr, None, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True)
+        skipping = WF.flow_ctx_warp(flow_lr, None, a01, ctx_ts, pred_ts, occ, tw, s, layer_max=True, layer_bits=bits)
+        raw_plain = WF.flow_ctx_warp_into_raw(flow_lr, None, a01, ctx_ts, pred_ts, occ, tw, s, 5, False, layer_max=True)
+        raw_skip = WF.flow_ctx_warp_into_raw(flow_lr, None, a01, ctx_ts, pred_ts, occ, tw, s, 5, False, layer_max=True,
+                                             layer_bits=bits)
+    for x, y, name in list(zip(plain, skipping, ("flow", "alpha_ctx", "disocc", "alpha max"))) + \
+            list(zip(raw_plain[:4], raw_skip[:4], ("raw: flow", "raw: alpha_ctx", "raw: disocc", "raw: alpha max"))):
+        assert torch.equal(torch.isnan(x), torch.isnan(y)), f"{name}: NaNs differ"
+        assert torch.equal(torch.nan_to_num(x, nan=7.0), torch.nan_to_num(y, nan=7.0)), name
+    assert torch.equal(raw_plain[4].score.isnan(), raw_skip[4].score.isnan())
+    assert torch.equal(torch.nan_to_num(raw_plain[4].score, nan=7.0), torch.nan_to_num(raw_skip[4].score, nan=7.0))
+    if poison == "none" and amp < 1.0:
+        assert (plain[1] == -1).float().mean() > 0.5    # most layers ARE absent from most pixels: something to skip
+    with pytest.raises(_lib.WaldoHipError, match="layer_bits"):
+        WF.flow_ctx_warp(flow_lr, None, a01, ctx_ts, pred_ts, occ, tw, s, layer_bits=bits[:, :-1].contiguous())
+
+
 @pytest.mark.parametrize("poison,ncls", [("none", 20), ("occ", 20), ("dist", 20), ("logits", 20), ("alpha", 20),
                                          ("none", 21), ("logits", 32), ("none", 5)])
 def test_flow_ctx_alpha_skips_absent_layers_exactly(dev, poison, ncls):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1013
+ABI_VERSION = 1014
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -49,10 +49,10 @@ SIGNATURES = {
     "waldo_pose_affine_fwd": [_c_f] * 5 + [_i64, _int, _flt, _flt, _stream],
     "waldo_pose_affine_bwd": [_c_f] * 6 + [_i64, _int, _flt, _flt, _stream],
     "waldo_disocc_test_fwd": [_c_f, _c_f, _i64, _int, _int, _i64, _stream],
-    "waldo_flow_ctx_alpha_fwd": [_c_f] * 6 + [_int] * 10 + [_stream],
-    "waldo_flow_ctx_warp_fwd": [_c_f] * 11 + [_int] * 9 + [_stream],
+    "waldo_flow_ctx_alpha_fwd": [_c_f] * 7 + [_int] * 10 + [_stream],
+    "waldo_flow_ctx_warp_fwd": [_c_f] * 12 + [_int] * 9 + [_stream],
     "waldo_frame_warp_fuse_fwd": [_c_f] * 7 + [_int] * 9 + [_flt, _stream],
-    "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 12 + [_int] * 11 + [_stream],
+    "waldo_flow_ctx_warp_raw_fwd": [_c_f] * 13 + [_int] * 11 + [_stream],
     "waldo_frame_warp_fuse_raw_fwd": [_c_f] * 7 + [_int] * 9 + [_flt, _stream],
     "waldo_flow_ctx_alpha_bwd": [_c_f] * 10 + [_int] * 10 + [_stream],
     "waldo_flow_ctx_warp_bwd": [_c_f] * 13 + [_int] * 9 + [_stream],

@@ -43,8 +43,8 @@ template <int LP, int NCP>
 __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
     const float* __restrict__ alpha_lr, const float* __restrict__ input,
     const float* __restrict__ dist, const float* __restrict__ occ, float* __restrict__ a01,
-    float* __restrict__ alpha_out, int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W,
-    int scale, int units, int tiles, int nbands) {
+    float* __restrict__ alpha_out, unsigned* __restrict__ layer_bits, int T, int Tw, int L, int Nl, int C, int chan_off,
+    int H, int W, int scale, int units, int tiles, int nbands) {
   const int Hd = H * scale, Wd = W * scale;
   const int64_t HWd = (int64_t)Hd * Wd, HW = (int64_t)H * W;
   int n, x, y;  // n = (b, t) with t < Tw
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
   // padding layers carry alpha 0 (factor exactly 1); branch-free so that the arrays stay in registers.
   // Four columns of the order per step (OccLds), two and two on the packed-fp32 pipe.
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
+  unsigned nz = 0;  // (layer_bits) bit l: a01 of layer l is non-zero (or NaN) in some pixel of this wavefront's row segment
 #pragma unroll
   for (int j = 0; j < LP; j += 4) {
     f32x2_w prd[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
@@ -135,10 +136,16 @@ __global__ __launch_bounds__(kBlock) void flow_ctx_alpha_kernel(
       if (j + k < L) {
         a01[((int64_t)n * L + j + k) * HWd + p] = v;
         if (alpha_out != nullptr) alpha_out[((int64_t)n * L + j + k) * HWd + p] = v * 2.0f - 1.0f;
+        if (layer_bits != nullptr && __ballot(v != 0.0f) != 0ull) nz |= 1u << (j + k);  // (NaN != 0: counts)
       }
     }
     __builtin_amdgcn_sched_barrier(0);  // a quad of columns at a time (bounds the registers)
   }
+  // by-product for the second pass on the path WITHOUT a ghost mask (grid_to_flow, lvd.py:602-705): which layers are
+  // present at all in this 64-pixel row segment -- one word per (frame, row, segment); flow_ctx_warp_kernel ORs the words
+  // its tile's samples can reach and skips the layers that are absent from all of them
+  if (layer_bits != nullptr && (threadIdx.x & (kWave - 1)) == 0)
+    layer_bits[((int64_t)n * Hd + y) * ((Wd + kHdCols - 1) / kHdCols) + (x / kHdCols)] = nz;
 }
 
 // Layout of the staged low-resolution data of one tile (flow_ctx_warp): CELL-major, one 16-byte record per
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
     const float* __restrict__ a01, const int64_t* __restrict__ ctx_ts,
     const int64_t* __restrict__ pred_ts, const float* __restrict__ occ, float* __restrict__ flow,
     float* __restrict__ alpha_ctx, ActxLayout lay, float* __restrict__ score, float* __restrict__ disocc,
-    float* __restrict__ alpha_max, int* __restrict__ status, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
-    int units, int tiles, int nbands) {
+    float* __restrict__ alpha_max, const unsigned* __restrict__ layer_bits, int* __restrict__ status, int T, int Tw, int Tc,
+    int Tp, int L, int H, int W, int scale, int units, int tiles, int nbands) {
   using G = FcwLds<LP, R>;
   typedef float f32x2_w __attribute__((ext_vector_type(2)));
   const int Hd = H * scale, Wd = W * scale;
@@ -256,6 +263,11 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   if (R > 1 && !fits_lds) return;  // (never taken: see the launcher)
   const bool staged = R > 1 ? true : fits_lds;
   bool flow_bad = false;
+  // (layer_bits) the range of the tile's low-resolution flows over all layers: every pixel's upsampled flow is a convex
+  // combination of four of these cells
+  float fx_lo = INFINITY, fx_hi = -INFINITY, fy_lo = INFINITY, fy_hi = -INFINITY;
+  __shared__ float wave_box[kBlock / kWave][4];
+  __shared__ unsigned wave_seen[kBlock / kWave];
 #if WALDO_FCW_COMPACT
   unsigned mine = 0;  // bit l: this thread staged a cell of layer l whose object mask may pass the ghost test
   __shared__ unsigned wave_bits[kBlock / kWave];
@@ -281,8 +293,23 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
         if (KS > 0 && l < L && !(rec[2] <= 0.8999f)) mine |= 1u << l;
 #endif
         flow_bad |= !(fabsf(rec[0]) <= 3.0e38f) | !(fabsf(rec[1]) <= 3.0e38f);
+        if (layer_bits != nullptr) {  // (uniform)
+          fx_lo = fminf(fx_lo, rec[0]), fx_hi = fmaxf(fx_hi, rec[0]);
+          fy_lo = fminf(fy_lo, rec[1]), fy_hi = fmaxf(fy_hi, rec[1]);
+        }
         *reinterpret_cast<f32x4*>(lrimg + cell * G::kCell + 4 * l) = rec;
       }
+  }
+  if (layer_bits != nullptr && staged) {  // (uniform) the wavefront's range, one row of wave_box per wavefront
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      fx_lo = fminf(fx_lo, __shfl_xor(fx_lo, d, kWave)), fx_hi = fmaxf(fx_hi, __shfl_xor(fx_hi, d, kWave));
+      fy_lo = fminf(fy_lo, __shfl_xor(fy_lo, d, kWave)), fy_hi = fmaxf(fy_hi, __shfl_xor(fy_hi, d, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      float* wb = wave_box[threadIdx.x >> 6];
+      wb[0] = fx_lo, wb[1] = fx_hi, wb[2] = fy_lo, wb[3] = fy_hi;
+    }
   }
 #if WALDO_FCW_COMPACT
   if (KS > 0) {  // the wavefront's OR of `mine`, one word per wavefront (read behind the barrier below)
@@ -294,6 +321,50 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
   // (the barrier doubles as the vote: a non-finite entry anywhere in the order or in the tile's low-resolution flows
   // switches the skipping below off; a tile whose patch is not staged is not examined: dense)
   const bool dense = WALDO_FCW_SPARSE ? (__syncthreads_or(occ_bad | flow_bad | !staged) != 0) : (__syncthreads(), true);
+  // ---- the layers PRESENT around this tile's samples (no ghost mask: Warper.grid_to_flow, lvd.py:602-705).  The
+  // first pass left one word per (frame, row, 64-pixel segment) of the context frame's composited alphas: bit l = layer
+  // l is non-zero somewhere in the segment (`layer_bits`).  A sample of this tile lands at pixel + flow with the flow
+  // inside the range of the staged cells (a convex combination; two pixels of margin for its rounding and for the
+  // bilinear footprint), so a layer that is absent from every segment the box [tile + range] touches samples four zero
+  // taps in every pixel: value exactly 0, as if it had been sampled -- its upsampling, taps, gathers and its row and
+  // column of the product are skipped like a layer behind the ghost mask.  One more barrier per tile.  Not examined
+  // (every layer present): tiles that are not staged, a non-finite flow / order entry (`dense`), boxes of more than
+  // 2 * kBlock words.
+  unsigned present = 0xffffffffu;
+  if (layer_bits != nullptr && staged) {  // (uniform)
+    unsigned seen = 0xffffffffu;
+    if (!dense) {
+      const float bx_lo = fminf(fminf(wave_box[0][0], wave_box[1][0]), fminf(wave_box[2][0], wave_box[3][0]));
+      const float bx_hi = fmaxf(fmaxf(wave_box[0][1], wave_box[1][1]), fmaxf(wave_box[2][1], wave_box[3][1]));
+      const float by_lo = fminf(fminf(wave_box[0][2], wave_box[1][2]), fminf(wave_box[2][2], wave_box[3][2]));
+      const float by_hi = fmaxf(fmaxf(wave_box[0][3], wave_box[1][3]), fmaxf(wave_box[2][3], wave_box[3][3]));
+      // grid units -> pixels: (Wd / 2) per unit; the tile's pixels [tx0, tx0 + 63] x [ty0, ty0 + 4 R - 1]
+      const int tx0 = x - (int)(threadIdx.x & (kWave - 1)), ty0 = y_first - (int)(threadIdx.x >> 6);
+      const float hx = 0.5f * (float)Wd, hy = 0.5f * (float)Hd;
+      // (clamped in float first: a wild flow must not overflow the conversion)
+      const int x0 = (int)fmaxf(fminf(floorf(bx_lo * hx) + (float)(tx0 - 2), (float)Wd), -1.0f);
+      const int x1 = (int)fmaxf(fminf(ceilf(bx_hi * hx) + (float)(tx0 + kHdCols + 1), (float)Wd), -1.0f);
+      const int y0 = (int)fmaxf(fminf(floorf(by_lo * hy) + (float)(ty0 - 2), (float)Hd), -1.0f);
+      const int y1 = (int)fmaxf(fminf(ceilf(by_hi * hy) + (float)(ty0 + kHdRows * R + 1), (float)Hd), -1.0f);
+      const int cx0 = max(x0, 0), cx1 = min(x1, Wd - 1), cy0 = max(y0, 0), cy1 = min(y1, Hd - 1);
+      const int nseg = (Wd + kHdCols - 1) / kHdCols;
+      const int s0 = cx0 / kHdCols, ns = cx1 >= cx0 ? cx1 / kHdCols - s0 + 1 : 0, nr = cy1 >= cy0 ? cy1 - cy0 + 1 : 0;
+      const int words = ns * nr;  // (uniform: every input is)
+      if (words <= 2 * kBlock) {
+        seen = 0;
+        const unsigned* lb = layer_bits + ((int64_t)b * Tw + ts) * Hd * nseg;
+        for (int e = (int)threadIdx.x; e < words; e += kBlock) {
+          const int r = e / ns, c = e - r * ns;
+          seen |= lb[(int64_t)(cy0 + r) * nseg + s0 + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) seen |= (unsigned)__shfl_xor((int)seen, d, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_seen[threadIdx.x >> 6] = seen;
+    __syncthreads();
+    present = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_seen[0] | wave_seen[1] | wave_seen[2] | wave_seen[3]));
+  }
   int rr_first = 0;
 #if WALDO_FCW_COMPACT  // (variant builds only: round 6's rejected experiment, tools_dev/dropped/)
 #include "flow_ctx_warp_compact.hip.h"
@@ -372,7 +443,7 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
         bool want;
         if (WALDO_FCW_MASK_FIRST == 2 && LDS) {
           keep[k] = (keep_bits >> l) & 1u;
-          want = l < L && (WALDO_FCW_SPARSE ? ((want_bits >> l) & 1u) != 0 : true);
+          want = l < L && (WALDO_FCW_SPARSE ? ((want_bits & present) >> l & 1u) != 0 : true);
         } else {
           if (LDS) {
             // the mask alone first (four 4-byte reads): most layers stop here
@@ -383,8 +454,9 @@ __global__ __launch_bounds__(kBlock, (R > 1 && LP <= 12) ? WALDO_FCW_WAVES : ((R
             g = up_sample(isobj_lr + ((int64_t)m * (L - 1) + max(min(l, L - 1) - 1, 0)) * HW, ut);
           }
           keep[k] = !(masked && !(g > 0.9f));
-          // a padding layer (l >= L) is never sampled: its alpha is 0 by definition
-          want = l < L && (WALDO_FCW_SPARSE ? __ballot(keep[k]) != 0ull : true);
+          // a padding layer (l >= L) is never sampled: its alpha is 0 by definition; nor is a layer that is absent from
+          // every segment this tile's samples can reach (`present`)
+          want = l < L && (WALDO_FCW_SPARSE ? (__ballot(keep[k]) != 0ull && ((present >> l) & 1u) != 0) : true);
         }
         if (want || ((dense || WALDO_FCW_MASK_FIRST == 0) && l < L)) {  // (dense: the flow of every layer, its product with alpha 0 may be NaN)
           if (LDS) {
@@ -1022,8 +1094,8 @@ using namespace waldo;
     break;
 
 extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* input, const float* dist,
-                                        const float* occ, float* a01, float* alpha_out, int B, int T,
-                                        int Tw, int L, int Nl, int C, int chan_off, int H, int W,
+                                        const float* occ, float* a01, float* alpha_out, unsigned* layer_bits, int B,
+                                        int T, int Tw, int L, int Nl, int C, int chan_off, int H, int W,
                                         int scale, waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tw;
   int rc = check_flow_ctx("waldo_flow_ctx_alpha_fwd", N, L, H, W, scale);
@@ -1046,12 +1118,12 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   case LPV:                                                                                                              \
     if (dist == nullptr || Nl <= kFewCls)                                                                                \
       hipLaunchKernelGGL((flow_ctx_alpha_kernel<LPV, kFewCls>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,   \
-                         alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, (int)N,     \
-                         geom.tiles, geom.nbands);                                                                       \
+                         alpha_lr, input, dist, occ, a01, alpha_out, layer_bits, T, Tw, L, Nl, C, chan_off, H, W, scale, \
+                         (int)N, geom.tiles, geom.nbands);                                                               \
     else                                                                                                                 \
       hipLaunchKernelGGL((flow_ctx_alpha_kernel<LPV, kMaxCls>), dim3((unsigned)hd_grid(N, geom)), dim3(kBlock), 0, st,   \
-                         alpha_lr, input, dist, occ, a01, alpha_out, T, Tw, L, Nl, C, chan_off, H, W, scale, (int)N,     \
-                         geom.tiles, geom.nbands);                                                                       \
+                         alpha_lr, input, dist, occ, a01, alpha_out, layer_bits, T, Tw, L, Nl, C, chan_off, H, W, scale, \
+                         (int)N, geom.tiles, geom.nbands);                                                               \
     break;
   switch (flow_ctx_pad_l(L)) {
     WALDO_FCA_CASE(4)
@@ -1069,7 +1141,7 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
   hipLaunchKernelGGL((flow_ctx_warp_kernel<LPV, SC, RV, (RV == kFcwRows && kFcwRows > 1 && LPV >= 8 && LPV <= 17) ? WALDO_FCW_COMPACT : 0>), \
                      dim3((unsigned)fcw_grid), dim3(kBlock), 0, st,                                           \
                      flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow, alpha_ctx, lay, score, disocc, alpha_max, \
-                     status, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
+                     layer_bits, status, T, Tw, Tc, Tp, L, H, W, scale, (int)N, geom.tiles, geom.nbands)
 #define WALDO_FCW_CASE(LPV)                                        \
   case LPV:                                                       \
     if (rows == 1) {                                              \
@@ -1087,8 +1159,8 @@ extern "C" int waldo_flow_ctx_alpha_fwd(const float* alpha_lr, const float* inpu
 static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const float* isobj_lr, const float* a01,
                                 const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ, float* flow,
                                 float* alpha_ctx, ActxLayout lay, float* score, float* disocc, float* alpha_max,
-                                int* status, int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
-                                waldo_stream_t stream) {
+                                const unsigned* layer_bits, int* status, int B, int T, int Tw, int Tc, int Tp, int L,
+                                int H, int W, int scale, waldo_stream_t stream) {
   const int64_t N = (int64_t)B * Tc * Tp;
   int rc = check_flow_ctx(fn, N, L, H, W, scale);
   if (rc) return rc;
@@ -1137,21 +1209,22 @@ static int flow_ctx_warp_launch(const char* fn, const float* flow_lr, const floa
 
 extern "C" int waldo_flow_ctx_warp_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                        const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
-                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max, int* status,
-                                       int B, int T, int Tw, int Tc, int Tp, int L, int H, int W, int scale,
-                                       waldo_stream_t stream) {
+                                       float* flow, float* alpha_ctx, float* disocc, float* alpha_max,
+                                       const unsigned* layer_bits, int* status, int B, int T, int Tw, int Tc, int Tp,
+                                       int L, int H, int W, int scale, waldo_stream_t stream) {
   const int64_t plane = (int64_t)H * scale * W * scale;
   const ActxLayout lay = {(int64_t)Tc * Tp * L * plane, (int64_t)Tp * L * plane, (int64_t)L * plane};
   return flow_ctx_warp_launch("waldo_flow_ctx_warp_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
-                              alpha_ctx, lay, nullptr, disocc, alpha_max, status, B, T, Tw, Tc, Tp, L, H, W, scale,
-                              stream);
+                              alpha_ctx, lay, nullptr, disocc, alpha_max, layer_bits, status, B, T, Tw, Tc, Tp, L, H, W,
+                              scale, stream);
 }
 
 extern "C" int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* isobj_lr, const float* a01,
                                            const int64_t* ctx_ts, const int64_t* pred_ts, const float* occ,
                                            float* flow, float* raw, float* score, float* disocc,
-                                           float* alpha_max, int* status, int B, int T, int Tw, int Tc, int Tp,
-                                           int L, int H, int W, int scale, int C, int Tcx, waldo_stream_t stream) {
+                                           float* alpha_max, const unsigned* layer_bits, int* status, int B, int T,
+                                           int Tw, int Tc, int Tp, int L, int H, int W, int scale, int C, int Tcx,
+                                           waldo_stream_t stream) {
   if (C < 1 || Tcx < Tc || Tcx > Tc + 1 || !raw || !score) {
     set_error("waldo_flow_ctx_warp_raw_fwd: bad raw layout C=%d Tc'=%d for Tc=%d (need C >= 1, Tc <= Tc' <= Tc + 1, "
               "raw and score)", C, Tcx, Tc);
@@ -1160,8 +1233,8 @@ extern "C" int waldo_flow_ctx_warp_raw_fwd(const float* flow_lr, const float* is
   const int64_t plane = (int64_t)H * scale * W * scale, ctx = (int64_t)(C + L) * plane;
   const ActxLayout lay = {(int64_t)Tp * Tcx * ctx, ctx, (int64_t)Tcx * ctx};
   return flow_ctx_warp_launch("waldo_flow_ctx_warp_raw_fwd", flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, flow,
-                              raw + (int64_t)C * plane, lay, score, disocc, alpha_max, status, B, T, Tw, Tc, Tp, L,
-                              H, W, scale, stream);
+                              raw + (int64_t)C * plane, lay, score, disocc, alpha_max, layer_bits, status, B, T, Tw, Tc,
+                              Tp, L, H, W, scale, stream);
 }
 
 static int frame_warp_fuse_launch(const char* fn, const float* input, const float* flow, const float* alpha,

@@ -741,7 +741,7 @@ class _FlowCtxAlpha(torch.autograd.Function):
         out = alpha_lr.new_empty(n, nl, hd, wd)
         with _lib.on_device(alpha_lr.device):
             _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist),
-                      _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), b, t, tw, nl, ncls, c, chan_off, h, w,
+                      _lib.ptr(occ), _lib.ptr(a01), _lib.ptr(out), None, b, t, tw, nl, ncls, c, chan_off, h, w,
                       scale, _lib.current_stream(alpha_lr.device))
         ctx.save_for_backward(alpha_lr, input, dist, occ)
         ctx.cfg = (tw, chan_off, scale)
@@ -773,14 +773,17 @@ class _FlowCtxAlpha(torch.autograd.Function):
         return g_lr, None, g_dist, g_occ, None, None, None
 
 
-def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale, want_alpha=True):
+def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale, want_alpha=True, want_bits=False):
     """Upsampling + layout filter + first occlusion product (models/nets/lvd.py:731-766).
     alpha_lr (B*Tw, L, H, W) in [0, 1]; input (B, T, C, Hd, Wd) with the layout logits in channels
     [chan_off, chan_off + Nl); dist (B, L-1, Nl) or None (no filter); occ (B, T, L, L).
     Returns (a01, alpha) of shape (B*Tw, L, Hd, Wd): the composited alpha in [0, 1] and 2a - 1.
     Differentiable w.r.t. alpha_lr, dist and occ (the frames / layouts in ``input`` are data).
-    ``want_alpha=False`` (no autograd): ``alpha`` is not written and comes back as None -- ``Synthesizer.predict``
-    drops it (synthesizer.py:445, 472), and it is as large as ``a01``."""
+    ``want_alpha=False`` (no autograd): ``alpha`` is not written and comes back as None -- ``Synthesizer.predict``'s
+    reconstruction drops it (synthesizer.py:445), and it is as large as ``a01``.
+    ``want_bits`` (no autograd): a third result, ``layer_bits`` (B*Tw, Hd, ceil(Wd / 64)) int32 -- bit l of a word: layer
+    l of ``a01`` is non-zero somewhere in that 64-pixel row segment -- for ``flow_ctx_warp(..., layer_bits=...)`` on the
+    path without a ghost mask (``Warper.grid_to_flow``)."""
     _lib.check_cuda(alpha_lr, input, occ)
     alpha_lr, input, occ = _c(alpha_lr), _c(input.detach()), _c(occ)
     n, nl, h, w = alpha_lr.shape
@@ -793,20 +796,25 @@ def flow_ctx_alpha(alpha_lr, input, dist, occ, tw, chan_off, scale, want_alpha=T
         dist = _c(dist)
         if tuple(dist.shape[:2]) != (b, nl - 1):
             raise _lib.WaldoHipError(f"flow_ctx_alpha: dist {tuple(dist.shape)} is not (B, L-1, Nl)")
-    if not want_alpha and not (torch.is_grad_enabled() and (alpha_lr.requires_grad or occ.requires_grad or
-                                                               (dist is not None and dist.requires_grad))):
+    no_grad = not (torch.is_grad_enabled() and (alpha_lr.requires_grad or occ.requires_grad or
+                                                (dist is not None and dist.requires_grad)))
+    if no_grad and (not want_alpha or want_bits):
         a01 = alpha_lr.new_empty(n, nl, hd, wd)
+        alpha = alpha_lr.new_empty(n, nl, hd, wd) if want_alpha else None
+        bits = torch.empty(n, hd, (wd + 63) // 64, dtype=torch.int32, device=alpha_lr.device) if want_bits else None
         with _lib.on_device(alpha_lr.device):
             _lib.call("waldo_flow_ctx_alpha_fwd", _lib.ptr(alpha_lr), _lib.ptr(input), _lib.ptr(dist), _lib.ptr(occ),
-                      _lib.ptr(a01), None, b, t, tw, nl, dist.shape[2] if dist is not None else 0, c, chan_off, h, w,
-                      scale, _lib.current_stream(alpha_lr.device))
-        return a01, None
-    return _FlowCtxAlpha.apply(alpha_lr, input, dist, occ, tw, chan_off, scale)
+                      _lib.ptr(a01), _lib.ptr(alpha), _lib.ptr(bits), b, t, tw, nl,
+                      dist.shape[2] if dist is not None else 0, c, chan_off, h, w, scale,
+                      _lib.current_stream(alpha_lr.device))
+        return (a01, alpha, bits) if want_bits else (a01, alpha)
+    res = _FlowCtxAlpha.apply(alpha_lr, input, dist, occ, tw, chan_off, scale)
+    return (*res, None) if want_bits else res
 
 
 class _FlowCtxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max, status_ptr):
+    def forward(ctx, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max, status_ptr, bits_ptr=None):
         m, nl, _, h, w = flow_lr.shape
         b, tc, tp = ctx_ts.shape
         t = occ.shape[1]
@@ -818,8 +826,8 @@ class _FlowCtxWarp(torch.autograd.Function):
         with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(alpha_ctx),
-                      _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, status_ptr, b, t, tw, tc, tp, nl, h, w,
-                      scale, _lib.current_stream(flow_lr.device))
+                      _lib.ptr(disocc), _lib.ptr(amax) if layer_max else None, bits_ptr, status_ptr, b, t, tw, tc, tp, nl,
+                      h, w, scale, _lib.current_stream(flow_lr.device))
         ctx.save_for_backward(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ)
         ctx.cfg = (tw, scale)
         ctx.mark_non_differentiable(amax)
@@ -845,7 +853,7 @@ class _FlowCtxWarp(torch.autograd.Function):
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(g_flow), _lib.ptr(g_actx),
                       _lib.ptr(g_dis), _lib.ptr(g_lr), _lib.ptr(g_a01), _lib.ptr(g_occ), _lib.ptr(ws), b, t, tw,
                       tc, tp, nl, h, w, scale, _lib.current_stream(flow_lr.device))
-        return g_lr, None, g_a01, None, None, g_occ, None, None, None, None
+        return g_lr, None, g_a01, None, None, g_occ, None, None, None, None, None
 
 
 def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale):
@@ -870,7 +878,20 @@ def _flow_ctx_warp_args(fn, flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sc
     return flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ
 
 
-def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False, status=None):
+def _layer_bits_ptr(fn, layer_bits, a01):
+    """``flow_ctx_alpha(..., want_bits=True)``'s map for this very ``a01`` (shape-checked), or NULL."""
+    if layer_bits is None:
+        return None
+    n, _, hd, wd = a01.shape
+    if not layer_bits.is_cuda or layer_bits.dtype != torch.int32 or not layer_bits.is_contiguous() or \
+            tuple(layer_bits.shape) != (n, hd, (wd + 63) // 64):
+        raise _lib.WaldoHipError(f"{fn}: layer_bits {tuple(layer_bits.shape)} {layer_bits.dtype} is not the int32 "
+                                 f"(B*Tw, Hd, ceil(Wd / 64)) map of a01 {tuple(a01.shape)}")
+    return layer_bits.data_ptr()
+
+
+def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer_max=False, status=None,
+                  layer_bits=None):
     """Context-alpha warp + ghost mask + disocclusion + second occlusion product + flow compositing
     (models/nets/lvd.py:784-818).  flow_lr (B*Tc*Tp, L, 2, H, W); isobj_lr (B*Tc*Tp, L-1, H, W) or None;
     a01 (B*Tw, L, Hd, Wd) from flow_ctx_alpha; ctx_ts (B, Tc, Tp) long; pred_ts (Tp) long;
@@ -879,12 +900,15 @@ def flow_ctx_warp(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, layer
     carries no gradient, as in the reference).  ``layer_max``: a fourth result, ``alpha_ctx.amax(dim=1)``
     (M, Hd, Wd) -- what Synthesizer.predict's disocclusion test computes from alpha_ctx (synthesizer.py:447) --
     as a by-product (no gradient).  ``ctx_ts`` must lie in [0, tw), ``pred_ts`` in [0, T): validated on the device
-    (``status``: the caller's ``_lib.IndexStatus``, checked when the caller chooses; None: checked before returning)."""
+    (``status``: the caller's ``_lib.IndexStatus``, checked when the caller chooses; None: checked before returning).
+    ``layer_bits``: ``flow_ctx_alpha(..., want_bits=True)``'s map for this ``a01`` -- without a ghost mask it lets the
+    pass skip, per tile, the layers that are absent wherever the tile samples; the values do not depend on it."""
     flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ = _flow_ctx_warp_args("flow_ctx_warp", flow_lr, isobj_lr, a01, ctx_ts,
                                                                        pred_ts, occ, tw, scale)
     st, strict = _status(status)
     flow, alpha_ctx, disocc, amax = _FlowCtxWarp.apply(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale,
-                                                       bool(layer_max), st.ptr)
+                                                       bool(layer_max), st.ptr,
+                                                       _layer_bits_ptr("flow_ctx_warp", layer_bits, a01))
     if strict:
         st.check(sync=True)
     return (flow, alpha_ctx, disocc, amax) if layer_max else (flow, alpha_ctx, disocc)
@@ -900,7 +924,7 @@ class RawSlots:
 
 
 def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, scale, channels, include_self,
-                           layer_max=False, status=None):
+                           layer_max=False, status=None, layer_bits=None):
     """``flow_ctx_warp`` for the caller that runs ``frame_warp_fuse_raw`` on the result next
     (LVD.forward(mode="decode_output"), lvd.py:141-153), WITHOUT autograd: ``alpha_ctx`` is written straight
     into the alpha slots of input_to_output's ``raw`` tensor (lvd.py:846) and returned as a strided
@@ -926,8 +950,9 @@ def flow_ctx_warp_into_raw(flow_lr, isobj_lr, a01, ctx_ts, pred_ts, occ, tw, sca
         with _lib.on_device(flow_lr.device):
             _lib.call("waldo_flow_ctx_warp_raw_fwd", _lib.ptr(flow_lr), _lib.ptr(isobj_lr), _lib.ptr(a01),
                       _lib.ptr(ctx_ts), _lib.ptr(pred_ts), _lib.ptr(occ), _lib.ptr(flow), _lib.ptr(raw),
-                      _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax), st.ptr, b, t, tw, tc, tp, nl, h, w, scale,
-                      int(channels), tcx, _lib.current_stream(flow_lr.device))
+                      _lib.ptr(score), _lib.ptr(disocc), _lib.ptr(amax),
+                      _layer_bits_ptr("flow_ctx_warp_into_raw", layer_bits, a01), st.ptr, b, t, tw, tc, tp, nl, h, w,
+                      scale, int(channels), tcx, _lib.current_stream(flow_lr.device))
         alpha_ctx = raw[:, :, :tc, channels:].permute(0, 2, 1, 3, 4, 5)  # (B, Tc, Tp, L, Hd, Wd), strided
     if strict:
         st.check(sync=True)

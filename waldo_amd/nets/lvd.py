@@ -141,6 +141,9 @@ class Warper(nn.Module):
         # decode_output without autograd: the flow pass composites alpha_ctx straight into raw_output's slots (False: into
         # a tensor of its own that the frame warp reads and copies -- the same bits, for tests)
         self.raw_slots = True
+        # on the paths without a ghost mask the alpha pass maps where each layer is and the flow pass skips the layers that
+        # are absent around a tile's samples (WF.flow_ctx_alpha(want_bits=True)); False: every layer in every pixel
+        self.layer_occupancy = True
         self._index_status = None
 
     @property
@@ -393,10 +396,10 @@ class Warper(nn.Module):
             sgb = TimeRepeat(WF.time_gather(src_grid_bg, None, pred_ts, num_ctx=1, status=st).reshape(b, tp, h, w, 2), tc)
         return obj_flow.reshape(b * tc, tp, no, 2, ho, wo), bg_flow.reshape(b * tc, tp, 2, h, w), sgo, sgb
 
-    def _composited_alphas(self, input, grid, occ, obj_alpha, bg_alpha, cls, tw, filt):
+    def _composited_alphas(self, input, grid, occ, obj_alpha, bg_alpha, cls, tw, filt, want_bits):
         """First half of the fused flow synthesis (lvd.py:716-766 / 602-652): the rough alphas of frames 0 .. tw - 1 warped
         to the image, the layout filter's class distribution, and the full-resolution pass that upsamples, filters and
-        composites them.  Returns ``(a01, alpha_out)`` (WF.flow_ctx_alpha).  With ``restrict_to_ctx`` these depend on the
+        composites them.  Returns ``(a01, alpha_out, layer_bits)`` (WF.flow_ctx_alpha; ``layer_bits`` None with autograd).  With ``restrict_to_ctx`` these depend on the
         CONTEXT frames alone (their grids, frames and occlusion matrices): ``context_products``."""
         tgt_grid_obj, src_grid_obj, tgt_grid_bg, src_grid_bg = grid
         b, _, no = src_grid_obj.shape[:3]
@@ -418,8 +421,11 @@ class Warper(nn.Module):
         occ = occ.reshape(b, -1, nl, nl)
         # (an input of the context frames alone -- _clip_length -- goes with the occlusion matrices of those frames)
         occ_in = occ if input.size(1) == occ.size(1) else occ[:, :input.size(1)]
-        return WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s,
-                                 want_alpha=self.return_alpha)
+        # (want_bits: where each layer IS in the composited alphas -- the second pass's substitute for the ghost mask,
+        # asked for on the paths that have none)
+        res = WF.flow_ctx_alpha(alpha.reshape(b * tw, nl, h, w), input, dist, occ_in, tw, 3, s,
+                                want_alpha=self.return_alpha, want_bits=want_bits)
+        return res if want_bits else (*res, None)
 
     def context_products(self, input, grid, occ, obj_alpha, bg_alpha, cls, num_ctx):
         """What ``grid_to_flow_ctx`` (``restrict_to_ctx``) computes from the CONTEXT frames alone: the composited
@@ -434,7 +440,8 @@ class Warper(nn.Module):
         with torch.no_grad():
             g = [x[:, :num_ctx] if x is not None else None for x in grid]
             oc = occ.reshape(occ.shape[0], -1, *occ.shape[-2:])[:, :num_ctx]
-            return self._composited_alphas(input[:, :num_ctx], g, oc, obj_alpha, bg_alpha, cls, num_ctx, True)
+            return self._composited_alphas(input[:, :num_ctx], g, oc, obj_alpha, bg_alpha, cls, num_ctx, True,
+                                           bool(self.allow_ghost and self.layer_occupancy))
 
     def _flow_fused(self, input, grid, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts, ctx_only, into_raw=None,
                     ctx_products=None):
@@ -456,13 +463,15 @@ class Warper(nn.Module):
         tw = tc if ctx_only else t
         occ = occ.reshape(b, t, nl, nl)
         if ctx_products is not None and ctx_only:
-            a01, alpha_out = ctx_products
+            a01, alpha_out, layer_bits = ctx_products
             if tuple(a01.shape) != (b * tw, nl, hd, wd):
                 raise ValueError(f"ctx_products hold alphas of shape {tuple(a01.shape)}, this decode needs "
                                  f"{(b * tw, nl, hd, wd)}")
         else:
-            a01, alpha_out = self._composited_alphas(input, grid, occ, obj_alpha, bg_alpha, cls, tw,
-                                                     ctx_only or not self.no_filter)
+            a01, alpha_out, layer_bits = self._composited_alphas(input, grid, occ, obj_alpha, bg_alpha, cls, tw,
+                                                                 ctx_only or not self.no_filter,
+                                                                 self.layer_occupancy and s >= 2 and
+                                                                 not (ctx_only and not self.allow_ghost))
 
         obj_flow, bg_flow, sgo, sgb = self._layer_flows(grid, ctx_ts, pred_ts)
         gridp = [None, sgo, None, sgb]
@@ -483,11 +492,13 @@ class Warper(nn.Module):
         if into_raw is not None:
             res = WF.flow_ctx_warp_into_raw(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts,
                                             occ, tw, s, input.size(2), self.include_self and tp == t,
-                                            layer_max=self.keep_alpha_ctx_max, status=self.index_status)
+                                            layer_max=self.keep_alpha_ctx_max, status=self.index_status,
+                                            layer_bits=layer_bits if is_obj is None else None)
             into_raw.append(res[4])
         else:
             res = WF.flow_ctx_warp(flow_lr.reshape(b * tc * tp, nl, 2, h, w), is_obj, a01, ctx_ts, pred_ts, occ, tw, s,
-                                   layer_max=self.keep_alpha_ctx_max, status=self.index_status)
+                                   layer_max=self.keep_alpha_ctx_max, status=self.index_status,
+                                   layer_bits=layer_bits if is_obj is None else None)
         flow, alpha_ctx, disocc = res[:3]
         # by-product for Synthesizer.predict's disocclusion test (synthesizer.py:447: alpha_ctx.max(dim=3)[0])
         self.alpha_ctx_max = res[3].view(b, tc, tp, hd, wd) if self.keep_alpha_ctx_max else None
