@@ -169,7 +169,7 @@ def _cached_index(values, device):
 
 def _block_net(opt, net, b, t, b0, b1, sel, device):
     """The stand-ins' outputs for clips b0:b1 at the frames ``sel`` (ascending) of the clip's T."""
-    if (b0, b1) == (0, b) and len(sel) == t:
+    if (b0, b1) == (0, b) and list(sel) == list(range(t)):
         return net
     no = opt.num_obj
     idx = _cached_index(sel, device)
@@ -220,12 +220,13 @@ def _points_grids_occ(opt, warper, net, nb, nt):
     return grid, compute_occ(net["occ_score"])
 
 
-def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, shared=None, shared_key=None,
+def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, where, shared=None, shared_key=None,
                   out_alpha=None):
     """One decode of predict() (estimate_alpha_grid_occ -> decode_output -> disocclusion test -> WIF fusion,
-    synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (ascending frame numbers: the
-    context frames 0 .. ctx_len - 1 and the frames to decode), producing the frames ``frames`` (ascending, a subset of
-    ``sel``).  ``net`` holds the stand-ins' outputs for exactly those clips and frames (_block_net); ``real_input``
+    synthesizer.py:434-460 / 464-484) for ``nb`` clips on the compact time axis ``sel`` (frame numbers: the context
+    frames 0 .. ctx_len - 1, then the other frames whose poses the decode needs -- a frame may stand there twice, with
+    the reconstruction's and with the prediction's poses), producing the units at the positions ``where`` of that axis.
+    ``net`` holds the stand-ins' outputs for exactly those clips and axis entries (_block_net); ``real_input``
     (nb, >= ctx_len, C, Hd, Wd) at least the context frames.  ``shared`` (a ``SharedContext``): what depends on the
     context alone is taken from / left for the other decodes of the step (``shared_key``: the tensors whose identity
     vouches for it, when ``net`` is a per-block copy of them).  Returns (output (nb, n, 3, Hd, Wd), disocc
@@ -234,7 +235,7 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
     do not depend on which other frames or clips are decoded beside it (tests/test_gpu_pipeline.py)."""
     no = opt.num_obj
     dev = real_input.device
-    nt, n = len(sel), len(frames)
+    nt, n = len(sel), len(where)
     assert list(sel[:ctx_len]) == list(range(ctx_len)), "the compact time axis starts with the context frames"
     # `alpha` (2 a' - 1 on the context frames) is dropped by the reconstruction (synthesizer.py:445) and handed by the
     # prediction to net_ii.inpaint (synthesizer.py:472, 484), which reads it only with the inpainter on (wif.py:103):
@@ -284,8 +285,6 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, frames, s
         occ = torch.cat([occ_c, occ_n], dim=1)
     else:
         grid, occ = list(grid_c), occ_c
-    where = [sel.index(f) for f in frames]
-
     def make_ctx_ts():  # synthesizer.py:438-442
         ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
         return WF.normalise_time_index(ts[:, -opt.last_n_ctx:] if opt.last_n_ctx > 0 else ts)
@@ -331,24 +330,63 @@ def predict(opt, warper, wif, real_vid, real_lyt, net, ctx_len):
     # that is handed all T frames)
     n_in = t if getattr(opt, "include_self", False) else ctx_len
     real_input = torch.cat([real_vid[:, :n_in], real_lyt[:, :n_in]], dim=2)
-    # what both decodes compute from the context alone, once (the second decode is handed the same context poses)
-    shared = SharedContext() if not getattr(opt, "include_self", False) else None
-    rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every, shared=shared)
-    out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
+    if getattr(opt, "include_self", False) or not MERGE_DECODES or opt.no_future:
+        # the reference's two calls, one after the other (include_self: every frame is a context of itself)
+        shared = SharedContext() if not getattr(opt, "include_self", False) else None
+        rec, dis, inp, _ = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every, shared=shared)
+        out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
+        if not opt.no_future:
+            alpha = []
+            pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every,
+                                                 list(range(ctx_len, t)), shared=shared, out_alpha=alpha)
+    else:
+        # ONE decode for the reconstruction's and the prediction's units (see decode_units): the context's products once,
+        # every full-resolution pass launched once with T + Tp units per clip
+        alpha = []
+        (rec, dis, inp, _), (pred, dis_p, inp_p, flow) = decode_units(
+            opt, warper, wif, real_input, net, ctx_len, b, t, 0, b, every, list(range(ctx_len, t)), out_alpha=alpha)
+        out["rec_vid"], out["rec_disocc"], out["inp_rec_vid"] = rec, dis, inp
+        dis, inp = dis_p, inp_p
     if not opt.no_future:
         # the pose generator (net_pg, outside the path) returns full-length pose sequences: the context
         # poses as they came in, the future ones predicted (flp.py:275-290) -- here the synthetic poses
         # of all T frames stand for them (synthesizer.py:464-472)
-        alpha = []
-        pred, dis, inp, flow = _decode_block(opt, warper, wif, real_input, net, ctx_len, b, every, every[ctx_len:],
-                                             shared=shared, out_alpha=alpha)
-        if alpha[0] is not None:  # (with opt.use_inpainter: what the prediction hands to net_ii.inpaint, synthesizer.py:484)
+        if alpha and alpha[0] is not None:  # (with opt.use_inpainter: what the prediction hands to net_ii.inpaint, synthesizer.py:484)
             out["pred_alpha"] = alpha[0]
         out["pred_disocc"] = dis
         out["pred_flow"] = flow
         out["pred_vid"] = torch.cat([real_vid[:, :ctx_len], pred], dim=1)
         out["inp_pred_vid"] = torch.cat([real_vid[:, :ctx_len], inp], dim=1)
     return out
+
+
+# Synthesizer.predict decodes twice: all T frames from the estimated poses (synthesizer.py:434-445), then the T - Tc future
+# frames from the pose generator's (synthesizer.py:464-472).  Both decodes read the same context; their units are
+# independent of each other, and the pose generator needs nothing the first decode produces -- so both sets of units can go
+# through ONE decode_output on one time axis [context | the reconstruction's other frames | the prediction's frames]: every
+# full-resolution pass is launched once with all units (a rank's share of a split job is launch-bound: ~150 launches
+# become ~85), what depends on the context alone is computed once by construction.  The same bits per unit (every kernel
+# of the chain works per (b, t) unit).  False: the reference's two calls, one after the other.
+MERGE_DECODES = True
+
+
+def decode_units(opt, warper, wif, real_input, net, ctx_len, b, t, b0, b1, rec_frames, pred_frames, out_alpha=None):
+    """The reconstruction's frames ``rec_frames`` and the prediction's frames ``pred_frames`` (clip-relative frame numbers,
+    ascending) of clips b0:b1 in ONE decode.  Returns the two 4-tuples of ``_decode_block`` (either may be None when its
+    list is empty)."""
+    dev = real_input.device
+    rec_new = [f for f in rec_frames if f >= ctx_len]
+    sel = list(range(ctx_len)) + rec_new + list(pred_frames)
+    where = [f if f < ctx_len else ctx_len + rec_new.index(f) for f in rec_frames] + \
+            [ctx_len + len(rec_new) + i for i in range(len(pred_frames))]
+    blk = _block_net(opt, net, b, t, b0, b1, sel, dev)
+    vid, dis, inp, flow = _decode_block(opt, warper, wif, real_input, blk, ctx_len, b1 - b0, sel, where, out_alpha=out_alpha)
+    nr = len(rec_frames)
+
+    def part(lo, hi):
+        return (vid[:, lo:hi], dis[:, lo:hi], inp[:, lo:hi], flow[:, :, lo:hi]) if hi > lo else None
+
+    return part(0, nr), part(nr, nr + len(pred_frames))
 
 
 def rec_unit_order(t, ctx_len):
@@ -436,34 +474,55 @@ def predict_sharded(opt, warper, wif, real_vid, real_lyt, net, ctx_len, rank, wo
     out = {}
     inputs, shared = {}, {}  # clips b0:b1 -> cat of their context frames and layouts / their context's products
     job = (net["raw"], net["pred_obj_pose"], net["pred_bg_pose"], net["occ_score"], net["cls"])
+    parts = {k: [] for ph in phases for k in UNIT_KEYS[ph] if not (ph == "pred" and opt.no_future)}
+
+    def clip_input(b0, b1):
+        if (b0, b1) not in inputs:
+            inputs[(b0, b1)] = torch.cat([real_vid[b0:b1, :ctx_len], real_lyt[b0:b1, :ctx_len]], dim=2)
+            shared[(b0, b1)] = SharedContext()
+        return inputs[(b0, b1)]
+
+    def keep(phase, nb, res):
+        vid, dis, inp, flow = res
+        n = vid.shape[1]
+        parts[phase + "_vid"].append(vid.reshape(-1, 3, hd, wd))
+        parts[phase + "_disocc"].append(dis.reshape(-1, 1, hd, wd))
+        parts["inp_" + phase + "_vid"].append(inp.reshape(-1, 3, hd, wd))
+        if phase == "pred":  # (nb, Tc, n, 2, Hd, Wd) -> units x (Tc * 2)
+            parts["pred_flow"].append(flow.permute(0, 2, 1, 3, 4, 5).reshape(nb * n, -1, hd, wd))
+
+    segs = {}
     for phase in phases:
         if phase == "pred" and opt.no_future:
             continue
         first = 0 if phase == "rec" else ctx_len
         per_clip = t - first
         u0, u1 = shard_range(b * per_clip, rank, world)
-        parts = {k: [] for k in UNIT_KEYS[phase]}
-        for b0, b1, units in unit_segments(u0, u1, per_clip, phase_order(phase, t, ctx_len)):
-            frames = [first + f for f in units]
-            sel = sorted(set(range(ctx_len)) | set(frames))
-            if (b0, b1) not in inputs:
-                inputs[(b0, b1)] = torch.cat([real_vid[b0:b1, :ctx_len], real_lyt[b0:b1, :ctx_len]], dim=2)
-                shared[(b0, b1)] = SharedContext()
-            blk = _block_net(opt, net, b, t, b0, b1, sel, dev)
-            vid, dis, inp, flow = _decode_block(opt, warper, wif, inputs[(b0, b1)], blk, ctx_len, b1 - b0, sel, frames,
-                                                shared=shared[(b0, b1)], shared_key=job + (inputs[(b0, b1)],))
-            n = len(frames)
-            parts[phase + "_vid"].append(vid.reshape(-1, 3, hd, wd))
-            parts[phase + "_disocc"].append(dis.reshape(-1, 1, hd, wd))
-            parts["inp_" + phase + "_vid"].append(inp.reshape(-1, 3, hd, wd))
-            if phase == "pred":  # (nb, Tc, n, 2, Hd, Wd) -> units x (Tc * 2)
-                parts["pred_flow"].append(flow.permute(0, 2, 1, 3, 4, 5).reshape((b1 - b0) * n, -1, hd, wd))
-        for k, v in parts.items():
-            if v:
-                out[k] = v[0] if len(v) == 1 else torch.cat(v, dim=0)
-            else:  # a rank past the end of a short job holds no unit
-                ch = {"disocc": 1, "flow": 2 * (opt.last_n_ctx or ctx_len)}.get(k.split("_")[-1], 3)
-                out[k] = real_vid.new_empty(0, ch, hd, wd)
+        segs[phase] = [(b0, b1, [first + f for f in units])
+                       for b0, b1, units in unit_segments(u0, u1, per_clip, phase_order(phase, t, ctx_len))]
+    if MERGE_DECODES and len(segs.get("rec", ())) == 1 and len(segs.get("pred", ())) == 1 and \
+            segs["rec"][0][:2] == segs["pred"][0][:2]:
+        # this rank's reconstruction and prediction units belong to the same clips: ONE decode for both (decode_units)
+        b0, b1, rec_frames = segs["rec"][0]
+        rec, pred = decode_units(opt, warper, wif, clip_input(b0, b1), net, ctx_len, b, t, b0, b1, rec_frames,
+                                 segs["pred"][0][2])
+        keep("rec", b1 - b0, rec)
+        keep("pred", b1 - b0, pred)
+    else:
+        for phase, lst in segs.items():
+            for b0, b1, frames in lst:
+                sel = sorted(set(range(ctx_len)) | set(frames))
+                blk = _block_net(opt, net, b, t, b0, b1, sel, dev)
+                res = _decode_block(opt, warper, wif, clip_input(b0, b1), blk, ctx_len, b1 - b0, sel,
+                                    [sel.index(f) for f in frames], shared=shared[(b0, b1)],
+                                    shared_key=job + (inputs[(b0, b1)],))
+                keep(phase, b1 - b0, res)
+    for k, v in parts.items():
+        if v:
+            out[k] = v[0] if len(v) == 1 else torch.cat(v, dim=0)
+        else:  # a rank past the end of a short job holds no unit
+            ch = {"disocc": 1, "flow": 2 * (opt.last_n_ctx or ctx_len)}.get(k.split("_")[-1], 3)
+            out[k] = real_vid.new_empty(0, ch, hd, wd)
     return out
 
 

@@ -109,22 +109,26 @@ class Pipeline:
         hwd = o.load_dim * int(o.load_dim * o.aspect_ratio)
         ghost = 0 if o.allow_ghost else nl - 1
         out = {}
-        for tp in (t, t - tc):  # reconstruction over all T frames, prediction over the T - Tc future ones
+        merged = demo.MERGE_DECODES and not o.no_future and not getattr(o, "include_self", False)
+        for i, tp in enumerate((t, t - tc)):  # reconstruction over all T frames, prediction over the T - Tc future ones
             m = b * tc * tp
             lr = m * (nl * 2 + ghost) * hw                      # per-layer flows and object masks, low resolution
             fcw_out = m * (2 + nl + 1 + 1) * hwd                # flow, alpha_ctx, disocc, layer maximum
+            # (both decodes' units go through ONE launch of every full-resolution pass -- demo.decode_units -- so the
+            # context's alphas and frames are read once per step, not once per decode)
+            ctx_once = 0 if (merged and i == 1) else 1
             add = {
                 # (a01 alone is written: without an inpainter -- opt.use_inpainter, off in the stand-in pipeline --
                 # nothing reads `alpha` = 2 a01 - 1 and the pass is asked not to write it; the pass itself runs ONCE per
-                # step, its result shared by the two decodes: tools/demo.py:SharedContext)
+                # step, its result shared by the two decodes)
                 "waldo_flow_ctx_alpha_fwd": (4 * (b * tc * nl * hw + b * tc * ncls * hwd
                                                   + (2 if getattr(o, "use_inpainter", False) else 1) * b * tc * nl * hwd)
-                                             if tp == t else 0),
-                "waldo_flow_ctx_warp_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out),
-                "waldo_flow_ctx_warp_raw_fwd": 4 * (lr + b * tc * nl * hwd + fcw_out + m * hwd),  # + score
-                "waldo_frame_warp_fuse_fwd": 4 * (b * tc * c * hwd + m * (2 + nl) * hwd + b * tp * (c + 1) * hwd
+                                             if i == 0 else 0),
+                "waldo_flow_ctx_warp_fwd": 4 * (lr + ctx_once * b * tc * nl * hwd + fcw_out),
+                "waldo_flow_ctx_warp_raw_fwd": 4 * (lr + ctx_once * b * tc * nl * hwd + fcw_out + m * hwd),  # + score
+                "waldo_frame_warp_fuse_fwd": 4 * (ctx_once * b * tc * c * hwd + m * (2 + nl) * hwd + b * tp * (c + 1) * hwd
                                                   + m * (c + nl) * hwd),
-                "waldo_frame_warp_fuse_raw_fwd": 4 * (b * tc * c * hwd + m * (2 + 1) * hwd + b * tp * (c + 1) * hwd
+                "waldo_frame_warp_fuse_raw_fwd": 4 * (ctx_once * b * tc * c * hwd + m * (2 + 1) * hwd + b * tp * (c + 1) * hwd
                                                       + m * c * hwd),
                 # the fusion reads channels 0-2 and 4 of the raw frames and the UNet's four outputs (wif.py:49-54)
                 "waldo_wif_fuse_fwd": 4 * (m * 4 * hwd + m * 4 * hwd + b * tp * 3 * hwd),
