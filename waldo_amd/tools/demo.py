@@ -275,16 +275,34 @@ def _decode_block(opt, warper, wif, real_input, net, ctx_len, nb, sel, where, sh
         key = shared_key if shared_key is not None else (net["raw"], net["pred_obj_pose"], net["pred_bg_pose"],
                                                           net["occ_score"], net["cls"], real_input)
         occ_c, obj_alpha, bga, grid_c, products = shared.get(key, context_part)
+        if nt > ctx_len:  # the frames beyond the context: their control points, grids and occlusion matrices
+            new_net = dict(pred_obj_pose=frames_of(net["pred_obj_pose"], ctx_len, nt),
+                           pred_bg_pose=frames_of(net["pred_bg_pose"], ctx_len, nt), occ_score=net["occ_score"][:, ctx_len:])
+            grid_n, occ_n = _points_grids_occ(opt, warper, new_net, nb, nt - ctx_len)
+            grid = [torch.cat([a, b], dim=1) for a, b in zip(grid_c, grid_n)]
+            occ = torch.cat([occ_c, occ_n], dim=1)
+        else:
+            grid, occ = list(grid_c), occ_c
     else:
-        occ_c, obj_alpha, bga, grid_c, products = context_part()
-    if nt > ctx_len:  # the frames beyond the context: their control points, grids and occlusion matrices
-        new_net = dict(pred_obj_pose=frames_of(net["pred_obj_pose"], ctx_len, nt),
-                       pred_bg_pose=frames_of(net["pred_bg_pose"], ctx_len, nt), occ_score=net["occ_score"][:, ctx_len:])
-        grid_n, occ_n = _points_grids_occ(opt, warper, new_net, nb, nt - ctx_len)
-        grid = [torch.cat([a, b], dim=1) for a, b in zip(grid_c, grid_n)]
-        occ = torch.cat([occ_c, occ_n], dim=1)
-    else:
-        grid, occ = list(grid_c), occ_c
+        # nothing to share with another decode: the whole axis in ONE call each of the pose heads' affine, Warper.forward
+        # and compute_occ (estimate_alpha_grid_occ, lvd.py:126-135) -- no second set of launches for the context's grids,
+        # nothing to concatenate; the context's products from the first ctx_len frames of those grids
+        lo = opt.obj_shape[0] * opt.obj_shape[1]
+        lb = opt.latent_shape[0] * opt.latent_shape[1]
+        buf = pose_buffers(opt, dev)
+        obj_alpha = decoder_tail(net["raw"], init_bias=0.0, scale_factor=opt.scale_factor)
+        obj_alpha = obj_alpha.view(nb, no, 1, *obj_alpha.shape[-2:])
+        obj_pose = flp.obj_pose_to_points(net["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+        bg_pose = flp.bg_pose_to_points(net["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"])
+        occ, obj_alpha, bga, grid = estimate_alpha_grid_occ(warper, obj_alpha, bg_alpha, obj_pose.view(nb, nt, no, lo, 2),
+                                                            bg_pose.view(nb, nt, 1, lb, 2), net["occ_score"],
+                                                            obj_alpha_mask=mask)
+        prev = warper.return_alpha
+        warper.return_alpha = want_alpha
+        try:
+            products = warper.context_products(real_input, grid, occ, obj_alpha, bga, net["cls"], ctx_len)
+        finally:
+            warper.return_alpha = prev
     def make_ctx_ts():  # synthesizer.py:438-442
         ts = torch.arange(ctx_len, device=dev, dtype=torch.int64).view(1, -1, 1).expand(nb, -1, n)
         return WF.normalise_time_index(ts[:, -opt.last_n_ctx:] if opt.last_n_ctx > 0 else ts)
