@@ -242,6 +242,51 @@ def cpu_baseline(nl, h, w, frames, reps):
     return out
 
 
+# kernels behind the two entry points of the fused path, as rocprofv3 names them
+_TRAFFIC_KERNELS = {"waldo_warp_composite_fwd": ("warp_composite_fwd_lds_kernel", "warp_composite_fwd_kernel"),
+                    "waldo_warp_composite_bwd": ("warp_composite_bwd_px16_kernel", "warp_composite_splat_kernel",
+                                                 "warp_composite_gmap_reduce_kernel", "warp_composite_bwd_kernel")}
+
+
+def live_traffic(argv, timeout=240):
+    """HBM-side bytes per launch of the fused path's entry points, measured NOW: this command again (three steps, no
+    baselines) as a child under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and, in a second pass, ``--pmc WRITE_SIZE``
+    (the two do not fit one pass; MI355X_MICROARCH.md: the counters sit on the L2's fabric side, are reported in KiB, and
+    on gfx950 FETCH_SIZE tallies a 128-byte request of a wide coalesced read as 64 bytes -- doubled here -- while
+    WRITE_SIZE is exact for 16-byte streaming stores).  Returns {entry point: bytes per launch} or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this run is itself under a profiler")
+    per = {k: 0.0 for k in _TRAFFIC_KERNELS}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=timeout)
+            rows = {}
+            for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            rows.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+            if not rows:
+                raise RuntimeError(f"no {counter} rows (rocprofv3 rc {r.returncode}): {r.stderr[-300:]}")
+            for entry, kernels in _TRAFFIC_KERNELS.items():
+                for name, vals in rows.items():
+                    if any(name.endswith("::" + k) or ("::" + k + "<") in name for k in kernels):
+                        per[entry] += sum(vals) / len(vals) * factor
+    return per
+
+
 def measured_traffic(entry_point, frames, nl, h, w):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written
     by tools_dev/traffic.py from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of
@@ -399,6 +444,9 @@ def main():
                     help="experiment: free and re-create the workload's tensors before every timed block (does the "
                          "placement of the buffers explain run-to-run differences of a few per cent?)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profiles/traffic.json instead of two rocprofv3 --pmc child "
+                         "runs of this command (FETCH_SIZE, WRITE_SIZE: ~40 s)")
     ap.add_argument("--cpu-frames", type=int, default=28)
     ap.add_argument("--cpu-reps", type=int, default=5)
     args = ap.parse_args()
@@ -614,13 +662,25 @@ def main():
             gbs = alg[k] / (ks[k][1] * 1e-3) / 1e9
             kern[k] = {"launches": ks[k][0], "ms": round(ks[k][1], 4), "alg_bytes": alg[k],
                        "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        traffic = measured_traffic(dom, frames, nl, h, w)
+        # HBM-side bytes per launch: measured by two rocprofv3 --pmc children of this very command (the default workload
+        # on one GPU), else from the committed passes of the same command (profiles/traffic.json)
+        live, live_note = None, None
+        if args.config == "C3" and not custom and world == 1 and not args.no_live_traffic:
+            try:
+                live = live_traffic(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"])
+            except Exception as exc:  # (the line stands on the committed passes)
+                live_note = f"live passes failed ({type(exc).__name__}: {str(exc)[:200]})"
+
+        def moved_bytes(k):
+            return live[k] if live and live.get(k) else measured_traffic(k, frames, nl, h, w)
+
+        traffic = moved_bytes(dom)
         copy_gbs = copy_bandwidth(device)  # measured D2D copy rate of this box (read + write bytes per second)
         for k in kern:
-            # next to the fraction of the 8 TB/s spec: the fraction of what a copy kernel reaches on THIS box, and --
-            # when the committed PMC passes match the workload -- what the entry point really moved
+            # next to the fraction of the 8 TB/s spec: the fraction of what a copy kernel reaches on THIS box, and what
+            # the entry point really moved
             kern[k]["frac_of_copy"] = round(kern[k]["GBps"] / copy_gbs, 4)
-            moved = measured_traffic(k, frames, nl, h, w)
+            moved = moved_bytes(k)
             if moved:
                 kern[k]["moved_bytes"] = int(moved)
                 kern[k]["moved_over_alg"] = round(moved / alg[k], 3)
@@ -628,8 +688,12 @@ def main():
                 kern[k]["moved_frac_of_copy"] = round(kern[k]["moved_GBps"] / copy_gbs, 4)
         roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
-                "traffic_source": ("profiles/traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this "
-                                   "workload, committed; not re-measured in this run") if traffic else None,
+                "traffic_source": (("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this "
+                                    "command in this run (FETCH_SIZE x2: gfx950 tallies 128-byte requests at 64 bytes; "
+                                    "KiB -> bytes), mean per dispatch, summed over the entry point's kernels") if live else
+                                   ("profiles/traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                    "committed; not re-measured in this run" + (": " + live_note if live_note else "")))
+                if traffic else None,
                 "ms_per_launch": kern[dom]["ms"], "alg_bytes_per_launch": alg[dom],
                 "kernels": kern}
         roof["copy_GBps"] = round(copy_gbs, 1)

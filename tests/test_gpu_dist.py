@@ -255,3 +255,28 @@ def test_bench_wif_line():
                  "waldo_wif_fuse_fwd", "waldo_wif_fuse_bwd", "waldo_inverse_warp_fwd"):
         assert name in table, sorted(table)
     assert table["waldo_wif_fuse_bwd"]["frac"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_default_line_measures_its_hbm_traffic_in_the_run():
+    """The default one-GPU command (what the driver runs) collects ``roofline.traffic`` itself: two rocprofv3 --pmc child
+    runs of the same command (bench.py::live_traffic), and the bytes they report per backward launch lie between the
+    algorithmic bytes and three times them (the K1 -> K2 records are real traffic of this design: 2.2 x)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    roof = out["roofline"]
+    if "under a profiler" in roof["traffic_source"]:
+        pytest.skip("the test run is itself profiled: bench.py took the committed passes, as it says")
+    assert roof["traffic_source"].startswith("rocprofv3 --kernel-trace --pmc"), roof["traffic_source"]
+    assert roof["alg_bytes_per_launch"] < roof["traffic"] < 3 * roof["alg_bytes_per_launch"]
+    fwd = roof["kernels"]["waldo_warp_composite_fwd"]
+    assert fwd["alg_bytes"] < fwd["moved_bytes"] < 2 * fwd["alg_bytes"]
