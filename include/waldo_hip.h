@@ -459,6 +459,21 @@ int waldo_wif_fuse_bwd(const float* vid, const float* net, const float* out, con
                        int64_t HW, int ab, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f3. The mask dilation of WIF.inpaint: expand() (tools/utils.py:300-323; called at models/nets/wif.py:77,
+ * 108-112, 204).  `num` rounds; a round is the steps named in `steps` (bit 0 south, 1 north, 2 east, 3 west -- 15 =
+ * the reference's dir=None) taken IN THAT ORDER over the whole plane, each seeing the result of the one before:
+ *     south: m[y,x] = max(m[y,x], alpha*m[y-1,x])   north: ... alpha*m[y+1,x]   east: ... alpha*m[y,x-1]   west: ... alpha*m[y,x+1]
+ * with torch.maximum's NaN rule.  soft == 0: the same recurrence on (mask != 0) with alpha = 1 (the reference's
+ * bool branch), written as 0.0 / 1.0.  The recurrence is executed literally inside a workgroup's LDS tile, so the
+ * result has the framework's bits for every input.
+ *   mask (planes,H,W) -> out (planes,H,W); mask is never written; out / scratch must not alias mask or each other;
+ *   scratch (planes,H,W) is needed only when num > 30 (passes of 30 rounds ping-pong through it), else NULL.
+ * The masks are data: no backward.
+ * ------------------------------------------------------------------------------------- */
+int waldo_mask_expand_fwd(const float* mask, float* out, float* scratch, int64_t planes, int H, int W, int num,
+                          int steps, int soft, float alpha, waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A8. gather_time (models/nets/lvd.py:462-467) with the frame arithmetic of the flow synthesis
  * (lvd.py:660-668, 780-787) on a clip's grids x (B,T,P,2) -- P pairs per frame:
  *   subtract != 0:  out[b,tc,tp] = x[b, ctx_ts[b,tc,tp]] - x[b, pred_ts[tp]]   (layer-space flow)

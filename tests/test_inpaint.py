@@ -68,6 +68,63 @@ def test_expand_matches_box_dilation():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 17, 23), (1, 1, 70, 130), (1, 2, 64, 64), (1, 1, 1, 200), (1, 1, 131, 1),
+                                   (1, 2, 1, 90, 75)])
+def test_mask_expand_kernel_has_the_oracle_bits(dev, shape):
+    """``waldo_mask_expand_fwd`` -- expand() (tools/utils.py:300-323) as one launch -- against the oracle's step-by-step
+    statement (oracle/inpaint_oracle.py:expand, itself pinned to the reference bit for bit by tests/test_oracle_live.py):
+    hard and soft masks, every ``dir``, 1 ... 64 rounds (more than 30 take two passes), rasters that are no multiple
+    of the 64-pixel tile, one-pixel-wide planes, and the five-dimensional hole masks of wif.py:77 whose dims 2 and 3 are
+    (1, H).  BIT-exact; the argument is left alone."""
+    from waldo_amd import functional as WF
+    torch.manual_seed(sum(shape))
+    hard = (torch.rand(*shape) > 0.93).float()
+    soft = torch.rand(*shape) * (torch.rand(*shape) > 0.9)
+    for d in (None, "south", "north", "east", "west"):
+        for num in (0, 1, 2, 5, 30, 31, 64) if d is None else (1, 7):
+            keep = hard.to(dev)
+            got = WF.mask_expand(keep, num, dir=d)
+            assert torch.equal(got.cpu(), IO.expand(hard.clone(), num, dir=d)), (shape, d, num, "hard")
+            assert torch.equal(keep.cpu(), hard)
+            keep = soft.to(dev)
+            got = WF.mask_expand(keep, num, dir=d, soft=True)
+            assert torch.equal(got.cpu(), IO.expand(soft.clone(), num, dir=d, soft=True)), (shape, d, num, "soft")
+            assert torch.equal(keep.cpu(), soft)
+    b = hard.bool().to(dev)
+    assert torch.equal(WF.mask_expand(b, 3).cpu(), IO.expand(hard.clone(), 3))
+    assert b.dtype == torch.bool and torch.equal(b.cpu(), hard.bool())
+
+
+@pytest.mark.gpu
+def test_mask_expand_kernel_runs_the_steps_literally(dev):
+    """Inputs on which the step-by-step recurrence is NOT a plain dilation -- negative values (alpha * m > m), a growth
+    factor above one, NaN (torch.maximum lets it through from either side), infinities -- and the recipe's own
+    30-round soft shadow growth at 512 x 1024: the kernel gives the framework's bits."""
+    from waldo_amd import functional as WF
+    torch.manual_seed(3)
+    x = torch.randn(1, 2, 97, 150)
+    for kw in (dict(num=4, alpha=0.97), dict(num=3, alpha=1.25), dict(num=33, alpha=0.9), dict(num=2, alpha=-0.5)):
+        want = IO.expand(x.clone(), soft=True, **kw)
+        got = WF.mask_expand(x.to(dev), soft=True, **kw).cpu()
+        assert torch.equal(got, want), kw
+    y = x.clone()
+    y[0, 0, 40, 70] = float("nan")
+    y[0, 1, 10, 10] = float("inf")
+    y[0, 1, 60, 100] = float("-inf")
+    want = IO.expand(y.clone(), 6, soft=True)
+    got = WF.mask_expand(y.to(dev), 6, soft=True).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.isnan(want).sum() > 1
+    assert torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0))
+    big = (torch.rand(1, 1, 512, 1024) > 0.999).float()
+    assert torch.equal(WF.mask_expand(big.to(dev), 30, soft=True).cpu(), IO.expand(big.clone(), 30, soft=True))
+    assert torch.equal(WF.mask_expand(big.to(dev), 30).cpu(), IO.expand(big.clone(), 30))
+    with pytest.raises(Exception):
+        WF.mask_expand(big.to(dev)[0], 3)           # three dimensions
+    with pytest.raises(ValueError):
+        WF.mask_expand(big.to(dev), 3, dir="up")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", sorted(INPAINT_CASES))
 def test_inpaint_hip_vs_oracle_and_reference(dev, golden, tag):
     from waldo_amd.nets import WIF, Warper
@@ -257,3 +314,16 @@ def test_inpaint_timing_at_recipe_size(dev):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "inpaint_R_timing.json"), "w") as fh:
             fh.write(json.dumps(line) + "\n")
+        import cProfile
+        import io
+        import pstats
+        prof = cProfile.Profile()
+        prof.enable()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+        with open(os.path.join(out_dir, "inpaint_R_host_profile.txt"), "w") as fh:
+            fh.write("five calls of WIF.inpaint (tests/test_inpaint.py::test_inpaint_timing_at_recipe_size)\n" + buf.getvalue())

@@ -1152,6 +1152,48 @@ def downscale_frames(input, num_frames, first_channel, factor):
     return out
 
 
+_EXPAND_STEPS = {None: 15, "": 15, "south": 1, "north": 2, "east": 4, "west": 8}
+
+
+def mask_expand(mask, num=1, dir=None, soft=False, alpha=0.97):
+    """The reference's ``expand`` (tools/utils.py:300-323) as ONE launch: ``num`` rounds of one-pixel growth towards
+    the south, north, east and west in that order along dims 2 and 3 of ``mask``, each step seeing the one before
+    (``dir`` keeps one of the four); hard masks (``soft=False``) are read as ``mask != 0`` and returned as float
+    0 / 1, soft ones grow by ``max(pixel, alpha * neighbour)``.  The same bits as the framework's 8 * num launches
+    (``waldo_amd.tools.utils.expand`` states them) for every input; never writes its argument.
+
+    ``mask``: (N, C, H, W) -- or, as ``WIF.inpaint`` calls it on its (B, Tp, 1, H, W) hole masks (wif.py:77), five
+    dimensions of which dim 2 has size 1: dims 2 and 3 are then (1, H), so "south / north" have nothing to do and "east /
+    west" run along H -- the reference's own behaviour, kept."""
+    if not mask.is_cuda:
+        raise _lib.WaldoHipError("waldo_amd ops need tensors on the GPU (cuda device); there is no CPU fallback")
+    if dir not in _EXPAND_STEPS:
+        raise ValueError(f"mask_expand: dir {dir!r} (south, north, east, west or None)")
+    steps = _EXPAND_STEPS[dir]
+    if mask.dim() == 4:
+        planes, h, w = mask.shape[0] * mask.shape[1], mask.shape[2], mask.shape[3]
+    elif mask.dim() == 5 and mask.shape[2] == 1:
+        # dims (2, 3) = (1, H) with W elementwise behind them: east / west of the reference run along H = the kernel's
+        # south / north on (H, W) planes; its south / north see a dimension of size 1
+        planes, h, w = mask.shape[0] * mask.shape[1], mask.shape[3], mask.shape[4]
+        steps = ((steps >> 2) & 3)
+    else:
+        raise _lib.WaldoHipError(f"mask_expand: a mask of shape {tuple(mask.shape)} (four dimensions, or five with a "
+                                 f"dim 2 of size 1)")
+    if soft and mask.dtype != torch.float32:
+        raise _lib.WaldoHipError(f"mask_expand: a soft mask of dtype {mask.dtype} (float32: the kernel's arithmetic)")
+    x = _c(mask.detach().float())
+    num = int(num)
+    if num == 0 or steps == 0 or planes == 0:
+        return x.clone() if soft else (x != 0).float()
+    out = torch.empty_like(x)
+    scratch = torch.empty_like(x) if num > 30 else None
+    with _lib.on_device(x.device):
+        _lib.call("waldo_mask_expand_fwd", _lib.ptr(x), _lib.ptr(out), _lib.ptr(scratch), planes, h, w, num, steps,
+                  1 if soft else 0, float(alpha), _lib.current_stream(x.device))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # fused hot path
 # --------------------------------------------------------------------------------------

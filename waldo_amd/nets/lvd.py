@@ -290,26 +290,39 @@ class Warper(nn.Module):
                 output_alpha)
 
     # ------------------------------------------------------------------ flow helpers (WIF.inpaint)
+    # (the reference indexes the frame with a LIST, ``tgt_grid_bg[:, [ref]]``: an index tensor built on the host and
+    # copied to the device -- a copy that waits for the queue to drain, 5 ms into WIF.inpaint at 512 x 1024; a slice
+    # of one frame is the same tensor without it)
+    @staticmethod
+    def _frame(x, i):
+        return x.narrow(1, i % x.shape[1], 1)
+
     def grid_to_bg_flow_from_ref_to_pred(self, grid, ctx_len, ref):
         _, _, tgt_grid_bg, src_grid_bg = grid
-        bg_flow = (tgt_grid_bg[:, [ref]] - tgt_grid_bg[:, ctx_len:]).permute(0, 1, 4, 2, 3)
+        bg_flow = (self._frame(tgt_grid_bg, ref) - tgt_grid_bg[:, ctx_len:]).permute(0, 1, 4, 2, 3)
         bg_flow = self.bg_to_output(bg_flow, [None, None, None, src_grid_bg[:, ctx_len:]], delta_bg=0).squeeze(2)
         return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
 
     def grid_to_obj_flow_from_ref_to_pred(self, grid, ctx_len, ref, obj_id):
         tgt_grid_obj, src_grid_obj, _, _ = grid
-        obj_flow = tgt_grid_obj[:, [ref], [obj_id]] - tgt_grid_obj[:, ctx_len:, [obj_id]]
+        if tgt_grid_obj.shape[0] == 1:  # (WIF.inpaint: one clip; the list indices of lvd.py:586-588 as slices)
+            one = tgt_grid_obj.narrow(2, obj_id % tgt_grid_obj.shape[2], 1)
+            obj_flow = self._frame(one, ref) - one[:, ctx_len:]
+            src_one = src_grid_obj.narrow(2, obj_id % src_grid_obj.shape[2], 1)
+        else:  # the reference's expression as it stands (its two lists pair up: (B, 1, ...) against (B, Tp, 1, ...))
+            obj_flow = tgt_grid_obj[:, [ref], [obj_id]] - tgt_grid_obj[:, ctx_len:, [obj_id]]
+            src_one = src_grid_obj[:, :, [obj_id]]
         obj_flow = obj_flow.permute(0, 1, 2, 5, 3, 4)  # B T 1 2 Ho Wo
         b, t = obj_flow.shape[:2]
         h, w = self.src_shape
-        g = src_grid_obj[:, ctx_len:, [obj_id]].reshape(b * t, h, w, 2)
+        g = src_one[:, ctx_len:].reshape(b * t, h, w, 2)
         out = WF.grid_sample(obj_flow.reshape(b * t, 2, *self.tgt_shape), g).view(b, t, 2, h, w)
         return scale(out, self.scale_hd).permute(0, 1, 3, 4, 2)
 
     def grid_to_bg_flow_from_ctx_to_ref(self, grid, ctx_len, ref):
         _, _, tgt_grid_bg, src_grid_bg = grid
-        bg_flow = (tgt_grid_bg[:, :ctx_len] - tgt_grid_bg[:, [ref]]).permute(0, 1, 4, 2, 3)
-        g = src_grid_bg[:, [ref]].expand(-1, ctx_len, -1, -1, -1)
+        bg_flow = (tgt_grid_bg[:, :ctx_len] - self._frame(tgt_grid_bg, ref)).permute(0, 1, 4, 2, 3)
+        g = self._frame(src_grid_bg, ref).expand(-1, ctx_len, -1, -1, -1)
         bg_flow = self.bg_to_output(bg_flow, [None, None, None, g], delta_bg=0).squeeze(2)
         return scale(bg_flow, self.scale_hd).permute(0, 1, 3, 4, 2)
 

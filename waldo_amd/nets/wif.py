@@ -9,7 +9,9 @@ import torch
 import torch.nn as nn
 
 from .. import functional as WF
-from ..tools.utils import expand, get_grid
+from ..tools.utils import get_grid
+
+expand = WF.mask_expand  # tools/utils.py:300-323 as one launch (waldo_amd.tools.utils.expand states the steps)
 
 _MASK_T = 0.1  # `mask_thresh` of wif.py:65: a warped / composited mask counts above 1 - _MASK_T
 
