@@ -451,6 +451,53 @@ def test_warp_composite_random(dev, cfg):
     _compare_fused(hip, ref32, ref64)
 
 
+def test_warp_composite_seeded_fuzz(dev):
+    """Forty-eight shapes drawn from a seeded generator -- 1 ... 9 frames, 1 ... 32 layers, rasters of 4 ... 80 by
+    4 ... 140 pixels (any remainder against the 16 x 16 / 4 x 64 / 32 x 64 tiles and the four-pixel vectors), 3 x 3 ...
+    5 x 5 control points, mild to folding warps, the three `delta` paddings, both backward kernels -- forward and all
+    three gradients against the fp32 and fp64 oracle through the same `close` as every other case.  The fixed lists
+    above hold the shapes somebody thought of; this holds the ones nobody did."""
+    import random
+    rng = random.Random(20260)
+    for case in range(48):
+        f, nl = rng.randint(1, 9), rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 16, 17, 18, 23, 24, 25, 31, 32])
+        h, w = rng.randint(4, 80), rng.randint(4, 140)
+        if nl > 17:  # (the oracle's L^2 product in fp64: keep the big layer counts small)
+            f, h, w = min(f, 2), min(h, 40), min(w, 72)
+        k = rng.choice([3, 4, 4, 4, 5])
+        sigma = rng.choice([0.05, 0.1, 0.2, 0.35, 0.5])
+        delta = rng.choice([0.0, 0.0, 0.5, 1.0])
+        generic = rng.random() < 0.25
+        smooth = rng.choice([0, 2, 4])
+        ctrl = O.get_grid(k, k).view(-1, 2)
+        if nl == 1:
+            torch.manual_seed(case)
+            layers = torch.rand(f, 1, 4, h, w) * 2 - 1
+            pts = ctrl.view(1, -1, 2) + sigma * torch.randn(f, k * k, 2)
+            occ = torch.zeros(f, 1, 1)
+        else:
+            layers, pts, occ, _, _ = O.make_synthetic(f, nl, h, w, k_side=k, seed=1000 + case, sigma=sigma,
+                                                      smooth=smooth)
+        torch.manual_seed(case)
+        w1, w2 = torch.randn(f, 3, h, w), torch.randn(f, nl, h, w)
+        ref32 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float32, delta=delta)
+        ref64 = _oracle_fused(layers, pts, occ, ctrl, w1, w2, torch.float64, delta=delta)
+        hip = _hip_fused(dev, layers, pts, occ, ctrl, w1, w2, generic=generic, delta=delta)
+        if smooth == 0 or nl == 1:
+            # white-noise layers: the control-point gradient is DISCONTINUOUS in the sample positions (the bilinear
+            # interpolant's derivative jumps by O(texel difference) across a texel boundary), one pixel whose position
+            # rounds to the other side of a boundary moves it by several per cent of its scale, and the two oracles'
+            # agreement there says nothing about a third summation order (seen: |hip - ref64| 49 where |ref32 - ref64|
+            # is 0.66 and another shape has the oracles themselves 31 apart, on a scale of 800-900).  Everything else is
+            # continuous and is compared; grad_pts is compared on the smooth two thirds of the cases.
+            hip, ref32, ref64 = [[x if i != 3 else None for i, x in enumerate(t)] for t in (hip, ref32, ref64)]
+        try:
+            _compare_fused(hip, ref32, ref64)
+        except AssertionError as exc:
+            raise AssertionError(f"case {case}: f={f} nl={nl} h={h} w={w} k={k} sigma={sigma} delta={delta} "
+                                 f"generic={generic} smooth={smooth}: {exc}") from exc
+
+
 def test_warp_composite_smooth_is_strict(dev):
     """On smooth layers the fp32 reference is itself determined to ~1e-6, so the bound that is
     enforced is the plain north-star 1e-4 (checked here without the noise allowance)."""
