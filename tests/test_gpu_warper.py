@@ -124,6 +124,50 @@ def test_inverse_warp_random(dev, cfg):
     assert torch.equal(s3.grad, s2.grad), "fused backward differs from the per-pass kernels"
 
 
+def test_inverse_warp_seeded_fuzz(dev):
+    """Forty more inversions from a seeded generator: source rasters of 3 ... 40, targets of 3 ... 150 pixels a side
+    (minifications and magnifications, every remainder against the tile + halo kernels' regions), 0 ... 9 fill passes,
+    erosion on and off, shrinking and expanding maps, 1 ... 5 maps per call: forward and backward against the oracle and
+    the one-launch kernels against the per-pass kernels bit for bit, as ``test_inverse_warp_random``."""
+    import random
+    import waldo_amd
+    from waldo_amd import _lib
+    lib = _lib.load()
+    rng = random.Random(77)
+    for case in range(40):
+        hs, ws = rng.randint(3, 40), rng.randint(3, 40)
+        ht, wt = rng.randint(3, 150), rng.randint(3, 150)
+        niter, erode, n = rng.randint(0, 9), rng.random() < 0.6, rng.randint(1, 5)
+        shrink, jitter = rng.choice([0.3, 0.6, 0.9, 1.0, 1.2]), rng.choice([0.02, 0.1, 0.25])
+        what = f"case {case}: {hs}x{ws} -> {ht}x{wt}, niter {niter}, erode {erode}, {n} maps, shrink {shrink}, jitter {jitter}"
+        torch.manual_seed(case)
+        ctrl = O.get_grid(4, 4).view(-1, 2)
+        inv, rep = O.tps_init(hs, ws, ctrl)
+        pts = ctrl.view(1, 16, 2) * shrink + jitter * torch.randn(n, 16, 2)
+        sg = O.tps_grid(inv, rep, pts, hs, ws).requires_grad_()
+        ref = O.inverse_warp(sg, (ht, wt), niter=niter, erode=erode)
+        wgt = torch.randn(ref.shape)
+        (ref * wgt).sum().backward()
+        mod = waldo_amd.InverseWarp(hs, ws, ht, wt).to(dev)
+        s2 = sg.detach().to(dev).requires_grad_()
+        out = mod(s2, niter=niter, erode=erode)
+        (out * wgt.to(dev)).sum().backward()
+        assert lib.waldo_set_debug_option(_lib.DEBUG_IW_PASSES, 1) == 0
+        try:
+            s3 = sg.detach().to(dev).requires_grad_()
+            out3 = mod(s3, niter=niter, erode=erode)
+            (out3 * wgt.to(dev)).sum().backward()
+        finally:
+            lib.waldo_set_debug_option(_lib.DEBUG_IW_PASSES, 0)
+        try:
+            close(out, ref, what="out")
+            close(s2.grad, sg.grad, rel=True, what="grad")
+            assert torch.equal(out3, out), "fused forward differs from the per-pass kernels"
+            assert torch.equal(s3.grad, s2.grad), "fused backward differs from the per-pass kernels"
+        except AssertionError as exc:
+            raise AssertionError(f"{what}: {exc}") from exc
+
+
 def test_inverse_warp_identity_and_errors(dev):
     import waldo_amd
     mod = waldo_amd.InverseWarp(12, 20, 12, 20).to(dev)
@@ -868,6 +912,62 @@ def test_frame_warp_fuse_at_256x512(dev, amp_px, tc):
     ((out * w_out.to(dev)).sum() + (raw * w_raw.to(dev)).sum()).backward()
     close(f.grad, r32[2], rel=True, what=f"{amp_px} px: grad_flow", exact=r64[2])
     close(a.grad, r32[3], rel=True, what=f"{amp_px} px: grad_alpha", exact=r64[3])
+
+
+def test_frame_warp_fuse_seeded_fuzz(dev):
+    """Thirty shapes of ``input_to_output`` from a seeded generator -- rasters of 5 ... 90 by 5 ... 160 pixels, 1 ... 4
+    contexts, 1 ... 3 predicted frames (or the include_self branch), 1 ... 26 channels, 1 ... 17 alpha layers, flows of
+    1 ... 60 pixels (smooth, with a shear: the staged boxes and the per-context gather fallback both occur), random
+    context indices: forward with and without autograd (the staged no-grad kernel) and both gradients against the
+    oracle in fp32 and fp64."""
+    import random
+    from waldo_amd import functional as WF
+    rng = random.Random(4242)
+    for case in range(30):
+        hd, wd = rng.randint(5, 90), rng.randint(5, 160)
+        b, tc, c, nl = rng.randint(1, 2), rng.randint(1, 4), rng.randint(1, 26), rng.randint(1, 17)
+        include_self = rng.random() < 0.3
+        t = rng.randint(2, 4)
+        tp = t if include_self else rng.randint(1, 3)
+        amp_px = rng.choice([1.0, 4.0, 15.0, 60.0])
+        what = (f"case {case}: {hd}x{wd} b={b} t={t} tc={tc} tp={tp} c={c} nl={nl} include_self={include_self} "
+                f"amp={amp_px}")
+        opt = opt_ns(num_obj=nl - 1, dim=hd, aspect_ratio=(wd + 0.5) / hd, load_dim=hd, include_self=include_self)
+        cfg = WO.WarperCfg.from_opt(opt)
+        g = torch.Generator().manual_seed(case)
+        lo = torch.randn(b * t, c, max(hd // 4, 2), max(wd // 4, 2), generator=g)
+        inp = torch.nn.functional.interpolate(lo, size=(hd, wd), mode="bilinear").view(b, t, c, hd, wd)
+        fl = (amp_px * 2 / wd) * torch.randn(b * tc * tp, 2, max(hd // 16, 2), max(wd // 16, 2), generator=g)
+        flow = torch.nn.functional.interpolate(fl, size=(hd, wd), mode="bilinear").view(b, tc, tp, 2, hd, wd)
+        flow = flow + (amp_px * 2 / wd) * torch.linspace(-1, 1, hd).view(1, 1, 1, 1, hd, 1)
+        alpha = torch.rand(b, tc, tp, nl, hd, wd, generator=g) * 2 - 1
+        ctx_ts = torch.randint(0, t, (b, tc, tp), generator=g)
+        n_out = tc + 1 if include_self else tc
+        w_out = torch.randn(b, tp, c + 1, hd, wd, generator=g)
+        w_raw = torch.randn(b, n_out, tp, c + nl, hd, wd, generator=g)
+
+        def ref(dtype):
+            f, a = flow.clone().to(dtype).requires_grad_(), alpha.clone().to(dtype).requires_grad_()
+            out, raw = WO.input_to_output(cfg, inp.to(dtype), a, f, ctx_ts)
+            ((out * w_out.to(dtype)).sum() + (raw * w_raw.to(dtype)).sum()).backward()
+            return out.detach(), raw.detach(), f.grad, a.grad
+
+        try:
+            r32, r64 = ref(torch.float32), ref(torch.float64)
+            f, a = flow.to(dev).requires_grad_(), alpha.to(dev).requires_grad_()
+            out, raw = WF.frame_warp_fuse(inp.to(dev), f, a, ctx_ts.to(dev), include_self=include_self)
+            close(out, r32[0], what="out", exact=r64[0])
+            close(raw, r32[1], what="raw", exact=r64[1])
+            ((out * w_out.to(dev)).sum() + (raw * w_raw.to(dev)).sum()).backward()
+            close(f.grad, r32[2], rel=True, what="grad_flow", exact=r64[2], outliers=0.001)
+            close(a.grad, r32[3], rel=True, what="grad_alpha", exact=r64[3])
+            with torch.no_grad():  # the staged kernel of the no-grad path: the same values
+                out2, raw2 = WF.frame_warp_fuse(inp.to(dev), flow.to(dev), alpha.to(dev), ctx_ts.to(dev),
+                                                include_self=include_self)
+            close(out2, r32[0], what="out (no grad)", exact=r64[0])
+            close(raw2, r32[1], what="raw (no grad)", exact=r64[1])
+        except AssertionError as exc:
+            raise AssertionError(f"{what}: {exc}") from exc
 
 
 @pytest.mark.parametrize("tc,include_self", [(4, False), (2, False), (3, True), (4, True), (1, False), (1, True)])
