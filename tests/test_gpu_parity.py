@@ -863,3 +863,62 @@ def test_graphed_forward_replay(dev):
             assert torch.equal(g(*inp), fwd(*inp))
     with pytest.raises(ValueError):
         g(a[0][:1], a[1], a[2])
+
+
+def test_small_ops_seeded_fuzz(dev):
+    """The single-op entry points over shapes from a seeded generator, each against the oracle's expression of the
+    same op, forward and backward: ``grid_sample`` (any input / output raster, samples up to 20 % outside the image,
+    the three deltas), ``occ_composite`` (1 ... 32 layers, shared occlusion matrices), ``wif_fuse`` (1 ... 6 contexts,
+    5 ... 40 channels, with and without the sigmoid term).  24 cases each."""
+    import random
+    from oracle import warper_oracle as WO
+    from waldo_amd import functional as WF
+    rng = random.Random(99)
+    for case in range(24):
+        torch.manual_seed(case)
+        # --- grid_sample
+        n, c = rng.randint(1, 6), rng.randint(1, 40)
+        hi, wi, ho, wo = rng.randint(1, 70), rng.randint(1, 140), rng.randint(1, 70), rng.randint(1, 140)
+        delta = rng.choice([0.0, 0.5, 1.0])
+        x = torch.randn(n, c, hi, wi, requires_grad=True)
+        grid = (torch.rand(n, ho, wo, 2) * 2.4 - 1.2).requires_grad_()
+        ref = O.grid_sample_delta(x, grid, delta)
+        wgt = torch.randn(ref.shape)
+        (ref * wgt).sum().backward()
+        x2, g2 = x.detach().to(dev).requires_grad_(), grid.detach().to(dev).requires_grad_()
+        out = WF.grid_sample(x2, g2, delta=delta)
+        (out * wgt.to(dev)).sum().backward()
+        tag = f"case {case} grid_sample {n}x{c}x{hi}x{wi} -> {ho}x{wo} delta {delta}"
+        close(out, ref, what=tag + " out")
+        close(x2.grad, x.grad, rel=True, what=tag + " grad_x")
+        close(g2.grad, grid.grad, rel=True, what=tag + " grad_grid")
+        # --- occ_composite
+        nl, div = rng.choice([1, 2, 3, 5, 8, 9, 12, 13, 17, 18, 24, 31, 32]), rng.randint(1, 3)
+        m, h, w = div * rng.randint(1, 3), rng.randint(1, 40), rng.randint(1, 90)
+        alpha = torch.rand(m, nl, h, w, requires_grad=True)
+        occ = torch.rand(m // div, nl, nl, requires_grad=True)
+        ref = O.occlusion_product(alpha, occ.repeat_interleave(div, dim=0))
+        wgt = torch.randn(ref.shape)
+        (ref * wgt).sum().backward()
+        a2, o2 = alpha.detach().to(dev).requires_grad_(), occ.detach().to(dev).requires_grad_()
+        out = WF.occ_composite(a2, o2, occ_div=div)
+        (out * wgt.to(dev)).sum().backward()
+        tag = f"case {case} occ_composite m={m} nl={nl} {h}x{w} div={div}"
+        close(out, ref, what=tag + " out")
+        close(a2.grad, alpha.grad, rel=True, what=tag + " grad_alpha")
+        close(o2.grad, occ.grad, rel=True, what=tag + " grad_occ")
+        # --- wif_fuse
+        b, t, tc, cv, co = rng.randint(1, 2), rng.randint(1, 3), rng.randint(1, 6), rng.randint(5, 40), rng.choice([4, 5])
+        h, w, ab = rng.randint(1, 50), rng.randint(1, 130), rng.random() < 0.7
+        vid = torch.randn(b, t, tc, cv, h, w, requires_grad=True)
+        net = torch.randn(b, t, tc, co, h, w, requires_grad=True)
+        ref = WO.wif_fuse(vid, net, ab=ab)
+        wgt = torch.randn(ref.shape)
+        (ref * wgt).sum().backward()
+        v2, n2 = vid.detach().to(dev).requires_grad_(), net.detach().to(dev).requires_grad_()
+        out = WF.wif_fuse(v2, n2, ab=ab)
+        (out * wgt.to(dev)).sum().backward()
+        tag = f"case {case} wif_fuse b={b} t={t} tc={tc} c={cv} co={co} {h}x{w} ab={ab}"
+        close(out, ref, what=tag + " out")
+        close(v2.grad, vid.grad, rel=True, what=tag + " grad_vid")
+        close(n2.grad, net.grad, rel=True, what=tag + " grad_net")
