@@ -112,7 +112,8 @@ def _assemble(pipe_full, blocks, key):
     return demo.units_to_clips(key, full, b, t, ctx, len(blocks), pipe_full.vid)
 
 
-@pytest.mark.parametrize("name,clips,worlds", [("C4", 1, (2, 5, 8)), ("C4", 2, (3, 4)), ("C5", 1, (8,))])
+@pytest.mark.parametrize("name,clips,worlds", [("C4", 1, (2, 5, 8)), ("C4", 2, (3, 4)), ("C5", 1, (8,)),
+                                               ("C4", 3, (2, 7)), ("C5", 2, (3, 5))])
 def test_predict_split_by_output_frames_has_the_same_bits(dev, name, clips, worlds):
     """One job split over `world` ranks by (b, t) output units (demo.predict_sharded): every rank decodes
     its contiguous block from the clip's context frames and its OWN frames' poses only, and the blocks put together
