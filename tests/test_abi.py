@@ -90,6 +90,25 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)
 
 
+def test_only_the_checker_legs_touch_the_oracle():
+    """Outside ``tests/`` the oracle is imported in exactly two places -- ``__graft_entry__.smoke()`` (the checker of the
+    smoke run) and ``bench.py``'s ``cpu_baseline`` child -- and by no development script (``tools_dev/``)."""
+    import re
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools_dev")):
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(bench)]
+    assert len(hits) == 1
+    inside = bench.rfind("\ndef ", 0, hits[0])
+    assert bench[inside:].lstrip().startswith("def cpu_baseline_child"), bench[inside:inside + 60]
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    hits = [m.start() for m in pat.finditer(entry)]
+    assert hits and all(entry[entry.rfind("\ndef ", 0, h):].lstrip().startswith("def smoke") for h in hits)
+
+
 def test_timing_only_ablations_cannot_reach_a_product_build(tmp_path):
     """A WALDO_ABL_* switch (timing-only, may compute wrong values) without -DWALDO_TIMING_ONLY_BUILD does not get
     past the preprocessor; with it, the library reports version 0."""
