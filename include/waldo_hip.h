@@ -89,9 +89,10 @@ int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid, float* grad
 
 /* ---------------------------------------------------------------------------------------
  * A3. Grid inversion by forward splat + hole filling -- replaces InverseWarp.forward
- *     (models/modules/warp.py:71-174; num_perm == 1, kernel_size == 3, pad == True) and its autograd.
+ *     (models/modules/warp.py:71-174; pad == True) and its autograd.
  *   src_grid (B,Hs,Ws,2) layer->image grid;  src_id (Hs,Ws,2), tgt_id (H,W,2) the identity grids
- *   (reference buffers `src_grid`, `tgt_grid`);  gauss3x3 (9) the reference buffer `kernel`;
+ *   (reference buffers `src_grid`, `tgt_grid`);  gauss (ksize*ksize) the reference buffer `kernel`, ksize = the
+ *   module's `kernel_size`: odd, 1 ... 15 (3 in every script: one launch; other sizes run the fill passes one by one);
  *   out (B,H,W,2) image->layer grid.  Hp = H + 2*(niter+1), Wp likewise.
  * Among several samples landing on one cell the lowest sample index wins (the reference's answer
  * under a stable sort; its own tie-break is implementation-defined).
@@ -102,10 +103,10 @@ int waldo_tps_grid_bwd(const float* basis_t, const float* grad_grid, float* grad
  * them, plus gfield (B,2,Hp*Wp) f32 scratch; grad_src_grid (B,Hs,Ws,2) is overwritten.
  * ------------------------------------------------------------------------------------- */
 int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id, const float* tgt_id,
-                           const float* gauss3x3, float* out, float* dxy, int* cell, int* winner,
+                           const float* gauss, float* out, float* dxy, int* cell, int* winner,
                            float* field_a, float* field_b, unsigned char* fill_iter, float* denom,
                            unsigned char* mask_a, unsigned char* mask_b, int64_t B, int Hs, int Ws,
-                           int H, int W, int niter, int erode, waldo_stream_t stream);
+                           int H, int W, int niter, int erode, int ksize, waldo_stream_t stream);
 /* The same with the tie-break order given (InverseWarp with num_perm > 1, warp.py:91-111, one
  * call per permutation; the results are averaged by the caller -- the fill, the erosion and the
  * final grid are linear in the elected field for a fixed set of occupied cells, and that set does
@@ -113,15 +114,15 @@ int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id, const flo
  * reference buffer `perm`), rank (H*W) i32 its inverse.  Among the samples landing on one cell
  * the one standing first in `order` wins.  waldo_inverse_warp_bwd serves both. */
 int waldo_inverse_warp_order_fwd(const float* src_grid, const float* src_id, const float* tgt_id,
-                                 const float* gauss3x3, const int* rank, const int* order,
+                                 const float* gauss, const int* rank, const int* order,
                                  float* out, float* dxy, int* cell, int* winner, float* field_a,
                                  float* field_b, unsigned char* fill_iter, float* denom,
                                  unsigned char* mask_a, unsigned char* mask_b, int64_t B, int Hs,
-                                 int Ws, int H, int W, int niter, int erode, waldo_stream_t stream);
-int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3, const int* cell,
+                                 int Ws, int H, int W, int niter, int erode, int ksize, waldo_stream_t stream);
+int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss, const int* cell,
                            const int* winner, const unsigned char* fill_iter, const float* denom,
                            const unsigned char* mask, float* gfield, float* grad_src_grid,
-                           int64_t B, int Hs, int Ws, int H, int W, int niter,
+                           int64_t B, int Hs, int Ws, int H, int W, int niter, int ksize,
                            waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -166,6 +166,25 @@ def gen_inverse_warp(ns):
              hs=hs, ws=ws, ht=ht, wt=wt, erode=erode)
 
 
+def gen_inverse_warp_kernel_size(ns):
+    """kernel_size 5 and 7 (warp.py:58-63, 140-146: the fill's Gaussian window; no script passes one, the module takes
+    it)."""
+    g = torch.Generator().manual_seed(25)
+    ctrl = ns.get_grid(4, 4).view(-1, 2)
+    for tag, (hs, ws, ht, wt, erode, shrink, sigma, ks, niter) in {
+            "k5": (8, 8, 16, 32, True, 0.55, 0.1, 5, 5), "k7": (12, 20, 24, 40, False, 0.5, 0.15, 7, 4)}.items():
+        inv = ns.InverseWarp(hs, ws, ht, wt, kernel_size=ks)
+        tps = ns.TPSWarp(hs, ws, ctrl)
+        pts = ctrl.view(1, 16, 2) * shrink + sigma * torch.randn(3, 16, 2, generator=g)
+        src_grid = tps(pts).detach().requires_grad_()
+        with R.stable_sort():
+            out = inv(src_grid, niter=niter, erode=erode)
+        wgt = torch.randn(out.shape, generator=g)
+        (out * wgt).sum().backward()
+        save(f"inverse_warp_{tag}", src_grid=src_grid, out=out, wgt=wgt, grad_src_grid=src_grid.grad,
+             hs=hs, ws=ws, ht=ht, wt=wt, erode=erode, kernel_size=ks, niter=niter)
+
+
 def gen_inverse_warp_perm(ns):
     """num_perm > 1 (warp.py:91-111): the module's own randperm buffer goes into the fixture."""
     g = torch.Generator().manual_seed(15)
@@ -420,7 +439,7 @@ def main():
     ns = R.load()
     only = set(sys.argv[1:])  # e.g. `make_golden.py inverse_warp_perm`; none = all
     for fn in (gen_tps, gen_grid_sample, gen_occ_comp, gen_warp_composite, gen_warp_composite_delta, gen_inverse_warp,
-               gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers, gen_pose_affine):
+               gen_inverse_warp_kernel_size, gen_inverse_warp_perm, gen_warper, gen_inpaint, gen_producers, gen_pose_affine):
         if not only or fn.__name__[4:] in only:
             fn(ns)
     if not only or "demo_clip" in only:

@@ -44,6 +44,44 @@ def test_inverse_warp_golden(dev, golden, tag):
     close(sg.grad, g["grad_src_grid"], rel=True, what="grad_src_grid")
 
 
+@pytest.mark.parametrize("tag", ["k5", "k7"])
+def test_inverse_warp_kernel_size_golden(dev, golden, tag):
+    """``InverseWarp(kernel_size=5 / 7)`` (warp.py:58-63, 140-146; no script passes one) against the reference's own
+    outputs and gradients: the fill passes run one by one with the K x K window."""
+    import waldo_amd
+    g = golden(f"inverse_warp_{tag}")
+    mod = waldo_amd.InverseWarp(int(g["hs"]), int(g["ws"]), int(g["ht"]), int(g["wt"]),
+                                kernel_size=int(g["kernel_size"])).to(dev)
+    sg = g["src_grid"].to(dev).requires_grad_()
+    out = mod(sg, niter=int(g["niter"]), erode=bool(g["erode"]))
+    close(out, g["out"], what="out")
+    (out * g["wgt"].to(dev)).sum().backward()
+    close(sg.grad, g["grad_src_grid"], rel=True, what="grad_src_grid")
+
+
+@pytest.mark.parametrize("ks,cfg", [(5, (8, 8, 40, 70, 6, True)), (7, (16, 32, 16, 32, 3, False)), (9, (6, 6, 70, 40, 2, True)),
+                                    (1, (8, 8, 8, 8, 0, False)), (5, (64, 64, 128, 256, 5, True))])
+def test_inverse_warp_kernel_size_random(dev, ks, cfg):
+    """Other odd kernel sizes and rasters against the oracle, forward and backward (kernel_size 1 with no fill pass: the
+    1 x 1 window would divide by the empty neighbourhood's zero weight, in the reference too)."""
+    import waldo_amd
+    hs, ws, ht, wt, niter, erode = cfg
+    torch.manual_seed(ks * 100 + wt)
+    ctrl = O.get_grid(4, 4).view(-1, 2)
+    inv, rep = O.tps_init(hs, ws, ctrl)
+    pts = ctrl.view(1, 16, 2) * 0.6 + 0.12 * torch.randn(3, 16, 2)
+    sg = O.tps_grid(inv, rep, pts, hs, ws).requires_grad_()
+    ref = O.inverse_warp(sg, (ht, wt), niter=niter, erode=erode, kernel_size=ks)
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    mod = waldo_amd.InverseWarp(hs, ws, ht, wt, kernel_size=ks).to(dev)
+    s2 = sg.detach().to(dev).requires_grad_()
+    out = mod(s2, niter=niter, erode=erode)
+    close(out, ref, what="out")
+    (out * wgt.to(dev)).sum().backward()
+    close(s2.grad, sg.grad, rel=True, what="grad")
+
+
 @pytest.mark.parametrize("tag", ["perm3", "perm4"])
 def test_inverse_warp_num_perm_golden(dev, golden, tag):
     """num_perm > 1 (warp.py:91-111) against the reference's own output for its own perm buffer:
@@ -175,8 +213,8 @@ def test_inverse_warp_identity_and_errors(dev):
     close(mod(ident, erode=False), ident.cpu(), 1e-6, what="identity")
     with pytest.raises(ValueError):
         mod(ident, pad=False)
-    with pytest.raises(NotImplementedError):
-        waldo_amd.InverseWarp(8, 8, 8, 8, kernel_size=5).to(dev)(O.get_grid(8, 8).to(dev))
+    with pytest.raises(ValueError):  # an even window changes the raster under conv2d(padding=k // 2): fails in the reference
+        waldo_amd.InverseWarp(8, 8, 8, 8, kernel_size=4).to(dev)(O.get_grid(8, 8).to(dev))
     two = waldo_amd.InverseWarp(12, 20, 12, 20, num_perm=2).to(dev)  # no collisions: order is moot
     close(two(ident, erode=False), ident.cpu(), 1e-6, what="identity, num_perm=2")
     assert mod(torch.zeros(0, 12, 20, 2, device=dev)).shape == (0, 12, 20, 2)

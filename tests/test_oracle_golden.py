@@ -118,6 +118,20 @@ def test_inverse_warp(golden, tag):
     close(sg.grad, g["grad_src_grid"], 1e-5)
 
 
+@pytest.mark.parametrize("tag", ["k5", "k7"])
+def test_inverse_warp_kernel_size(golden, tag):
+    """kernel_size 5 / 7 (warp.py:58-63, 140-146): the reference's own outputs for a wider Gaussian fill window."""
+    g = golden(f"inverse_warp_{tag}")
+    sg = g["src_grid"].clone().requires_grad_()
+    out = O.inverse_warp(sg, (int(g["ht"]), int(g["wt"])), niter=int(g["niter"]), erode=bool(g["erode"]),
+                         kernel_size=int(g["kernel_size"]))
+    close(out, g["out"], 1e-6)
+    (out * g["wgt"]).sum().backward()
+    close(sg.grad, g["grad_src_grid"], 1e-5)
+    three = O.inverse_warp(sg.detach(), (int(g["ht"]), int(g["wt"])), niter=int(g["niter"]), erode=bool(g["erode"]))
+    assert (three - g["out"]).abs().max() > 1e-4  # the window matters in these cases
+
+
 @pytest.mark.parametrize("tag", ["perm3", "perm4"])
 def test_inverse_warp_num_perm(golden, tag):
     """num_perm > 1: the reference's output for its own randperm buffer (stable sort)."""

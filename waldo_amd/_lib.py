@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1015
+ABI_VERSION = 1016
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -29,9 +29,9 @@ SIGNATURES = {
     "waldo_tps_mapping_bwd": [_c_f, _c_f, _c_f, _i64, _int, _stream],
     "waldo_tps_grid_fwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
     "waldo_tps_grid_bwd": [_c_f, _c_f, _c_f, _i64, _i64, _int, _stream],
-    "waldo_inverse_warp_fwd": [_c_f] * 14 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
-    "waldo_inverse_warp_order_fwd": [_c_f] * 16 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
-    "waldo_inverse_warp_bwd": [_c_f] * 9 + [_i64, _int, _int, _int, _int, _int, _stream],
+    "waldo_inverse_warp_fwd": [_c_f] * 14 + [_i64, _int, _int, _int, _int, _int, _int, _int, _stream],
+    "waldo_inverse_warp_order_fwd": [_c_f] * 16 + [_i64, _int, _int, _int, _int, _int, _int, _int, _stream],
+    "waldo_inverse_warp_bwd": [_c_f] * 9 + [_i64, _int, _int, _int, _int, _int, _int, _stream],
     "waldo_grid_sample2d_fwd": [_c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,
                                 _i64, _i64, _i64, _stream],
     "waldo_grid_sample2d_ex_fwd": [_c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int, _int, _flt, _i64,

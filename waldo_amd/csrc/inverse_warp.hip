@@ -1,5 +1,6 @@
 // A3: grid inversion by forward splat + hole filling -- replaces InverseWarp.forward
-// (models/modules/warp.py:71-174, num_perm == 1, kernel_size == 3, pad == True) and its autograd.
+// (models/modules/warp.py:71-174, pad == True; any odd kernel_size -- the one-launch kernels are written for the 3 x 3
+// every script uses, other sizes run pass by pass) and its autograd.
 //
 //   1. displacement d = src_grid - identity, bilinearly resized to the target raster
 //      (F.interpolate, align_corners=False)                                       warp.py:75-79
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void iw_fill_kernel(const float* __restrict
                                                          unsigned char* __restrict__ fill_iter,
                                                          float* __restrict__ denom,
                                                          const float* __restrict__ kern, int Hp,
-                                                         int Wp, int iter) {
+                                                         int Wp, int iter, int K) {
   const int64_t b = blockIdx.y;
   const int HWp = Hp * Wp;
   const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -126,16 +127,17 @@ __global__ __launch_bounds__(kBlock) void iw_fill_kernel(const float* __restrict
     const bool up = y > 0 && fi[e - Wp] < iter, dn = y < Hp - 1 && fi[e + Wp] < iter;
     const bool lf = x > 0 && fi[e - 1] < iter, rt = x < Wp - 1 && fi[e + 1] < iter;
     if (up || dn || lf || rt) {
+      // the K x K Gaussian-weighted mean of the filled neighbours (warp.py:140-146: conv2d with zero padding K / 2),
+      // row by row -- for K == 3 the order iw_fused_kernel sums in
+      const int r = K / 2;
       float sx = 0.0f, sy = 0.0f, sm = 0.0f;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
+      for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
           const int yy = y + dy, xx = x + dx;
           if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
             const int n = yy * Wp + xx;
             if (fi[n] < iter) {  // unfilled cells hold 0 and contribute nothing
-              const float k = kern[(dy + 1) * 3 + (dx + 1)];
+              const float k = kern[(dy + r) * K + (dx + r)];
               sx = fmaf(k, fx[n], sx);
               sy = fmaf(k, fy[n], sy);
               sm += k;
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fill_kernel(float* __restrict__
                                                              const unsigned char* __restrict__ fill_iter,
                                                              const float* __restrict__ denom,
                                                              const float* __restrict__ kern, int Hp,
-                                                             int Wp, int iter) {
+                                                             int Wp, int iter, int K) {
   const int64_t b = blockIdx.y;
   const int HWp = Hp * Wp;
   const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -512,17 +514,16 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_fill_kernel(float* __restrict__
   const int y = e / Wp, x = e - y * Wp;
   float* gx = gfield + (b * 2 + 0) * HWp;
   float* gy = gfield + (b * 2 + 1) * HWp;
+  const int r = K / 2;
   float ax = 0.0f, ay = 0.0f;
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
       const int yy = y + dy, xx = x + dx;
       if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
         const int n = yy * Wp + xx;
         if (fi[n] == iter) {
-          // this cell sits at offset (-dy, -dx) in n's stencil; the Gaussian is symmetric
-          const float k = kern[(1 - dy) * 3 + (1 - dx)] / denom[b * HWp + n];
+          // this cell sits at offset (-dy, -dx) in n's stencil
+          const float k = kern[(r - dy) * K + (r - dx)] / denom[b * HWp + n];
           ax = fmaf(k, gx[n], ax);
           ay = fmaf(k, gy[n], ay);
         }
@@ -740,11 +741,16 @@ __global__ __launch_bounds__(kBlock) void iw_bwd_gather_kernel(
   g[1] = ay;
 }
 
-static int check_iw(const char* fn, int64_t B, int Hs, int Ws, int H, int W, int niter) {
+static int check_iw(const char* fn, int64_t B, int Hs, int Ws, int H, int W, int niter, int ksize) {
   if (B < 0 || Hs < 1 || Ws < 1 || H < 1 || W < 1 || niter < 0 || niter > 200 || B > 65535 ||
       (int64_t)(H + 2 * niter + 2) * (W + 2 * niter + 2) > 2147483647 / 4) {
     set_error("%s: bad shape B=%lld src=%dx%d tgt=%dx%d niter=%d (B <= 65535, niter <= 200)", fn,
               (long long)B, Hs, Ws, H, W, niter);
+    return WALDO_EINVAL;
+  }
+  if (ksize < 1 || ksize > 15 || ksize % 2 == 0) {
+    set_error("%s: kernel size %d (odd, 1 ... 15: the reference's conv2d with padding K / 2 keeps the raster for odd K only)",
+              fn, ksize);
     return WALDO_EINVAL;
   }
   return WALDO_OK;
@@ -756,54 +762,54 @@ using namespace waldo;
 
 namespace waldo {
 static int inverse_warp_fwd_impl(const char* fn, const float* src_grid, const float* src_id,
-                                 const float* tgt_id, const float* gauss3x3, float* out, float* dxy,
+                                 const float* tgt_id, const float* gauss, float* out, float* dxy,
                                  int* cell, int* winner, float* field_a, float* field_b,
                                  unsigned char* fill_iter, float* denom, unsigned char* mask_a,
                                  unsigned char* mask_b, const int* rank, const int* order, int64_t B,
-                                 int Hs, int Ws, int H, int W, int niter, int erode,
+                                 int Hs, int Ws, int H, int W, int niter, int erode, int ksize,
                                  waldo_stream_t stream);
 }
 
 extern "C" int waldo_inverse_warp_fwd(const float* src_grid, const float* src_id,
-                                      const float* tgt_id, const float* gauss3x3, float* out,
+                                      const float* tgt_id, const float* gauss, float* out,
                                       float* dxy, int* cell, int* winner, float* field_a,
                                       float* field_b, unsigned char* fill_iter, float* denom,
                                       unsigned char* mask_a, unsigned char* mask_b, int64_t B,
-                                      int Hs, int Ws, int H, int W, int niter, int erode,
+                                      int Hs, int Ws, int H, int W, int niter, int erode, int ksize,
                                       waldo_stream_t stream) {
-  return inverse_warp_fwd_impl("waldo_inverse_warp_fwd", src_grid, src_id, tgt_id, gauss3x3, out,
+  return inverse_warp_fwd_impl("waldo_inverse_warp_fwd", src_grid, src_id, tgt_id, gauss, out,
                                dxy, cell, winner, field_a, field_b, fill_iter, denom, mask_a, mask_b,
-                               nullptr, nullptr, B, Hs, Ws, H, W, niter, erode, stream);
+                               nullptr, nullptr, B, Hs, Ws, H, W, niter, erode, ksize, stream);
 }
 
 extern "C" int waldo_inverse_warp_order_fwd(const float* src_grid, const float* src_id,
-                                            const float* tgt_id, const float* gauss3x3,
+                                            const float* tgt_id, const float* gauss,
                                             const int* rank, const int* order, float* out,
                                             float* dxy, int* cell, int* winner, float* field_a,
                                             float* field_b, unsigned char* fill_iter, float* denom,
                                             unsigned char* mask_a, unsigned char* mask_b, int64_t B,
-                                            int Hs, int Ws, int H, int W, int niter, int erode,
+                                            int Hs, int Ws, int H, int W, int niter, int erode, int ksize,
                                             waldo_stream_t stream) {
   if (B > 0 && (!rank || !order)) {
     set_error("waldo_inverse_warp_order_fwd: null pointer");
     return WALDO_EINVAL;
   }
-  return inverse_warp_fwd_impl("waldo_inverse_warp_order_fwd", src_grid, src_id, tgt_id, gauss3x3,
+  return inverse_warp_fwd_impl("waldo_inverse_warp_order_fwd", src_grid, src_id, tgt_id, gauss,
                                out, dxy, cell, winner, field_a, field_b, fill_iter, denom, mask_a,
-                               mask_b, rank, order, B, Hs, Ws, H, W, niter, erode, stream);
+                               mask_b, rank, order, B, Hs, Ws, H, W, niter, erode, ksize, stream);
 }
 
 int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const float* src_id,
-                                        const float* tgt_id, const float* gauss3x3, float* out,
+                                        const float* tgt_id, const float* gauss, float* out,
                                         float* dxy, int* cell, int* winner, float* field_a,
                                         float* field_b, unsigned char* fill_iter, float* denom,
                                         unsigned char* mask_a, unsigned char* mask_b,
                                         const int* rank, const int* order, int64_t B, int Hs, int Ws,
-                                        int H, int W, int niter, int erode, waldo_stream_t stream) {
-  int rc = check_iw(fn, B, Hs, Ws, H, W, niter);
+                                        int H, int W, int niter, int erode, int ksize, waldo_stream_t stream) {
+  int rc = check_iw(fn, B, Hs, Ws, H, W, niter, ksize);
   if (rc) return rc;
   if (B == 0) return WALDO_OK;
-  if (!src_grid || !src_id || !tgt_id || !gauss3x3 || !out || !dxy || !cell || !winner ||
+  if (!src_grid || !src_id || !tgt_id || !gauss || !out || !dxy || !cell || !winner ||
       !field_a || !field_b || !fill_iter || !denom || !mask_a || !mask_b) {
     set_error("%s: null pointer", fn);
     return WALDO_EINVAL;
@@ -825,9 +831,10 @@ int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const fl
   const bool passes = debug_option(WALDO_DEBUG_IW_PASSES);
   const int tiles_x = (Wp + kFusedTW - 1) / kFusedTW, tiles_y = (Hp + kFusedTH - 1) / kFusedTH;
   const size_t lds = (size_t)(kFusedTH + 4 * niter + 2) * (kFusedTW + 4 * niter + 2) * (2 * sizeof(float) + 3);
-  if (!passes && lds <= kFusedMaxLds && (int64_t)B * tiles_x * tiles_y <= 2147483647) {
+  // (the one-launch kernel is written for the 3 x 3 kernel every script uses; other sizes take the passes one by one)
+  if (!passes && ksize == 3 && lds <= kFusedMaxLds && (int64_t)B * tiles_x * tiles_y <= 2147483647) {
     hipLaunchKernelGGL(iw_fused_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(kBlock), lds, st, dxy,
-                       winner, gauss3x3, tgt_id, out, fill_iter, denom, mask_a, H, W, niter, erode, tiles_x,
+                       winner, gauss, tgt_id, out, fill_iter, denom, mask_a, H, W, niter, erode, tiles_x,
                        tiles_x * tiles_y);
     return launch_status(fn);
   }
@@ -837,7 +844,7 @@ int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const fl
   float* fout = field_b;
   for (int it = 1; it <= niter; ++it) {
     hipLaunchKernelGGL(iw_fill_kernel, gp, dim3(kBlock), 0, st, fin, fout, fill_iter, denom,
-                       gauss3x3, Hp, Wp, it);
+                       gauss, Hp, Wp, it, ksize);
     hipLaunchKernelGGL(iw_mark_kernel, gp, dim3(kBlock), 0, st, fill_iter, denom, Hp, Wp, it);
     float* t = fin;
     fin = fout;
@@ -864,16 +871,16 @@ int waldo::inverse_warp_fwd_impl(const char* fn, const float* src_grid, const fl
   return launch_status(fn);
 }
 
-extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3x3,
+extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss,
                                       const int* cell, const int* winner,
                                       const unsigned char* fill_iter, const float* denom,
                                       const unsigned char* mask, float* gfield,
                                       float* grad_src_grid, int64_t B, int Hs, int Ws, int H, int W,
-                                      int niter, waldo_stream_t stream) {
-  int rc = check_iw("waldo_inverse_warp_bwd", B, Hs, Ws, H, W, niter);
+                                      int niter, int ksize, waldo_stream_t stream) {
+  int rc = check_iw("waldo_inverse_warp_bwd", B, Hs, Ws, H, W, niter, ksize);
   if (rc) return rc;
   if (B == 0) return WALDO_OK;
-  if (!grad_out || !gauss3x3 || !cell || !winner || !fill_iter || !denom || !mask || !gfield ||
+  if (!grad_out || !gauss || !cell || !winner || !fill_iter || !denom || !mask || !gfield ||
       !grad_src_grid) {
     set_error("waldo_inverse_warp_bwd: null pointer");
     return WALDO_EINVAL;
@@ -892,14 +899,14 @@ extern "C" int waldo_inverse_warp_bwd(const float* grad_out, const float* gauss3
   const int sink_lists = bw_rw <= 64 && 4 * bw_rh <= kBlock && bw_lists <= kFusedMaxLds;
   if (sink_lists) bw_lds = bw_lists;
   const int btx = (Wp + kBwdTW - 1) / kBwdTW, bty = (Hp + kBwdTH - 1) / kBwdTH;
-  if (!debug_option(WALDO_DEBUG_IW_PASSES) && bw_lds <= kFusedMaxLds && B * btx * bty <= 2147483647ll) {
+  if (!debug_option(WALDO_DEBUG_IW_PASSES) && ksize == 3 && bw_lds <= kFusedMaxLds && B * btx * bty <= 2147483647ll) {
     hipLaunchKernelGGL(iw_bwd_fused_kernel, dim3((unsigned)(B * btx * bty)), dim3(kBlock), bw_lds, st, grad_out,
-                       mask, fill_iter, denom, gauss3x3, gfield, H, W, niter, btx, btx * bty, sink_lists);
+                       mask, fill_iter, denom, gauss, gfield, H, W, niter, btx, btx * bty, sink_lists);
   } else {
     hipLaunchKernelGGL(iw_bwd_init_kernel, gp, dim3(kBlock), 0, st, grad_out, mask, gfield, H, W, pad);
     for (int it = niter; it >= 1; --it)
       hipLaunchKernelGGL(iw_bwd_fill_kernel, gp, dim3(kBlock), 0, st, gfield, fill_iter, denom,
-                         gauss3x3, Hp, Wp, it);
+                         gauss, Hp, Wp, it, ksize);
   }
   hipLaunchKernelGGL(iw_bwd_gather_kernel, dim3((Hs * Ws + kBlock - 1) / kBlock, (unsigned)B), dim3(kBlock), 0,
                      st, gfield, cell, winner, grad_src_grid, Hs, Ws, H, W, pad);

@@ -172,6 +172,9 @@ class _InverseWarp(torch.autograd.Function):
         src_grid, src_id, tgt_id, gauss = _c(src_grid), _c(src_id), _c(tgt_id), _c(gauss)
         b, hs, ws, _ = src_grid.shape
         h, w = tgt_id.shape[-3], tgt_id.shape[-2]
+        ksize = int(round(gauss.numel() ** 0.5))
+        if ksize * ksize != gauss.numel():
+            raise _lib.WaldoHipError(f"inverse_warp: a Gaussian kernel of {gauss.numel()} elements (K x K)")
         pad = niter + 1
         hwp = (h + 2 * pad) * (w + 2 * pad)
         dev = src_grid.device
@@ -187,7 +190,7 @@ class _InverseWarp(torch.autograd.Function):
         mask_b = torch.empty(b, hwp, dtype=torch.uint8, device=dev)
         work = (_lib.ptr(out), _lib.ptr(dxy), _lib.ptr(cell), _lib.ptr(winner), _lib.ptr(field_a),
                 _lib.ptr(field_b), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask_a),
-                _lib.ptr(mask_b), b, hs, ws, h, w, niter, int(bool(erode)))
+                _lib.ptr(mask_b), b, hs, ws, h, w, niter, int(bool(erode)), ksize)
         with _lib.on_device(dev):
             if order is None:
                 _lib.call("waldo_inverse_warp_fwd", _lib.ptr(src_grid), _lib.ptr(src_id),
@@ -203,28 +206,29 @@ class _InverseWarp(torch.autograd.Function):
                           _lib.ptr(tgt_id), _lib.ptr(gauss), _lib.ptr(rank), _lib.ptr(order), *work,
                           _lib.current_stream(dev))
         ctx.save_for_backward(gauss, cell, winner, fill_iter, denom, mask_a)
-        ctx.cfg = (b, hs, ws, h, w, niter)
+        ctx.cfg = (b, hs, ws, h, w, niter, ksize)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         gauss, cell, winner, fill_iter, denom, mask = ctx.saved_tensors
-        b, hs, ws, h, w, niter = ctx.cfg
+        b, hs, ws, h, w, niter, ksize = ctx.cfg
         grad_out = _c(grad_out)
         gfield = grad_out.new_empty(b, 2, fill_iter.shape[1])
         gsrc = grad_out.new_empty(b, hs, ws, 2)
         with _lib.on_device(grad_out.device):
             _lib.call("waldo_inverse_warp_bwd", _lib.ptr(grad_out), _lib.ptr(gauss), _lib.ptr(cell),
                       _lib.ptr(winner), _lib.ptr(fill_iter), _lib.ptr(denom), _lib.ptr(mask),
-                      _lib.ptr(gfield), _lib.ptr(gsrc), b, hs, ws, h, w, niter,
+                      _lib.ptr(gfield), _lib.ptr(gsrc), b, hs, ws, h, w, niter, ksize,
                       _lib.current_stream(grad_out.device))
         return gsrc, None, None, None, None, None, None, None
 
 
-def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True, perm=None):
-    """InverseWarp.forward (models/modules/warp.py:71-174; 3x3 kernel, pad).
+def inverse_warp(src_grid, src_id, tgt_id, gauss, niter=5, erode=True, perm=None):
+    """InverseWarp.forward (models/modules/warp.py:71-174; pad).
     src_grid (B, Hs, Ws, 2) -> (B, H, W, 2); src_id / tgt_id are the identity grids of the two
-    rasters, gauss3x3 the normalised Gaussian (the reference module's buffers).
+    rasters, gauss the normalised K x K Gaussian, flattened (the reference module's buffers; K odd -- 3 in every
+    script: one launch each way; other sizes run the fill passes one by one).
 
     perm None: num_perm == 1 (the lowest sample index wins a contested cell, warp.py:113-123).
     perm (P, H*W) integer, P > 1: the reference's tie-break averaging (warp.py:91-111): for each
@@ -232,7 +236,7 @@ def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True, perm=N
     fill / erosion / crop are linear in the elected field for a fixed set of occupied cells (which
     does not depend on the order), so the average is taken over the P results instead."""
     if perm is None:
-        return _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode), None,
+        return _InverseWarp.apply(src_grid, src_id, tgt_id, gauss, int(niter), bool(erode), None,
                                   None)
     order = perm.to(torch.int32)
     rank = torch.empty_like(order)
@@ -240,7 +244,7 @@ def inverse_warp(src_grid, src_id, tgt_id, gauss3x3, niter=5, erode=True, perm=N
     rank.scatter_(1, order.long(), pos.expand_as(order))
     out = None
     for p in range(order.shape[0]):
-        o = _InverseWarp.apply(src_grid, src_id, tgt_id, gauss3x3, int(niter), bool(erode), rank[p],
+        o = _InverseWarp.apply(src_grid, src_id, tgt_id, gauss, int(niter), bool(erode), rank[p],
                                order[p])
         out = o if out is None else out + o
     return out / order.shape[0]

@@ -77,7 +77,8 @@ class InverseWarp(nn.Module):
     Differences from the reference, on purpose: among colliding samples the first in tie-break
     order wins (sample index for ``num_perm == 1``, position in ``perm[p]`` for ``num_perm > 1``;
     the reference's result under a stable sort -- its own depends on torch.sort's implementation);
-    ``pad=False`` (which fails with a shape error in the reference) raises.  ``num_perm > 1``
+    ``pad=False`` and an even ``kernel_size`` (which fail with shape errors in the reference) raise; every odd
+    ``kernel_size`` works (3, the default every script uses, in one launch each way).  ``num_perm > 1``
     (warp.py:91-111, unused by every script) runs one inversion per permutation and averages the
     results, which equals averaging the elected fields first (see ``WF.inverse_warp``)."""
 
@@ -95,11 +96,11 @@ class InverseWarp(nn.Module):
         self.register_buffer("perm", torch.stack([torch.randperm(tgt_height * tgt_width) for _ in range(num_perm)]))
 
     def forward(self, src_grid, niter=5, pad=True, erode=True):
-        if self.kernel_size != 3:
-            raise NotImplementedError("InverseWarp: only kernel_size == 3 (what the reference's "
-                                      "scripts use) is implemented")
+        if self.kernel_size % 2 == 0:
+            raise ValueError("InverseWarp: an even kernel_size changes the raster under conv2d(padding=k // 2) and "
+                             "fails in the reference (warp.py:140-146); not supported")
         if not pad:
             raise ValueError("InverseWarp: pad=False fails with a shape error in the reference "
                              "(warp.py:169-173); not supported")
-        return WF.inverse_warp(src_grid, self.src_grid[0], self.tgt_grid[0], self.kernel.view(9),
+        return WF.inverse_warp(src_grid, self.src_grid[0], self.tgt_grid[0], self.kernel.reshape(-1),
                                niter=niter, erode=erode, perm=self.perm if self.num_perm > 1 else None)
