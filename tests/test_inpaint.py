@@ -276,6 +276,10 @@ def test_inpaint_timing_at_recipe_size(dev):
         lin.bias.copy_(d["bias"])
     wif, warper = WIF(opt, unet=lin).to(dev), Warper(wopt).to(dev)
     dd = {k: v.to(dev) for k, v in d.items()}
+    # raw_output as ``decode_output`` hands it over: a (B, Tc, Tp, ...) VIEW of the (B, Tp, Tc, ...) buffer the frame warp
+    # writes -- the per-frame ``forward(raw_output[:, :, t:t+1])`` of wif.py:88 then permutes back to
+    # contiguous memory and copies nothing (a contiguous (B, Tc, Tp, ...) tensor costs 0.29 GB of copies per frame)
+    dd["raw_output"] = dd["raw_output"].permute(0, 2, 1, 3, 4, 5).contiguous().permute(0, 2, 1, 3, 4, 5)
     with torch.no_grad():
         grid = warper(dd["obj_pose"], dd["bg_pose"])
 
