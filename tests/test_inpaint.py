@@ -215,7 +215,7 @@ def recipe_inpaint_inputs(seed=31, tp=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_inpaint_at_recipe_size(dev, tag):
     """WIF.inpaint (wif.py:58-226; its warps wif.py:96-121, 179-204) at the raster it runs at -- 512 x 1024, B = 1, four
     context frames, 12 layers (BASELINE config 5's shape): properties (shape, finite values, the context frames passed
