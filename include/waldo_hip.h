@@ -475,6 +475,18 @@ int waldo_mask_expand_fwd(const float* mask, float* out, float* scratch, int64_t
                           int steps, int soft, float alpha, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f3. The point-in-polygon test of WIF.inpaint (models/nets/wif.py:228-235: matplotlib.path.Path(corners)
+ * .contains_points(pts) -- radius 0, no transform -- for the region an object enters the frame from, wif.py:140-160).
+ * matplotlib's own test (the crossings-multiply test over the path's vertices, closed back to the first, in double
+ * precision) restated operation by operation, so that a point ON an edge gets matplotlib's answer.
+ *   pts (N,2) f32 on the device (x, y);  corners_host (K,2) f64 in HOST memory, read before the call returns
+ *   (3 <= K <= 16; fewer than three corners: nothing is inside, as in matplotlib);  out (N) f32: 1.0 inside, 0.0 outside
+ *   (a point with a non-finite coordinate is outside).
+ * ------------------------------------------------------------------------------------- */
+int waldo_points_in_polygon_fwd(const float* pts, const double* corners_host, int K, float* out, int64_t N,
+                                waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A8. gather_time (models/nets/lvd.py:462-467) with the frame arithmetic of the flow synthesis
  * (lvd.py:660-668, 780-787) on a clip's grids x (B,T,P,2) -- P pairs per frame:
  *   subtract != 0:  out[b,tc,tp] = x[b, ctx_ts[b,tc,tp]] - x[b, pred_ts[tp]]   (layer-space flow)

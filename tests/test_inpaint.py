@@ -125,6 +125,62 @@ def test_mask_expand_kernel_runs_the_steps_literally(dev):
 
 
 @pytest.mark.gpu
+def test_points_in_polygon_is_matplotlibs(dev):
+    """``waldo_points_in_polygon_fwd`` against ``matplotlib.path.Path.contains_points`` itself (what wif.py:228-235
+    calls): random convex and concave polygons of 3 ... 16 corners with random points, and the cases where a
+    crossings test can go either way -- points ON vertices, on edge midpoints, on horizontal and vertical edges of
+    lattice polygons, repeated and collinear corners, the pixel rasters and quadrilaterals ``WIF.inpaint`` builds (corner
+    coordinates that ARE pixel coordinates) -- every one of ~2.5 M answers equal."""
+    import matplotlib.path as mpath
+    import numpy as np
+    from waldo_amd import functional as WF
+    rng = np.random.default_rng(12)
+    total = 0
+
+    def check(corners, pts, what):
+        nonlocal total
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        want = mpath.Path(corners).contains_points(pts)
+        got = WF.points_in_polygon(torch.from_numpy(pts).to(dev), corners).cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (what, corners, pts[bad[:5]].tolist(), want[bad[:5]].tolist())
+        total += pts.shape[0]
+
+    for case in range(60):
+        k = int(rng.integers(3, 17))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        rad = rng.uniform(0.2, 1.0, k) * rng.choice([10.0, 300.0])
+        poly = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1) + rng.uniform(-50, 50, 2)
+        if case % 3 == 0:
+            poly = poly[rng.permutation(k)]                      # self-intersecting
+        if case % 4 == 0:
+            poly = np.round(poly)                                # lattice corners: horizontal / vertical / repeated ones
+        corners = [(float(x), float(y)) for x, y in poly.astype(np.float32 if case % 2 else np.float64)]
+        lo, hi = poly.min(0) - 5, poly.max(0) + 5
+        pts = [rng.uniform(lo, hi, (20000, 2)), poly, (poly + np.roll(poly, 1, 0)) / 2,
+               np.round(rng.uniform(lo, hi, (5000, 2)))]
+        for t in (0.25, 0.5, 0.125):                             # points on the edges (exactly, for lattice corners)
+            pts.append(poly * t + np.roll(poly, -1, 0) * (1 - t))
+        # every lattice point of the bounding box: rows through the corners' own y
+        gx, gy = np.meshgrid(np.arange(np.floor(lo[0]), np.ceil(hi[0]) + 1)[:200], np.arange(np.floor(lo[1]), np.ceil(hi[1]) + 1)[:200])
+        pts.append(np.stack([gx.ravel(), gy.ravel()], 1))
+        check(corners, np.concatenate(pts), f"random polygon {case}")
+    # what WIF.inpaint builds: the pixel raster of a frame against quadrilaterals whose corners are pixel coordinates
+    h, w = 128, 256
+    xs = (torch.linspace(-1 + 1 / w, 1 - 1 / w, w) * w + w - 1) / 2
+    ys = (torch.linspace(-1 + 1 / h, 1 - 1 / h, h) * h + h - 1) / 2
+    raster = torch.stack(torch.meshgrid(xs, ys, indexing="xy"), dim=-1).reshape(-1, 2).numpy()
+    for corners in ([(0, 12.0), (0, 99.0), (40.0, 101.0), (40.0, 10.0)],
+                    [(0, float(ys[12])), (0, float(ys[99])), (float(xs[40]), float(ys[101])), (float(xs[40]), float(ys[10]))],
+                    [(float(xs[200]), float(ys[5])), (float(xs[200]), float(ys[77])), (w - 1, 80.5), (w - 1, 3.25)],
+                    [(3.0, 3.0), (3.0, 3.0), (9.0, 3.0), (9.0, 9.0), (3.0, 9.0)], [(1.0, 1.0), (5.0, 5.0), (9.0, 9.0)]):
+        check(corners, raster, "pixel raster")
+    check([(0.0, 0.0), (4.0, 0.0)], raster[:100], "two corners: nothing inside")
+    check([(0.0, 0.0), (8.0, 0.0), (8.0, 8.0)], np.array([[np.nan, 1.0], [2.0, np.inf], [6.0, 2.0]]), "non-finite points")
+    assert total > 2_000_000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", sorted(INPAINT_CASES))
 def test_inpaint_hip_vs_oracle_and_reference(dev, golden, tag):
     from waldo_amd.nets import WIF, Warper
@@ -259,7 +315,8 @@ def test_inpaint_timing_at_recipe_size(dev):
     """WIF.inpaint timed at BASELINE config 5's shape (512 x 1024, B = 1, 4 context + 10 predicted frames, 12 layers,
     the default option set): one JSON line (printed; written to gpurun_out/ when that directory exists -> profiles/).
     The inpainter (MAT in the reference, outside the path) is the deterministic stub; the border-object polygon test
-    runs on the host (matplotlib), as in the reference (wif.py:228-235).  Asserts only that the call is repeatable."""
+    (matplotlib on the host in the reference, wif.py:228-235) is the library's kernel.  Asserts only that the call is
+    repeatable."""
     import json
     import os
     import time
@@ -310,9 +367,9 @@ def test_inpaint_timing_at_recipe_size(dev):
             "ms_per_call_median_of_7": round(med, 3), "ms_best": round(min(times), 3), "ms_worst": round(max(times), 3),
             "ms_per_predicted_frame": round(med / tp, 3),
             "ms_in_library_calls": round(sum(r["ms"] for r in table.values()), 3),
-            "note": "wall time per call incl. the host-side polygon test (matplotlib, a device -> host read per border "
-                    "object, as the reference) and the framework's mask arithmetic; library calls = the grid_sample2d "
-                    "warps, the time gathers and the WIF fusion", "entry_points": table}
+            "note": "wall time per call incl. the device -> host reads of the border-object branch (hit test, object id, "
+                    "polygon corners: wif.py:140-157) and the framework's mask arithmetic; library calls = the grid_sample2d "
+                    "warps, the dilations, the polygon test and the WIF fusion", "entry_points": table}
     print("[inpaint R size timing] " + json.dumps(line))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):

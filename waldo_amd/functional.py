@@ -1156,6 +1156,29 @@ def downscale_frames(input, num_frames, first_channel, factor):
     return out
 
 
+def points_in_polygon(pts, corners):
+    """``matplotlib.path.Path(corners).contains_points(pts)`` (radius 0, no transform) on the device, as ``WIF.inpaint``
+    uses it (models/nets/wif.py:228-235): ``pts`` (..., 2) float32 (x, y) on the GPU, ``corners`` a sequence of 3 ... 16
+    (x, y) pairs of host numbers -> a bool tensor of ``pts.shape[:-1]``.  matplotlib's crossings test in double precision,
+    operation by operation: points on an edge get matplotlib's answer."""
+    import ctypes
+    _lib.check_cuda(pts)
+    if pts.shape[-1] != 2:
+        raise _lib.WaldoHipError(f"points_in_polygon: points of shape {tuple(pts.shape)} (..., 2)")
+    flat = [float(v) for c in corners for v in c]
+    k = len(flat) // 2
+    if len(flat) != 2 * k or any(len(c) != 2 for c in corners) or k > 16:
+        raise _lib.WaldoHipError(f"points_in_polygon: {len(corners)} corners (pairs, at most 16)")
+    host = (ctypes.c_double * max(len(flat), 1))(*flat)
+    x = _c(pts.detach())
+    n = x.numel() // 2
+    out = x.new_empty(x.shape[:-1])
+    with _lib.on_device(x.device):
+        _lib.call("waldo_points_in_polygon_fwd", _lib.ptr(x), ctypes.addressof(host), k, _lib.ptr(out), n,
+                  _lib.current_stream(x.device))
+    return out > 0
+
+
 _EXPAND_STEPS = {None: 15, "": 15, "south": 1, "north": 2, "east": 4, "west": 8}
 
 

@@ -17,14 +17,14 @@ _MASK_T = 0.1  # `mask_thresh` of wif.py:65: a warped / composited mask counts a
 
 
 def point_in_polygon(pts, corners):
-    """(1, H, W, 2) pixel coordinates inside the polygon `corners` -> (1, 1, H, W) bool.  Host side
-    (matplotlib), exactly as the reference does it (wif.py:228-235)."""
-    import matplotlib.path as mplt_path
+    """(1, H, W, 2) pixel coordinates inside the polygon `corners` -> (1, 1, H, W) bool: the reference's
+    ``matplotlib.path.Path(corners).contains_points`` (wif.py:228-235) -- which it runs on the host, behind a copy of
+    every pixel coordinate -- as one launch of matplotlib's own crossings test in double precision
+    (``WF.points_in_polygon``; against matplotlib itself in tests/test_inpaint.py)."""
     b, h, w, _ = pts.shape
     if b != 1:
         raise ValueError("point_in_polygon: batch size 1 only (as the reference)")
-    inside = mplt_path.Path(corners).contains_points(pts.reshape(-1, 2).detach().cpu().numpy())
-    return torch.from_numpy(inside).view(b, 1, h, w).to(pts.device)
+    return WF.points_in_polygon(pts, corners).view(b, 1, h, w)
 
 
 class WIF(nn.Module):
@@ -136,12 +136,13 @@ class WIF(nn.Module):
             obj_id = int(hit.flatten(start_dim=2).sum(-1).argmax(dim=1)[0])
             sel = hit[:, obj_id].bool()
             bv, ov = pred_px[sel], orig_px[sel]
+            # (the six extrema in ONE device -> host read; the reference takes a `float()` of each)
+            by0, by1, ox0, ox1, oy0, oy1 = torch.stack([bv[:, 1].min(), bv[:, 1].max(), ov[:, 0].min(), ov[:, 0].max(),
+                                                        ov[:, 1].min(), ov[:, 1].max()]).tolist()
             if side == "left":
-                corners = [(0, float(bv[:, 1].min())), (0, float(bv[:, 1].max())),
-                           (float(ov[:, 0].max()), float(ov[:, 1].max())), (float(ov[:, 0].max()), float(ov[:, 1].min()))]
+                corners = [(0, by0), (0, by1), (ox1, oy1), (ox1, oy0)]
             else:
-                corners = [(float(ov[:, 0].min()), float(ov[:, 1].min())), (float(ov[:, 0].min()), float(ov[:, 1].max())),
-                           (w - 1, float(bv[:, 1].max())), (w - 1, float(bv[:, 1].min()))]
+                corners = [(ox0, oy0), (ox0, oy1), (w - 1, by1), (w - 1, by0)]
             region = point_in_polygon(orig_px, corners).float()
             look = inpainter((1 - region) * raw_output[:, -1, -1, :3], region)
             out.append((region, look, warper.grid_to_obj_flow_from_ref_to_pred(grid, ctx_len, ref, obj_id)))
