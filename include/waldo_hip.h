@@ -487,6 +487,29 @@ int waldo_points_in_polygon_fwd(const float* pts, const double* corners_host, in
                                 waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f3. The per-frame propagation step of WIF.inpaint (models/nets/wif.py:179-214) as one launch: the inpainted reference
+ * background warped along the background flow, up to two objects entering through the image border pasted over it, the
+ * shadow mask, the fill of the frame's holes, and the inputs of the external inpainter (csrc/inpaint_ops.hip spells the
+ * arithmetic; every operation in the framework's order: the bits of the composition it replaces).  All planes (B,.,H,W)
+ * f32 contiguous:
+ *   flow (B,H,W,2) grid-unit flow of this frame, ident (H,W,2) the identity grid (WIF.src_grid_hd);
+ *   ref_img (B,3,H,W), ref_mask (B,1,H,W), shadow (B,1,H,W) or NULL (opt.use_shadows off);
+ *   enter_region[k] (B,1,H,W), enter_look[k] (B,3,H,W), enter_flow[k] (B,H,W,2): HOST arrays of n_enter <= 2 device
+ *   pointers (read before the call returns);  img (B,3,H,W), todo (B,1,H,W), obj (B,1,H,W) the frame, its hole mask and
+ *   its object mask;
+ *   out: img_out (B,3,H,W), todo_out (B,1,H,W), inp_mask (B,1,H,W) = 1 - (1 - todo)(1 - obj), and -- fix_mask == 0 --
+ *   inp_img (B,3,H,W) = (1 - todo)(1 - obj) img  (fix_mask != 0: the inpainter takes img_out; inp_img may be NULL).
+ * waldo_inpaint_blend_fwd: out (B,3,HW) = (1 - todo) img + todo fill  (wif.py:214).
+ * ------------------------------------------------------------------------------------- */
+int waldo_inpaint_propagate_fwd(const float* flow, const float* ident, const float* ref_img, const float* ref_mask,
+                                const float* shadow, const float* const* enter_region, const float* const* enter_look,
+                                const float* const* enter_flow, int n_enter, const float* img, const float* todo,
+                                const float* obj, float* img_out, float* todo_out, float* inp_img, float* inp_mask,
+                                int64_t B, int H, int W, int soft_shadow, int fix_mask, waldo_stream_t stream);
+int waldo_inpaint_blend_fwd(const float* img, const float* todo, const float* fill, float* out, int64_t B, int64_t HW,
+                            waldo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A8. gather_time (models/nets/lvd.py:462-467) with the frame arithmetic of the flow synthesis
  * (lvd.py:660-668, 780-787) on a clip's grids x (B,T,P,2) -- P pairs per frame:
  *   subtract != 0:  out[b,tc,tp] = x[b, ctx_ts[b,tc,tp]] - x[b, pred_ts[tp]]   (layer-space flow)

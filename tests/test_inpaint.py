@@ -311,6 +311,48 @@ def test_inpaint_at_recipe_size(dev, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("over", [dict(), dict(fix_mask=True, soft_shadow=True, propagate_obj=False),
+                                  dict(use_shadows=False), dict(soft_shadow=True, fix_thresh=False),
+                                  dict(fix_mask=True, use_expansion=False)])
+def test_fused_propagation_has_the_bits_of_the_spelled_out_loop(dev, over):
+    """``waldo_inpaint_propagate_fwd`` + ``waldo_inpaint_blend_fwd`` (one launch per predicted frame on either side of
+    the inpainter) against the loop body of wif.py:179-214 spelled with the per-op calls (``WIF.fuse_propagate = False``:
+    three warps by one grid, two per entering object, the mask algebra in framework kernels) at 512 x 1024 with an
+    object entering through the left border, for the option sets that change the step: the same bits."""
+    from waldo_amd import _lib
+    from waldo_amd.nets import WIF, Warper
+    wopt, d, ctx_len = recipe_inpaint_inputs(tp=3)
+    opt = inpaint_opt(**over)
+    for k, v in vars(wopt).items():
+        setattr(opt, k, v)
+    lin = torch.nn.Conv2d(d["weight"].shape[1], 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(d["weight"])
+        lin.bias.copy_(d["bias"])
+    wif, warper = WIF(opt, unet=lin).to(dev), Warper(wopt).to(dev)
+    dd = {k: v.to(dev) for k, v in d.items()}
+    with torch.no_grad():
+        grid = warper(dd["obj_pose"], dd["bg_pose"])
+
+        def run():
+            return wif.inpaint(IO.stub_inpainter, dd["raw_output"].clone(), dd["alpha"], dd["alpha_ctx"], dd["real_vid"],
+                               dd["pred_flow"], ctx_len, warper, grid)
+
+        with _lib.KernelTimer() as kt:
+            fused = run()
+            torch.cuda.synchronize()
+        launched = kt.summary()
+        assert launched["waldo_inpaint_propagate_fwd"][0] == 3 and launched["waldo_inpaint_blend_fwd"][0] == 3
+        wif.fuse_propagate = False
+        with _lib.KernelTimer() as kt:
+            spelled = run()
+            torch.cuda.synchronize()
+        assert "waldo_inpaint_propagate_fwd" not in kt.summary()
+    assert torch.isfinite(fused).all() and fused.std() > 0.05
+    assert torch.equal(fused, spelled), (fused - spelled).abs().max().item()
+
+
+@pytest.mark.gpu
 def test_inpaint_timing_at_recipe_size(dev):
     """WIF.inpaint timed at BASELINE config 5's shape (512 x 1024, B = 1, 4 context + 10 predicted frames, 12 layers,
     the default option set): one JSON line (printed; written to gpurun_out/ when that directory exists -> profiles/).

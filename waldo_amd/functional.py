@@ -1179,6 +1179,62 @@ def points_in_polygon(pts, corners):
     return out > 0
 
 
+def inpaint_propagate(flow, ident, ref_img, ref_mask, shadow, entering, img, todo, obj, soft_shadow=False,
+                      fix_mask=False):
+    """One frame of the propagation loop of ``WIF.inpaint`` (models/nets/wif.py:179-211) in one launch -- the warps of
+    the reference background, its mask and the shadow mask by ``flow + ident``, the entering objects
+    (``entering``: up to two ``(region, look, flow_k)``), the fill of the frame's holes and the inpainter's inputs --
+    with the bits of the spelled-out composition.  Returns ``(img, todo, inpainter_img, inpainter_mask)``; with
+    ``fix_mask`` the inpainter takes ``img`` itself and ``inpainter_mask`` is the undilated ``1 - (1 - todo)(1 - obj)``."""
+    import ctypes
+    _lib.check_cuda(flow, ident, ref_img, ref_mask, shadow, img, todo, obj)
+    b, c, h, w = img.shape
+    if c != 3 or len(entering) > 2:
+        raise _lib.WaldoHipError(f"inpaint_propagate: {c} channels, {len(entering)} entering objects (3; at most 2)")
+    flow, ident, ref_img, ref_mask, img, todo, obj = (_c(x.detach()) for x in (flow, ident, ref_img, ref_mask, img, todo, obj))
+    shadow = _c(shadow.detach()) if shadow is not None else None
+    for x, shape in ((flow, (b, h, w, 2)), (ref_img, (b, 3, h, w)), (ref_mask, (b, 1, h, w)), (todo, (b, 1, h, w)),
+                     (obj, (b, 1, h, w))) + (((shadow, (b, 1, h, w)),) if shadow is not None else ()):
+        if tuple(x.shape) != shape:
+            raise _lib.WaldoHipError(f"inpaint_propagate: a tensor of shape {tuple(x.shape)} where {shape} is expected")
+    if ident.numel() != h * w * 2:
+        raise _lib.WaldoHipError(f"inpaint_propagate: an identity grid of shape {tuple(ident.shape)} for {h} x {w} frames")
+    keep = []  # (contiguous copies must outlive the launch's enqueue)
+    ptrs = [[], [], []]
+    for region, look, fk in entering:
+        _lib.check_cuda(region, look, fk)
+        region, look, fk = _c(region.detach().expand(b, 1, h, w)), _c(look.detach()), _c(fk.detach())
+        if tuple(look.shape) != (b, 3, h, w) or tuple(fk.shape) != (b, h, w, 2):
+            raise _lib.WaldoHipError("inpaint_propagate: an entering object's look / flow has the wrong shape")
+        keep += [region, look, fk]
+        for lst, x in zip(ptrs, (region, look, fk)):
+            lst.append(x.data_ptr())
+    arrs = [(ctypes.c_void_p * 2)(*(lst + [None] * (2 - len(lst)))) for lst in ptrs]
+    img_out, todo_out, inp_mask = torch.empty_like(img), torch.empty_like(todo), torch.empty_like(todo)
+    inp_img = None if fix_mask else torch.empty_like(img)
+    with _lib.on_device(img.device):
+        _lib.call("waldo_inpaint_propagate_fwd", _lib.ptr(flow), _lib.ptr(ident), _lib.ptr(ref_img), _lib.ptr(ref_mask),
+                  _lib.ptr(shadow), ctypes.addressof(arrs[0]), ctypes.addressof(arrs[1]), ctypes.addressof(arrs[2]),
+                  len(entering), _lib.ptr(img), _lib.ptr(todo), _lib.ptr(obj), _lib.ptr(img_out), _lib.ptr(todo_out),
+                  _lib.ptr(inp_img), _lib.ptr(inp_mask), b, h, w, int(bool(soft_shadow)), int(bool(fix_mask)),
+                  _lib.current_stream(img.device))
+    return img_out, todo_out, (img_out if fix_mask else inp_img), inp_mask
+
+
+def inpaint_blend(img, todo, fill):
+    """``(1 - todo) * img + todo * fill`` (wif.py:214) in one launch; img / fill (B, 3, H, W), todo (B, 1, H, W)."""
+    _lib.check_cuda(img, todo, fill)
+    img, todo, fill = _c(img.detach()), _c(todo.detach()), _c(fill.detach())
+    b, c, h, w = img.shape
+    if c != 3 or tuple(fill.shape) != tuple(img.shape) or tuple(todo.shape) != (b, 1, h, w):
+        raise _lib.WaldoHipError(f"inpaint_blend: shapes {tuple(img.shape)}, {tuple(todo.shape)}, {tuple(fill.shape)}")
+    out = torch.empty_like(img)
+    with _lib.on_device(img.device):
+        _lib.call("waldo_inpaint_blend_fwd", _lib.ptr(img), _lib.ptr(todo), _lib.ptr(fill), _lib.ptr(out), b, h * w,
+                  _lib.current_stream(img.device))
+    return out
+
+
 _EXPAND_STEPS = {None: 15, "": 15, "south": 1, "north": 2, "east": 4, "west": 8}
 
 

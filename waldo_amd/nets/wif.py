@@ -39,6 +39,7 @@ class WIF(nn.Module):
         self.ab = opt.ii_ab
         self.opt = opt
         self.unet = unet
+        self.fuse_propagate = True  # WIF.inpaint's per-frame propagation as one launch (False: the spelled-out loop)
         if hasattr(opt, "dim"):  # the HD identity grid `inpaint` warps against (wif.py:29-31)
             shape = [opt.dim, int(opt.dim * opt.aspect_ratio)]
             if getattr(opt, "load_dim", 0) > 0:
@@ -181,8 +182,20 @@ class WIF(nn.Module):
                                                                    real_vid, ctx_len, warper, grid, ref)
             entering = self._border_objects(inpainter, raw_output, alpha_ctx, pred_flow, ctx_len, warper, grid,
                                             ref) if o.propagate_obj else []
+            fused = self.fuse_propagate and len(entering) <= 2 and all(x.dtype == torch.float32 for x in (ref_img, mask))
             for t in range(tp):
                 img, todo = frames[t].squeeze(1), mask[:, t]
+                if fused:  # the rest of this loop body as two launches around the inpainter (csrc/inpaint_ops.hip)
+                    img, todo, inp_img, inp_mask = WF.inpaint_propagate(
+                        ref_to_pred[:, t], self.src_grid_hd, ref_img, ref_mask, shadow if o.use_shadows else None,
+                        [(region, look, flow[:, t]) for region, look, flow in entering], img, todo, obj_mask[:, t],
+                        soft_shadow=o.soft_shadow, fix_mask=o.fix_mask)
+                    if o.fix_mask:
+                        fill = inpainter(inp_img, expand(inp_mask, 3), exp=False, is_masked=False)
+                    else:
+                        fill = inpainter(inp_img, inp_mask)
+                    frames[t] = WF.inpaint_blend(img, todo, fill).unsqueeze(1)
+                    continue
                 w_img = self._warp(ref_img, ref_to_pred[:, t])
                 w_mask = self._warp_mask(ref_mask, ref_to_pred[:, t])
                 for region, look, flow in entering:
