@@ -27,10 +27,11 @@ constexpr int kExpSide = kExpTile + 2 * kExpMaxNum;
 constexpr int kExpPitch = kExpSide + 1;  // odd: a thread per ROW walks conflict-free
 constexpr int kExpThreads = 128;
 
-// torch.maximum(d, alpha * s): a NaN on either side wins.  HARD: both are 0 / 1 and alpha is 1 -- an OR.
+// torch.maximum(d, alpha * s): a NaN on either side wins.  HARD: both are 0.0 / 1.0 and alpha is 1 -- an OR of the bits
+// (one instruction; fmaxf costs three: the compiler quiets both operands first).
 template <bool HARD>
 __device__ __forceinline__ float expand_combine(float d, float s, float alpha) {
-  if (HARD) return fmaxf(d, s);
+  if (HARD) return __uint_as_float(__float_as_uint(d) | __float_as_uint(s));
   const float v = alpha * s;
   return __builtin_isunordered(d, v) ? d + v : fmaxf(d, v);
 }
@@ -40,32 +41,57 @@ __device__ __forceinline__ float expand_combine(float d, float s, float alpha) {
 // `fwd` = the north / west step, in that order, as whole-line steps:  s(i) = combine(m(i), m(i - 1)),
 // out(i) = combine(s(i), s(i + 1)).  The walk writes out(i) in place BEHIND itself and reads ahead of itself, eight
 // cells per trip so that the eight LDS reads are in flight together (one read per cell, each waiting for the store
-// before it, made a 30-round growth 0.69 ms).
-template <bool HARD>
-__device__ __forceinline__ void expand_line(float* p, int step, int n, bool lo, bool hi, bool back, bool fwd,
-                                            float alpha) {
-  if (n <= 0) return;
+// before it, made a 30-round growth 0.69 ms); trips that lie inside the line -- all but the last -- carry no per-cell
+// tests (a wavefront issues one vector instruction per four cycles and two wavefronts walk a tile: the instruction
+// count per cell IS the kernel's time).
+template <bool HARD, bool BACK, bool FWD>
+__device__ __forceinline__ void expand_line_steps(float* p, int step, int n, bool lo, bool hi, float alpha) {
   constexpr int kTrip = 8;
   const float before = lo ? p[-step] : 0.0f;      // m(-1), old
   float cur = p[0];                               // m(i), old
-  float s_cur = (back && lo) ? expand_combine<HARD>(cur, before, alpha) : cur;
+  float s_cur = (BACK && lo) ? expand_combine<HARD>(cur, before, alpha) : cur;
   const int last = hi ? n : n - 1;                // the last cell that may be read
-  for (int i0 = 0; i0 < n; i0 += kTrip) {
+  int i0 = 0;
+  for (; i0 + kTrip <= last; i0 += kTrip) {       // cells i0 .. i0 + 7 all have a next cell
     float nxt[kTrip];
 #pragma unroll
-    for (int k = 0; k < kTrip; ++k) nxt[k] = (i0 + k + 1 <= last) ? p[(i0 + k + 1) * step] : 0.0f;  // m(i + 1), old
+    for (int k = 0; k < kTrip; ++k) nxt[k] = p[(i0 + k + 1) * step];  // m(i + 1), old
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) {
+      const float s_next = BACK ? expand_combine<HARD>(nxt[k], cur, alpha) : nxt[k];
+      p[(i0 + k) * step] = FWD ? expand_combine<HARD>(s_cur, s_next, alpha) : s_cur;
+      cur = nxt[k];
+      s_cur = s_next;
+    }
+  }
+  for (; i0 < n; i0 += kTrip) {
+    float nxt[kTrip];
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) nxt[k] = (i0 + k + 1 <= last) ? p[(i0 + k + 1) * step] : 0.0f;
 #pragma unroll
     for (int k = 0; k < kTrip; ++k) {
       const int i = i0 + k;
       if (i < n) {
         const bool has_next = i + 1 <= last;
-        const float s_next = (back && has_next) ? expand_combine<HARD>(nxt[k], cur, alpha) : nxt[k];
-        p[i * step] = (fwd && has_next) ? expand_combine<HARD>(s_cur, s_next, alpha) : s_cur;
+        const float s_next = (BACK && has_next) ? expand_combine<HARD>(nxt[k], cur, alpha) : nxt[k];
+        p[i * step] = (FWD && has_next) ? expand_combine<HARD>(s_cur, s_next, alpha) : s_cur;
         cur = nxt[k];
         s_cur = s_next;
       }
     }
   }
+}
+
+template <bool HARD>
+__device__ __forceinline__ void expand_line(float* p, int step, int n, bool lo, bool hi, bool back, bool fwd,
+                                            float alpha) {
+  if (n <= 0) return;
+  if (back && fwd)
+    expand_line_steps<HARD, true, true>(p, step, n, lo, hi, alpha);
+  else if (back)
+    expand_line_steps<HARD, true, false>(p, step, n, lo, hi, alpha);
+  else
+    expand_line_steps<HARD, false, true>(p, step, n, lo, hi, alpha);
 }
 
 template <bool HARD>
