@@ -182,7 +182,9 @@ class WIF(nn.Module):
                                                                    real_vid, ctx_len, warper, grid, ref)
             entering = self._border_objects(inpainter, raw_output, alpha_ctx, pred_flow, ctx_len, warper, grid,
                                             ref) if o.propagate_obj else []
-            fused = self.fuse_propagate and len(entering) <= 2 and all(x.dtype == torch.float32 for x in (ref_img, mask))
+            # (the kernels carry no gradient: under autograd with a differentiable frame the spelled-out loop runs)
+            fused = (self.fuse_propagate and len(entering) <= 2 and all(x.dtype == torch.float32 for x in (ref_img, mask))
+                     and not (torch.is_grad_enabled() and any(x.requires_grad for x in (*frames, ref_img))))
             for t in range(tp):
                 img, todo = frames[t].squeeze(1), mask[:, t]
                 if fused:  # the rest of this loop body as two launches around the inpainter (csrc/inpaint_ops.hip)
