@@ -353,6 +353,36 @@ def test_fused_propagation_has_the_bits_of_the_spelled_out_loop(dev, over):
 
 
 @pytest.mark.gpu
+def test_fused_propagation_two_clips(dev):
+    """The same comparison for a batch of two clips (``propagate_obj`` off: the border-object branch is one clip only, in
+    the reference too): the per-clip planes of the fused step are strided slices of (B, Tp, ...) tensors."""
+    from waldo_amd.nets import WIF, Warper
+    wopt, d1, ctx_len = recipe_inpaint_inputs(seed=31, tp=2)
+    _, d2, _ = recipe_inpaint_inputs(seed=47, tp=2)
+    d = {k: (torch.cat([d1[k], d2[k]], dim=0) if k not in ("weight", "bias") else d1[k]) for k in d1}
+    opt = inpaint_opt(propagate_obj=False, soft_shadow=True)
+    for k, v in vars(wopt).items():
+        setattr(opt, k, v)
+    lin = torch.nn.Conv2d(d["weight"].shape[1], 5, 1)
+    with torch.no_grad():
+        lin.weight.copy_(d["weight"])
+        lin.bias.copy_(d["bias"])
+    wif, warper = WIF(opt, unet=lin).to(dev), Warper(wopt).to(dev)
+    dd = {k: v.to(dev) for k, v in d.items()}
+    with torch.no_grad():
+        grid = warper(dd["obj_pose"], dd["bg_pose"])
+        outs = []
+        for fused in (True, False):
+            wif.fuse_propagate = fused
+            outs.append(wif.inpaint(IO.stub_inpainter, dd["raw_output"].clone(), dd["alpha"], dd["alpha_ctx"],
+                                    dd["real_vid"], dd["pred_flow"], ctx_len, warper, grid))
+        one = wif.inpaint(IO.stub_inpainter, dd["raw_output"][:1].clone(), dd["alpha"][:1], dd["alpha_ctx"][:1],
+                          dd["real_vid"][:1], dd["pred_flow"][:1], ctx_len, warper, [g[:1] for g in grid])
+    assert outs[0].shape[0] == 2 and torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[1][:1], one)  # (clips are independent)
+
+
+@pytest.mark.gpu
 def test_inpaint_timing_at_recipe_size(dev):
     """WIF.inpaint timed at BASELINE config 5's shape (512 x 1024, B = 1, 4 context + 10 predicted frames, 12 layers,
     the default option set): one JSON line (printed; written to gpurun_out/ when that directory exists -> profiles/).
