@@ -817,6 +817,42 @@ def test_short_batches_use_every_xcd_and_change_no_bit(dev, f, nl):
             assert torch.equal(a[i:i + 1], b), i
 
 
+def test_batches_beyond_four_gibibytes_change_no_bit(dev):
+    """A batch whose layer stack, gradient and record workspace each pass 4 GiB (300 frames of the headline shape:
+    5.0 GB of layers) -- 2.7 x the headline's 112 frames: every offset inside the fused forward and the two-kernel
+    backward that is kept in 32 bits must be an offset inside a plane or a frame, not inside the batch.  Frames are
+    independent: the first, a middle and the last three frames of the batch equal the same frames computed as a batch
+    of their own, bit for bit (forward, layer and control-point gradients), and the whole result is finite."""
+    from waldo_amd import functional as WF
+    import waldo_amd
+    f, nl, h, w = 300, 8, 256, 512
+    tps = waldo_amd.TPSWarp(h, w, O.get_grid(4, 4).view(-1, 2)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    layers = torch.rand(f, nl, 4, h, w, device=dev, generator=g) * 2 - 1
+    assert layers.numel() * 4 > 4 * 2 ** 30
+    pts = O.get_grid(4, 4).view(1, 16, 2).to(dev) + 0.05 * torch.randn(f * nl, 16, 2, device=dev, generator=g)
+    occ = O.compute_occ(torch.randn(f, 1, nl - 1, generator=torch.Generator().manual_seed(9)))[:, 0].to(dev)
+
+    wgt = torch.randn(f, 3, h, w, device=dev, generator=g)
+
+    def run(idx):
+        ld = layers[idx].clone().requires_grad_()
+        pd = pts.view(f, nl, 16, 2)[idx].reshape(-1, 16, 2).clone().requires_grad_()
+        rgb = WF.warp_composite(ld, pd, occ[idx], tps.inverse_kernel, tps.basis_t)
+        (rgb * wgt[idx]).sum().backward()
+        return rgb.detach(), ld.grad, pd.grad.view(-1, nl, 16, 2)
+
+    whole = run(torch.arange(f, device=dev))
+    for t in whole:
+        assert torch.isfinite(t).all()
+    probe = torch.tensor([0, 149, 297, 298, 299], device=dev)
+    part = run(probe)
+    for name, a, b in zip(("rgb", "grad_layers", "grad_pts"), whole, part):
+        assert torch.equal(a[probe], b), name
+    del whole, part, layers, wgt
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("f,nl,h,w,delta", [(8, 8, 128, 128, 0.0), (3, 5, 40, 72, 1.0), (1, 12, 64, 96, 0.0),
                                             (5, 17, 32, 64, 0.5)])
 def test_forward_from_control_points_is_one_launch_and_the_same_bits(dev, f, nl, h, w, delta):
