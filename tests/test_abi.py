@@ -65,6 +65,19 @@ def test_argument_validation_needs_no_gpu(lib_path):
     assert b"unsupported shape" in lib.waldo_last_error_string()
     rc = lib.waldo_grid_sample2d_fwd(None, None, None, 1, 0, 4, 4, 4, 4, 0.0, 1, 1, 1, 1, None)
     assert rc == -1
+    # round 6's entry points (WIF.inpaint's dilation, polygon test and propagation; InverseWarp's kernel size)
+    assert lib.waldo_mask_expand_fwd(None, None, None, 1, 8, 8, 3, 16, 0, 0.97, None) == -1       # steps: four bits
+    assert b"bad arguments" in lib.waldo_last_error_string()
+    assert lib.waldo_mask_expand_fwd(None, None, None, 1, 8, 8, 3, 15, 0, 0.97, None) == -1       # null planes
+    assert lib.waldo_mask_expand_fwd(None, None, None, 0, 8, 8, 3, 15, 0, 0.97, None) == 0        # nothing to do
+    assert lib.waldo_points_in_polygon_fwd(None, None, 17, None, 4, None) == -1                    # at most 16 corners
+    assert lib.waldo_points_in_polygon_fwd(None, None, 4, None, 0, None) == 0
+    assert lib.waldo_inpaint_propagate_fwd(*([None] * 8), 3, *([None] * 7), 1, 8, 8, 0, 0, None) == -1   # two objects at most
+    assert b"entering" in lib.waldo_last_error_string()
+    assert lib.waldo_inpaint_blend_fwd(None, None, None, None, 1, 64, None) == -1
+    args = [None] * 14 + [1, 8, 8, 8, 8, 5, 1]
+    assert lib.waldo_inverse_warp_fwd(*args, 4, None) == -1                                        # even window
+    assert b"kernel size" in lib.waldo_last_error_string()
 
 
 def test_product_has_no_cpu_fallback():
