@@ -1351,6 +1351,66 @@ def test_decode_output_glue(dev, restrict, use_disocc, include_self):
     assert lean[3] is None or not wp._fused_ok([inp.to(dev)], nl, inp.size(2) - 3)
 
 
+def test_decode_output_glue_seeded_fuzz(dev):
+    """Twenty more configurations of the ``estimate_alpha_grid_occ`` -> ``decode_output`` glue from a seeded generator
+    (1 ... 12 objects, x1 ... x4 rasters, 2 ... 21 classes, 1 ... 2 clips, the restrict / use_disocc / include_self
+    branches, the option sets, padding masks) against the oracle in fp32 and fp64 -- the seven outputs of
+    lvd.py:141-153, the lean form (``return_alpha = False``) bit for bit."""
+    import random
+    from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
+    rng = random.Random(19)
+    names = ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")
+    for case in range(20):
+        include_self = rng.random() < 0.3
+        restrict = True if include_self else rng.random() < 0.6
+        use_disocc = rng.random() < 0.5
+        dim, s = rng.choice([8, 12, 16]), rng.choice([0, 1, 2, 3, 4])
+        over = dict(num_obj=rng.randint(1, 12), dim=dim, load_dim=dim * s, allow_ghost=rng.random() < 0.3,
+                    weight_cls=rng.random() < 0.4, no_filter=rng.random() < 0.2, include_self=include_self)
+        over["min_cls"] = 0.05 if over["weight_cls"] else 0.0
+        opt = opt_ns(**over)
+        cfg = WO.WarperCfg.from_opt(opt)
+        wp = Warper(opt).to(dev)
+        b, tc = rng.randint(1, 2), rng.randint(1, 3)
+        t = tc + rng.randint(1, 2)
+        nl = rng.choice([2, 5, 20, 21])
+        what = f"case {case}: {over} restrict={restrict} use_disocc={use_disocc} b={b} t={t} tc={tc} nl={nl}"
+        obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=300 + case)
+        g = torch.Generator().manual_seed(case)
+        tp = t if include_self else t - tc
+        ctx_ts = torch.randint(0, tc, (b, tc, tp), generator=g)
+        pred_ts = torch.arange(t) if include_self else torch.arange(tc, t)
+        occ_score = torch.randn(b, t, cfg.num_obj, generator=g)
+        mask = (torch.rand(1, 1, 1, *cfg.tgt_shape, generator=g) > 0.2).float()
+        masked = mask * obj_alpha + (1 - mask) * -1.0
+        try:
+            with torch.no_grad():
+                grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
+                ref = WO.decode_output(cfg, inp, grid_o, O.compute_occ(occ_score), masked, bg_alpha, cls, ctx_ts, pred_ts,
+                                       restrict, use_disocc)
+                ref64 = WO.decode_output(cfg, *dbl((inp, grid_o, O.compute_occ(occ_score), masked, bg_alpha, cls)), ctx_ts,
+                                         pred_ts, restrict, use_disocc)
+                occ_h, oa_h, ba_h, grid_h = estimate_alpha_grid_occ(wp, obj_alpha.to(dev), bg_alpha[:1].to(dev),
+                                                                    obj_pose.to(dev), bg_pose.to(dev), occ_score.to(dev),
+                                                                    obj_alpha_mask=mask.to(dev))
+                close(occ_h, O.compute_occ(occ_score), what="occ")
+                close(grid_h[0], grid_o[0], what="tgo")
+                close(grid_h[2], grid_o[2], what="tgb")
+                args = (inp.to(dev), [x.to(dev) for x in grid_o], occ_h, oa_h, ba_h, cls.to(dev), ctx_ts.to(dev),
+                        pred_ts.to(dev), restrict, use_disocc)
+                got = decode_output(wp, *args)
+                wp.return_alpha = False
+                lean = decode_output(wp, *args)
+            for x, y, z, name in zip(got, ref, ref64, names):
+                close(x, y, what=name, exact=z)
+            for x, y, name in zip(lean, got, names):
+                if name in ("alpha_unflt", "alpha") and x is None:
+                    continue
+                assert (x is None and y is None) or torch.equal(x, y), "lean " + name
+        except AssertionError as exc:
+            raise AssertionError(f"{what}: {exc}") from exc
+
+
 def test_warper_state_dict_names(dev):
     """Buffer names / shapes survive, so a reference checkpoint's warper.* entries load."""
     from waldo_amd.nets import Warper
