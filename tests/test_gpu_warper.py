@@ -822,7 +822,7 @@ def _hd_backward_case(dev, opt, ctx_only, include_self, b, t, nl, seed, per_op=T
             close(grads[False][i], g_o[i], rel=True, what=f"per-op vs oracle: grad {name}", exact=g_64[i])
 
 
-def _recipe_size_case(dev, ctx_only):
+def _recipe_size_case(dev, ctx_only, recipe="cityscapes"):
     """The reference's real Cityscapes recipe R (scripts/cityscapes/train_wif.sh:12-14,28): L = 17 layers, Nl = 20
     classes, 128x256 -> 512x1024, B = 1, Tc = 4, Tp = 1 -- the fused passes of grid_to_flow_ctx (``ctx_only``:
     --s_restrict_to_ctx, what demo.sh / test.sh pass: alphas composited on the Tc context frames, ghost mask) or of the
@@ -830,16 +830,24 @@ def _recipe_size_case(dev, ctx_only):
     input_to_output, at full size against the CPU oracle in fp32 and fp64 (which materialises the reference's multi-GB
     broadcasts; ~1-2 min on the host)."""
     from waldo_amd.nets import Warper
-    opt = opt_ns(num_obj=16, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=512,
-                 aspect_ratio=2, use_lyt_filtering=True)
+    if recipe == "kitti":
+        # scripts/kitti/*.sh (BASELINE config 4): 128 x 416 layers -> 256 x 832 frames (x2: the <8, ., 2> instances, a
+        # width of 13 x 64 pixels), 7 objects + background, 8 x 26 background control points, two predicted frames
+        opt = opt_ns(num_obj=7, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 26], dim=128, load_dim=256,
+                     aspect_ratio=3.25, use_lyt_filtering=True, weight_cls=True, min_cls=0.1)
+        t, tp, tag = 6, 2, "KITTI size"
+    else:
+        opt = opt_ns(num_obj=16, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=512,
+                     aspect_ratio=2, use_lyt_filtering=True)
+        t, tp, tag = 5, 1, "R size"
     cfg = WO.WarperCfg.from_opt(opt)
     wp = Warper(opt).to(dev)
-    b, t, nl = 1, 5, 20
+    b, nl = 1, 20
     obj_pose, bg_pose, inp, occ, obj_alpha, bg_alpha, cls = _warper_inputs(cfg, b, t, nl, seed=21 if ctx_only else 22)
-    ctx_ts = torch.arange(4).view(1, 4, 1)
-    pred_ts = torch.tensor([4])
+    ctx_ts = torch.arange(4).view(1, 4, 1).expand(1, 4, tp).contiguous()
+    pred_ts = torch.arange(4, t)
     fo = WO.grid_to_flow_ctx if ctx_only else WO.grid_to_flow
-    tag = "R size, restricted" if ctx_only else "R size, UNRESTRICTED"
+    tag += ", restricted" if ctx_only else ", UNRESTRICTED"
     with torch.no_grad():
         grid_o = WO.warper_grids(cfg, obj_pose, bg_pose)
         ro = fo(cfg, inp, grid_o, occ, obj_alpha, bg_alpha, cls, ctx_ts, pred_ts)
@@ -857,8 +865,10 @@ def _recipe_size_case(dev, ctx_only):
         # the flow's tolerance a second time, not this kernel
         out_f, raw_f = wp.input_to_output(args[0], ro[3].to(dev), ro[0].to(dev), args[6])
     wp.check_time_indices()
-    assert rf[0].shape == (1, 4, 1, 2, 512, 1024) and rf[3].shape == (1, 4, 1, 17, 512, 1024)
-    assert rf[2].shape == (1, 4 if ctx_only else 5, 17, 512, 1024)  # `alpha`: on the context frames / on all T frames
+    hd, wd = cfg.src_shape_hd
+    nlay = cfg.num_obj + 1
+    assert rf[0].shape == (1, 4, tp, 2, hd, wd) and rf[3].shape == (1, 4, tp, nlay, hd, wd)
+    assert rf[2].shape == (1, 4 if ctx_only else t, nlay, hd, wd)  # `alpha`: on the context frames / on all T frames
     for x, y, z, name in zip(rf, ro, r64, ("flow", "alpha_unflt", "alpha", "alpha_ctx", "disocc")):
         if y is None:
             assert x is None, name
@@ -882,6 +892,15 @@ def test_fused_hd_passes_unrestricted_at_recipe_size(dev):
     --s_restrict_to_ctx) + input_to_output at the recipe's full size: the <17> tall-tile / four-pixels-per-thread
     instances with the alphas composited on all T = 5 frames and no ghost mask."""
     _recipe_size_case(dev, ctx_only=False)
+
+
+@pytest.mark.parametrize("ctx_only", [True, False])
+def test_fused_hd_passes_at_kitti_size(dev, ctx_only):
+    """The same comparison at BASELINE config 4's shape -- the KITTI recipe: 128 x 416 -> 256 x 832 (x2), L = 8, 20
+    classes with class weighting, four context and two predicted frames -- restricted and unrestricted: the instances the
+    C4 pipeline runs (``flow_ctx_warp_kernel<8, ., 2>``, ``flow_ctx_alpha_kernel<8, 20>``, ``frame_warp_fuse_lds_kernel<4>``
+    on a raster 13 tiles wide) against the oracle in fp32 and fp64."""
+    _recipe_size_case(dev, ctx_only, recipe="kitti")
 
 
 @pytest.mark.parametrize("include_self", [False, True])
