@@ -836,6 +836,12 @@ def _recipe_size_case(dev, ctx_only, recipe="cityscapes"):
         opt = opt_ns(num_obj=7, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 26], dim=128, load_dim=256,
                      aspect_ratio=3.25, use_lyt_filtering=True, weight_cls=True, min_cls=0.1)
         t, tp, tag = 6, 2, "KITTI size"
+    elif recipe == "c5":
+        # BASELINE config 5 (scripts/cityscapes/demo.sh / test.sh): the Cityscapes raster with 11 objects + background
+        # (the <12, ., 4> instances of the C5 pipeline), class weighting, two predicted frames
+        opt = opt_ns(num_obj=11, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=512,
+                     aspect_ratio=2, use_lyt_filtering=True, weight_cls=True, min_cls=0.1)
+        t, tp, tag = 6, 2, "C5 size"
     else:
         opt = opt_ns(num_obj=16, obj_shape=[4, 4], patch_size=16, latent_shape=[8, 16], dim=128, load_dim=512,
                      aspect_ratio=2, use_lyt_filtering=True)
@@ -901,6 +907,12 @@ def test_fused_hd_passes_at_kitti_size(dev, ctx_only):
     C4 pipeline runs (``flow_ctx_warp_kernel<8, ., 2>``, ``flow_ctx_alpha_kernel<8, 20>``, ``frame_warp_fuse_lds_kernel<4>``
     on a raster 13 tiles wide) against the oracle in fp32 and fp64."""
     _recipe_size_case(dev, ctx_only, recipe="kitti")
+
+
+def test_fused_hd_passes_at_c5_size(dev):
+    """... and at BASELINE config 5's own shape: 512 x 1024 with L = 12 (the C5 pipeline's ``flow_ctx_warp_kernel<12, .,
+    4>`` / ``flow_ctx_alpha_kernel<12, 20>``), the restricted path demo.sh / test.sh take."""
+    _recipe_size_case(dev, True, recipe="c5")
 
 
 @pytest.mark.parametrize("include_self", [False, True])
