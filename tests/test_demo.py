@@ -117,3 +117,38 @@ def test_demo_clip_predict_chain(dev, tmp_path):
     names = set(os.listdir(tmp_path / "out"))
     assert {"rec_vid.gif", "inp_pred_vid.gif", "pred_vid_last.png", "pred_flow_last.flo"} <= names
     assert torch.equal(res["rec_vid"], got["rec_vid"])
+
+
+def test_kitti_size_predict_chain(dev):
+    """The same stage-by-stage comparison for ONE clip of BASELINE config 4 at its own size -- the KITTI recipe of
+    waldo_amd/tools/pipeline.py (256 x 832 frames over 128 x 416 layers, 8 layers, 9 frames, 4 contexts), exactly what
+    ``bench.py --config C4 --pipeline`` times: ``demo.predict`` (merged decodes, raw slots, occupancy map, staged frame warp)
+    against the chain restated with the CPU oracle on the grids the HIP path produced, fp32 and fp64, through ``close``;
+    the inverted grids themselves with the robust measure."""
+    from waldo_amd.nets import flp
+    from waldo_amd.tools import demo
+    from waldo_amd.tools.pipeline import RECIPES, Pipeline
+    pipe = Pipeline("C4", 1, dev, seed=12)
+    opt, ctx_len, t = pipe.opt, pipe.ctx_len, pipe.frames
+    vid, lyt = pipe.vid.cpu(), pipe.lyt.cpu()
+    net = {k: v.cpu() for k, v in pipe.net.items()}
+    with torch.no_grad():
+        got = pipe()
+        buf = demo.pose_buffers(opt, dev)
+        no, lo = opt.num_obj, opt.obj_shape[0] * opt.obj_shape[1]
+        lb = opt.latent_shape[0] * opt.latent_shape[1]
+        pts = flp.obj_pose_to_points(pipe.net["pred_obj_pose"], buf["tgt_pts_obj"], buf["mul_obj"], buf["bias_obj"])
+        bgp = flp.bg_pose_to_points(pipe.net["pred_bg_pose"], buf["tgt_pts_bg"], buf["bias_bg"])
+        grid = pipe.warper(pts.view(1, t, no, lo, 2), bgp.view(1, t, 1, lb, 2))
+        hip_grid = [g.cpu() for g in grid]
+        own = oracle_predict(opt, vid, lyt, net, ctx_len)
+        assert (grid[0].cpu() - own["grid"][0]).abs().max() <= 1e-4
+        robust(grid[1], own["grid"][1], "inverted object grids (KITTI size)", tol=1e-3, share=0.02, mean_tol=5e-2)
+        robust(grid[3], own["grid"][3], "inverted background grid (KITTI size)", tol=1e-3, share=0.02, mean_tol=5e-2)
+        same32 = oracle_predict(opt, vid, lyt, net, ctx_len, grid=hip_grid)
+        same64 = oracle_predict(opt, vid, lyt, net, ctx_len, grid=hip_grid, dtype=torch.float64)
+    hd, wd = RECIPES["C4"][2], int(RECIPES["C4"][2] * RECIPES["C4"][1])
+    for key in ("rec_vid", "inp_rec_vid", "pred_vid", "inp_pred_vid"):
+        assert got[key].shape == (1, t, 3, hd, wd) and torch.isfinite(got[key]).all()
+        close(got[key], same32[key], what=key + " (KITTI size)", exact=same64[key])
+    assert torch.equal(got["pred_vid"][:, :ctx_len].cpu(), vid[:, :ctx_len])
