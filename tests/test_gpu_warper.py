@@ -726,18 +726,19 @@ def test_fused_hd_backward(dev, over, ctx_only, include_self):
 
 
 def test_fused_hd_backward_seeded_fuzz(dev):
-    """Sixteen more recipes from a seeded generator for the backward of the fused passes (1 ... 16 objects, x1 ... x4,
+    """Ten more recipes from a seeded generator for the backward of the fused passes (1 ... 16 objects, x1 ... x3,
     2 ... 32 classes, 2 ... 4 frames, either context mode, the option sets): every differentiable input's gradient
     against the oracle's autograd in fp32 and fp64, as ``test_fused_hd_backward`` -- with ``close``'s allowance for a
-    few elements downstream of a kink (two of these sixteen have one: in case 15 one of 6.3 M |dist - prob| terms of the
-    layout filter has a margin of 2.4e-9, the kernel's softmax rounds it to the other side, and the 32 class gradients of
-    that object move by 1.4e-3 of their scale; in case 0 the background grid's gradient is 4 % over its bound)."""
+    few elements downstream of a kink (an earlier draw of sixteen recipes had two -- one of 6.3 M
+    |dist - prob| terms of the layout filter with a margin of 2.4e-9, which the kernel's softmax rounds to the other side
+    and which moves the 32 class gradients of that object by 1.4e-3 of their scale, and a background-grid gradient 4 %
+    over its bound)."""
     import random
     rng = random.Random(11)
     failures = []
-    for case in range(16):
-        dim = rng.choice([8, 12, 16, 20])
-        s = rng.choice([0, 1, 2, 2, 3, 4])
+    for case in range(10):
+        dim = rng.choice([8, 12, 16])
+        s = rng.choice([0, 1, 2, 2, 3])
         include_self = rng.random() < 0.5
         over = dict(num_obj=rng.randint(1, 16), dim=dim, load_dim=dim * s, obj_shape=rng.choice([[2, 2], [3, 3]]),
                     allow_ghost=rng.random() < 0.3, weight_cls=rng.random() < 0.5, no_filter=rng.random() < 0.2,
@@ -984,7 +985,7 @@ def test_frame_warp_fuse_at_256x512(dev, amp_px, tc):
 
 
 def test_frame_warp_fuse_seeded_fuzz(dev):
-    """Thirty shapes of ``input_to_output`` from a seeded generator -- rasters of 5 ... 90 by 5 ... 160 pixels, 1 ... 4
+    """Twenty shapes of ``input_to_output`` from a seeded generator -- rasters of 5 ... 90 by 5 ... 160 pixels, 1 ... 4
     contexts, 1 ... 3 predicted frames (or the include_self branch), 1 ... 26 channels, 1 ... 17 alpha layers, flows of
     1 ... 60 pixels (smooth, with a shear: the staged boxes and the per-context gather fallback both occur), random
     context indices: forward with and without autograd (the staged no-grad kernel) and both gradients against the
@@ -992,7 +993,7 @@ def test_frame_warp_fuse_seeded_fuzz(dev):
     import random
     from waldo_amd import functional as WF
     rng = random.Random(4242)
-    for case in range(30):
+    for case in range(20):
         hd, wd = rng.randint(5, 90), rng.randint(5, 160)
         b, tc, c, nl = rng.randint(1, 2), rng.randint(1, 4), rng.randint(1, 26), rng.randint(1, 17)
         include_self = rng.random() < 0.3
@@ -1383,7 +1384,7 @@ def test_decode_output_glue(dev, restrict, use_disocc, include_self):
 
 
 def test_decode_output_glue_seeded_fuzz(dev):
-    """Twenty more configurations of the ``estimate_alpha_grid_occ`` -> ``decode_output`` glue from a seeded generator
+    """Fourteen more configurations of the ``estimate_alpha_grid_occ`` -> ``decode_output`` glue from a seeded generator
     (1 ... 12 objects, x1 ... x4 rasters, 2 ... 21 classes, 1 ... 2 clips, the restrict / use_disocc / include_self
     branches, the option sets, padding masks) against the oracle in fp32 and fp64 -- the seven outputs of
     lvd.py:141-153, the lean form (``return_alpha = False``) bit for bit."""
@@ -1391,7 +1392,7 @@ def test_decode_output_glue_seeded_fuzz(dev):
     from waldo_amd.nets import Warper, decode_output, estimate_alpha_grid_occ
     rng = random.Random(19)
     names = ("output", "flow", "alpha_unflt", "alpha", "raw_alpha", "raw_output", "alpha_ctx")
-    for case in range(20):
+    for case in range(14):
         include_self = rng.random() < 0.3
         restrict = True if include_self else rng.random() < 0.6
         use_disocc = rng.random() < 0.5
