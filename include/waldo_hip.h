@@ -508,6 +508,15 @@ int waldo_inpaint_propagate_fwd(const float* flow, const float* ident, const flo
                                 int64_t B, int H, int W, int soft_shadow, int fix_mask, waldo_stream_t stream);
 int waldo_inpaint_blend_fwd(const float* img, const float* todo, const float* fill, float* out, int64_t B, int64_t HW,
                             waldo_stream_t stream);
+/* The hole and object masks of the predicted frames (wif.py:60-75) in one pass over alpha_ctx (B,Tc,Tp,L,H,W) f32 --
+ * given by its element strides over (b, tc, tp, l); the (H,W) planes contiguous, HW = H*W:
+ *   cover = sum_l (alpha_ctx + 1) / 2,  obj = the same over l >= 1  (summed as the framework's reduction sums a short
+ *   strided dimension: four accumulators j % 4, combined in order); last_only != 0: the last context's, else the maximum
+ *   over the contexts (a NaN wins);  mask (B,Tp,HW) = (1 - cover) > thresh,  obj_mask (B,Tp,HW) = obj > 0.9, as 0 / 1.
+ *   thresh: 0.1 with opt.fix_thresh, 0.9 without (wif.py:70-73). */
+int waldo_inpaint_holes_fwd(const float* alpha_ctx, int64_t stride_b, int64_t stride_tc, int64_t stride_tp,
+                            int64_t stride_l, float* mask, float* obj_mask, int64_t B, int Tc, int Tp, int L,
+                            int64_t HW, int last_only, float thresh, waldo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * A8. gather_time (models/nets/lvd.py:462-467) with the frame arithmetic of the flow synthesis

@@ -311,9 +311,42 @@ def test_inpaint_at_recipe_size(dev, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4, 3, 12, 64, 96), (2, 2, 2, 17, 33, 50), (1, 1, 1, 1, 8, 8), (1, 3, 2, 2, 16, 16),
+                                   (1, 2, 3, 5, 40, 72)])
+def test_inpaint_holes_kernel_gives_the_frameworks_mask_pixels(dev, shape):
+    """``waldo_inpaint_holes_fwd`` against wif.py:60-75 spelled with framework ops on the device -- (alpha_ctx + 1) / 2,
+    the two sums over the layers, the last context or the maximum over the contexts, the thresholds -- for a contiguous
+    ``alpha_ctx`` and for the strided raw-slot view ``decode_output`` returns, both thresholds, both context rules:
+    every mask pixel equal (the sums are taken in the reduction's own order: a thresholded sum is a pixel)."""
+    from waldo_amd import functional as WF
+    b, tc, tp, nl, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    # per pixel a coverage drawn from [0, 1.3] and split over the layers: both thresholds cut through the sums
+    cov = torch.rand(b, tc, tp, 1, h, w, generator=g) * 1.3
+    dense = 2 * (cov / nl + (torch.rand(b, tc, tp, nl, h, w, generator=g) - 0.5) * 0.1 / nl) - 1
+    big = torch.zeros(b, tp, tc, nl + 7, h, w)
+    big[:, :, :, 7:] = dense.permute(0, 2, 1, 3, 4, 5)
+    view = big.to(dev)[:, :, :, 7:].permute(0, 2, 1, 3, 4, 5)
+    assert torch.equal(view.cpu(), dense) and (not view.is_contiguous() or tc * tp * nl == 1)
+    for actx in (dense.to(dev), view):
+        for last_only in (False, True):
+            for fix_thresh in (True, False):
+                cover = ((actx + 1) / 2).sum(dim=3, keepdim=True)
+                obj = ((actx[:, :, :, 1:] + 1) / 2).sum(dim=3, keepdim=True)
+                cover, obj = (cover[:, -1], obj[:, -1]) if last_only else (cover.max(dim=1)[0], obj.max(dim=1)[0])
+                mask = 1 - cover
+                want = (mask > 0.1).float() if fix_thresh else (mask > 1 - 0.1).float()
+                want_obj = (obj > 0.9).float()
+                got, got_obj = WF.inpaint_holes(actx, last_only=last_only, fix_thresh=fix_thresh)
+                assert torch.equal(got, want) and torch.equal(got_obj, want_obj), (shape, last_only, fix_thresh)
+                if last_only:  # (the thresholds cut through the data)
+                    assert 0.005 < want.mean() < 0.995 and (nl < 5 or 0.005 < want_obj.mean() < 0.995), (want.mean(), want_obj.mean())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("over", [dict(), dict(fix_mask=True, soft_shadow=True, propagate_obj=False),
                                   dict(use_shadows=False), dict(soft_shadow=True, fix_thresh=False),
-                                  dict(fix_mask=True, use_expansion=False)])
+                                  dict(fix_mask=True, use_expansion=False), dict(ii_last_only=True)])
 def test_fused_propagation_has_the_bits_of_the_spelled_out_loop(dev, over):
     """``waldo_inpaint_propagate_fwd`` + ``waldo_inpaint_blend_fwd`` (one launch per predicted frame on either side of
     the inpainter) against the loop body of wif.py:179-214 spelled with the per-op calls (``WIF.fuse_propagate = False``:
@@ -433,12 +466,37 @@ def test_inpaint_timing_at_recipe_size(dev):
         torch.cuda.synchronize()
     table = {k: {"launches": n, "ms": round(n * ms, 4)}
              for k, (n, ms) in sorted(kt.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1])}
+    # where the call's time goes, by section of the method (device time between events around each; one extra call)
+    sections, spans = {}, []
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            spans.append((name, e0, e1))
+            return out
+        return wrapper
+
+    saved = {n: getattr(wif, n) for n in ("_holes", "forward", "_reference_background", "_border_objects")}
+    for n, fn in saved.items():
+        setattr(wif, n, timed(n, fn))
+    try:
+        run()
+        torch.cuda.synchronize()
+    finally:
+        for n in saved:
+            delattr(wif, n)
+    for name, e0, e1 in spans:
+        sections[name] = round(sections.get(name, 0.0) + e0.elapsed_time(e1), 3)
     med = sorted(times)[len(times) // 2]
     line = {"what": f"WIF.inpaint at 512x1024, B=1, Tc={ctx_len}, Tp={tp}, 12 layers, default option set (loop_ii, shadows, "
                     f"propagate_obj), stub inpainter",
             "ms_per_call_median_of_7": round(med, 3), "ms_best": round(min(times), 3), "ms_worst": round(max(times), 3),
             "ms_per_predicted_frame": round(med / tp, 3),
             "ms_in_library_calls": round(sum(r["ms"] for r in table.values()), 3),
+            "ms_by_section": sections,
             "note": "wall time per call incl. the device -> host reads of the border-object branch (hit test, object id, "
                     "polygon corners: wif.py:140-157) and the framework's mask arithmetic; library calls = the grid_sample2d "
                     "warps, the dilations, the polygon test and the WIF fusion", "entry_points": table}

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwaldo_hip.so")
 # ABI this binding was written against (include/waldo_hip.h: waldo_version() = major * 1000 + minor); a
 # library of another version has other prototypes behind the same names and is refused by load()
-ABI_VERSION = 1018
+ABI_VERSION = 1019
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -69,6 +69,7 @@ SIGNATURES = {
     "waldo_points_in_polygon_fwd": [_c_f, _c_f, _int, _c_f, _i64, _stream],
     "waldo_inpaint_propagate_fwd": [_c_f] * 8 + [_int] + [_c_f] * 7 + [_i64, _int, _int, _int, _int, _stream],
     "waldo_inpaint_blend_fwd": [_c_f] * 4 + [_i64, _i64, _stream],
+    "waldo_inpaint_holes_fwd": [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _i64, _int, _int, _int, _i64, _int, _flt, _stream],
     "waldo_warp_composite_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,
                                  _flt, _stream],
     "waldo_warp_composite_pts_fwd": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _int, _int, _int, _int,

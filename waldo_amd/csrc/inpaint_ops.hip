@@ -88,6 +88,46 @@ __global__ __launch_bounds__(kBlock) void inpaint_propagate_kernel(
   }
 }
 
+// The hole and object masks of the predicted frames (wif.py:60-75):
+//     cover = sum_l (alpha_ctx + 1) / 2,  obj = the same over the object layers l >= 1        (per context tc)
+//     the last context's, or the maximum over the contexts;  mask = (1 - cover) > thr,  obj_mask = obj > 0.9
+// The framework reads the (B, Tc, Tp, L, H, W) tensor -- 1 GB at the Cityscapes recipe with ten predicted frames --
+// five times (two shifted copies, two sums, the slice): 1.9 ms of an 8 ms call.  Here every plane is read once.  The
+// sums are taken as the framework's reduction takes them over a short strided dimension -- element j into accumulator
+// j % 4, the four combined in order ((a0 + a1) + a2) + a3 (tools_dev/sum_order_probe.py: 100 % of 1.5 M sums equal,
+// 47 % for a sequential sum) -- because a thresholded sum is a mask pixel.
+struct CtxStrides {
+  int64_t b, tc, tp, l;  // element strides of alpha_ctx (B, Tc, Tp, L, H, W); the (H, W) planes are contiguous
+};
+
+__global__ __launch_bounds__(kBlock) void inpaint_holes_kernel(const float* __restrict__ actx, CtxStrides st,
+                                                               float* __restrict__ mask, float* __restrict__ obj_mask,
+                                                               int Tc, int Tp, int L, int64_t HW, int last_only,
+                                                               float thresh, int tiles) {
+  const int64_t u = blockIdx.x / tiles;  // (b, tp)
+  const int64_t p = (int64_t)(blockIdx.x % tiles) * kBlock + threadIdx.x;
+  if (p >= HW) return;
+  const int64_t b = u / Tp, tp = u - b * Tp;
+  const float* base = actx + b * st.b + tp * st.tp + p;
+  float cover = 0.0f, obj = 0.0f;
+  for (int tc = last_only ? Tc - 1 : 0; tc < Tc; ++tc) {
+    const float* a = base + tc * st.tc;
+    float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f}, oa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int l = 0; l < L; ++l) {
+      const float h = (a[l * st.l] + 1.0f) / 2.0f;
+      ca[l & 3] += h;
+      if (l > 0) oa[(l - 1) & 3] += h;
+    }
+    const float c = ((ca[0] + ca[1]) + ca[2]) + ca[3];
+    const float o = ((oa[0] + oa[1]) + oa[2]) + oa[3];
+    const bool first = last_only || tc == 0;
+    cover = (first || c > cover || c != c) ? c : cover;  // torch.max: a NaN wins
+    obj = (first || o > obj || o != o) ? o : obj;
+  }
+  mask[u * HW + p] = (1.0f - cover) > thresh ? 1.0f : 0.0f;
+  obj_mask[u * HW + p] = obj > 0.9f ? 1.0f : 0.0f;
+}
+
 // frames[t] = (1 - todo) img + todo fill                                                    wif.py:214
 __global__ __launch_bounds__(kBlock) void inpaint_blend_kernel(const float* __restrict__ img, const float* __restrict__ todo,
                                                                const float* __restrict__ fill, float* __restrict__ out,
@@ -142,6 +182,30 @@ extern "C" int waldo_inpaint_propagate_fwd(const float* flow, const float* ident
       flow, ident, ref_img, ref_mask, shadow, e[0], e[1], n_enter, img, todo, obj, img_out, todo_out, inp_img, inp_mask, H,
       W, soft_shadow, fix_mask, (int)tiles);
   return launch_status("waldo_inpaint_propagate_fwd");
+}
+
+extern "C" int waldo_inpaint_holes_fwd(const float* alpha_ctx, int64_t stride_b, int64_t stride_tc, int64_t stride_tp,
+                                       int64_t stride_l, float* mask, float* obj_mask, int64_t B, int Tc, int Tp, int L,
+                                       int64_t HW, int last_only, float thresh, waldo_stream_t stream) {
+  if (B < 0 || Tc < 1 || Tp < 0 || L < 1 || HW < 1 || stride_b < 0 || stride_tc < 0 || stride_tp < 0 || stride_l < 0) {
+    set_error("waldo_inpaint_holes_fwd: bad arguments B=%lld Tc=%d Tp=%d L=%d HW=%lld", (long long)B, Tc, Tp, L,
+              (long long)HW);
+    return WALDO_EINVAL;
+  }
+  if (B * Tp == 0) return WALDO_OK;
+  if (!alpha_ctx || !mask || !obj_mask) {
+    set_error("waldo_inpaint_holes_fwd: null pointer");
+    return WALDO_EINVAL;
+  }
+  const int64_t tiles = (HW + kBlock - 1) / kBlock;
+  if (B * Tp * tiles > 2147483647) {
+    set_error("waldo_inpaint_holes_fwd: problem too large for one launch");
+    return WALDO_EINVAL;
+  }
+  inpaint_holes_kernel<<<dim3((unsigned)(B * Tp * tiles)), dim3(kBlock), 0, (hipStream_t)stream>>>(
+      alpha_ctx, CtxStrides{stride_b, stride_tc, stride_tp, stride_l}, mask, obj_mask, Tc, Tp, L, HW, last_only, thresh,
+      (int)tiles);
+  return launch_status("waldo_inpaint_holes_fwd");
 }
 
 extern "C" int waldo_inpaint_blend_fwd(const float* img, const float* todo, const float* fill, float* out, int64_t B,

@@ -72,7 +72,7 @@ bool debug_option(int option) {
 #ifdef WALDO_TIMING_ONLY_BUILD
 extern "C" int waldo_version(void) { return 0; }
 #else
-extern "C" int waldo_version(void) { return 1018; }
+extern "C" int waldo_version(void) { return 1019; }
 #endif
 
 extern "C" int waldo_set_debug_option(int option, int value) {

@@ -1221,6 +1221,27 @@ def inpaint_propagate(flow, ident, ref_img, ref_mask, shadow, entering, img, tod
     return img_out, todo_out, (img_out if fix_mask else inp_img), inp_mask
 
 
+def inpaint_holes(alpha_ctx, last_only=False, fix_thresh=True):
+    """The hole and object masks of ``WIF.inpaint`` (models/nets/wif.py:60-75) from ``alpha_ctx`` (B, Tc, Tp, L, H, W)
+    in [-1, 1] in ONE pass (any strides over the first four dimensions: the raw-slot view of ``decode_output`` is taken
+    as it is): ``(mask, obj_mask)``, each (B, Tp, 1, H, W) of 0 / 1 -- before the optional expansion of wif.py:76-77.
+    The sums over the layers are taken in the order of the framework's reduction: the same mask pixels."""
+    _lib.check_cuda(alpha_ctx)
+    if alpha_ctx.dim() != 6:
+        raise _lib.WaldoHipError(f"inpaint_holes: alpha_ctx of shape {tuple(alpha_ctx.shape)} (B, Tc, Tp, L, H, W)")
+    x = alpha_ctx.detach()
+    b, tc, tp, nl, h, w = x.shape
+    if x.stride(5) != 1 or x.stride(4) != w or min(x.stride()[:4]) < 0:
+        x = x.contiguous()
+    mask = x.new_empty(b, tp, 1, h, w)
+    obj_mask = x.new_empty(b, tp, 1, h, w)
+    with _lib.on_device(x.device):
+        _lib.call("waldo_inpaint_holes_fwd", _lib.ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), _lib.ptr(mask),
+                  _lib.ptr(obj_mask), b, tc, tp, nl, h * w, int(bool(last_only)), 0.1 if fix_thresh else 0.9,
+                  _lib.current_stream(x.device))
+    return mask, obj_mask
+
+
 def inpaint_blend(img, todo, fill):
     """``(1 - todo) * img + todo * fill`` (wif.py:214) in one launch; img / fill (B, 3, H, W), todo (B, 1, H, W)."""
     _lib.check_cuda(img, todo, fill)

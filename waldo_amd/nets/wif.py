@@ -73,6 +73,12 @@ class WIF(nn.Module):
     def _holes(self, alpha_ctx):
         """Disocclusion and object masks of the predicted frames (wif.py:60-79), (B, Tp, 1, H, W)."""
         o = self.opt
+        if self.fuse_propagate and alpha_ctx.is_cuda and alpha_ctx.dtype == torch.float32:
+            # one pass over alpha_ctx instead of five (csrc/inpaint_ops.hip): the same mask pixels
+            mask, obj_mask = WF.inpaint_holes(alpha_ctx, last_only=o.ii_last_only, fix_thresh=o.fix_thresh)
+            if o.use_expansion:
+                mask = expand(mask, num=o.num_expansion) * (1 - obj_mask)
+            return mask, obj_mask
         cover = ((alpha_ctx + 1) / 2).sum(dim=3, keepdim=True)
         obj = ((alpha_ctx[:, :, :, 1:] + 1) / 2).sum(dim=3, keepdim=True)
         if o.ii_last_only:
